@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU machine)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as f:
+        return {k: f[k] for k in f.files}
+
+
+@pytest.fixture
+def golden():
+    return load_golden
+
+
+def assert_same_bits(a, b, what=""):
+    """bit-for-bit equality (NaN == NaN, -0 != +0), dtype and shape included."""
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.dtype == b.dtype, f"{what}: dtype {a.dtype} != {b.dtype}"
+    assert a.shape == b.shape, f"{what}: shape {a.shape} != {b.shape}"
+    if a.dtype.kind == "f":
+        ai, bi = a.view(f"u{a.dtype.itemsize}"), b.view(f"u{b.dtype.itemsize}")
+        # NaNs of any payload compare equal
+        both_nan = np.isnan(a) & np.isnan(b)
+        bad = (ai != bi) & ~both_nan
+    else:
+        bad = a != b
+    n = int(np.count_nonzero(bad))
+    if n:
+        idx = tuple(np.argwhere(bad)[0])
+        raise AssertionError(f"{what}: {n} of {a.size} elements differ; first at {idx}: {a[idx]!r} vs {b[idx]!r}")

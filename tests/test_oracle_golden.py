@@ -1,0 +1,172 @@
+"""The CPU oracle must reproduce the reference's own outputs bit for bit (CPU-only test).
+
+Fixtures: tests/golden/*.npz, written by tools/make_goldens.py from the reference's unmodified
+utils/fitting.py, utils/ipc_linearity.py, utils/flatutils.py, utils/reference_subtraction.py.
+"""
+
+import hashlib
+import json
+
+import numpy as np
+import pytest
+from conftest import assert_same_bits, load_golden
+
+import golden_cases as gc
+import oracle
+from oracle import finish, ipc, linearity, rampfit, refpix
+from romanimpreprocess_amd import synth
+
+
+def test_lin_known_answer():
+    # literal vector of the reference's tests/romanimpreprocess/test_linutils.py:14-48
+    g = load_golden("lin_known_answer")
+    phi, ex = linearity.legendre_series(g["z"], g["coefs"])
+    assert_same_bits(phi, g["phi"], "phi")
+    assert np.array_equal(ex, g["ex"])
+    assert np.all(np.abs(phi - g["literal"]) < 1e-6)
+
+
+@pytest.mark.parametrize("name", ["multilin_p3_g6", "multilin_p8_g8", "multilin_p8_g8_flagfirst", "multilin_p10_g16"])
+def test_multilin(name):
+    g = load_golden(name)
+    ac = linearity.attempt_corr_from_groupdq(g["groupdq"]) if bool(g["use_attempt_corr"]) else None
+    phi, dq = linearity.multilin(g["S"], g["coefs"], g["Smin"], g["Smax"], g["Sref"], g["lin_dq"],
+                                 do_not_flag_first=bool(g["do_not_flag_first"]), attempt_corr=ac)
+    assert_same_bits(phi, g["phi"], "phi")
+    assert_same_bits(dq, g["dq"], "dq")
+    assert np.count_nonzero(dq & linearity.NO_LIN_CORR) > 10  # the case does exercise the flag
+
+
+@pytest.mark.parametrize("name", ["ipc_f32", "ipc_k64", "ipc_g64", "ipc_g64_k64"])
+def test_ipc(name):
+    g = load_golden(name)
+    act = g["cube"][0, 4:-4, 4:-4]
+    gact = g["gain"][4:-4, 4:-4]
+    assert_same_bits(ipc.ipc_fwd(act, g["K"]), g["fwd"], "fwd")
+    assert_same_bits(ipc.ipc_fwd(act, g["K"], gain=gact), g["fwd_g"], "fwd_g")
+    assert_same_bits(ipc.ipc_rev(act, g["K"]), g["rev"], "rev")
+    assert_same_bits(ipc.ipc_rev(act, g["K"], gain=gact), g["rev_g"], "rev_g")
+    assert_same_bits(ipc.correct_cube(g["cube"].copy(), g["K"], g["gain"]), g["cube_gain"], "cube_gain")
+    assert_same_bits(ipc.correct_cube(g["cube"].copy(), g["K"], None), g["cube_nogain"], "cube_nogain")
+
+
+def test_weights():
+    g = load_golden("weights")
+    for tag, rp in (("g6", synth.READ_PATTERN_6), ("g8", synth.READ_PATTERN_8), ("g16", synth.READ_PATTERN_16)):
+        meta = rampfit.ma_table_meta(rp, synth.FRAME_TIME)
+        assert_same_bits(meta["tbar"], g[f"{tag}_tbar"], "tbar")
+        assert_same_bits(meta["tau"], g[f"{tag}_tau"], "tau")
+        assert_same_bits(meta["N"], g[f"{tag}_N"], "N")
+        for ef in (True, False):
+            for utag, u in (("udef", 0.4 / 1.8 / 6.5**2), ("ubig", 0.05)):
+                K = rampfit.construct_weights(u, meta, exclude_first=ef)
+                assert_same_bits(K, g[f"{tag}_{'ex' if ef else 'in'}_{utag}"], f"K {tag} {ef} {utag}")
+    # SURVEY.md appendix A.5 known answer (probe of the reference in the survey session)
+    meta = rampfit.ma_table_meta(synth.READ_PATTERN_8, 3.04)
+    K = rampfit.construct_weights(0.4 / 1.8 / 6.5**2, meta, True)
+    np.testing.assert_allclose(K, [0, -2.1932600e-03, -3.6439309e-03, -6.6932663e-03, 3.2127209e-10, 6.6932654e-03,
+                                   3.6439314e-03, 2.1932600e-03], rtol=2e-7, atol=1e-15)
+
+
+RAMPFIT = ["rampfit_g8", "rampfit_g6_custom", "rampfit_g16", "rampfit_g8_include_first", "rampfit_g8_gain64",
+           "rampfit_g4"]
+
+
+@pytest.mark.parametrize("name", RAMPFIT)
+def test_rampfit(name):
+    g = load_golden(name)
+    rp = json.loads(str(g["read_pattern"]))
+    ef = bool(g["exclude_first"])
+    jp = json.loads(str(g["jump_pars"]))
+    meta = rampfit.ma_table_meta(rp, synth.FRAME_TIME)
+    meta["nborder"] = 4
+    meta["K"] = rampfit.construct_weights(0.4 / 1.8 / 6.5**2, meta, ef)
+    assert_same_bits(meta["K"], g["K"], "K")
+    # single pass
+    loc = np.zeros_like(g["groupdq"])
+    s0, er0, ep0, smap = rampfit.fit_and_flag(g["data"], loc, g["gain"], g["read"], meta, 4, ef, None, jp)
+    assert_same_bits(s0, g["jd_slope"], "jd_slope")
+    assert_same_bits(er0, g["jd_err_read"], "jd_err_read")
+    assert_same_bits(ep0, g["jd_err_poisson"], "jd_err_poisson")
+    assert_same_bits(smap, g["jd_smap"], "jd_smap")
+    assert_same_bits(loc, g["jd_flags"], "jd_flags")
+    # full ramp_fit
+    rdq, pdq = g["groupdq"].copy(), g["pixeldq"].copy()
+    slope, er, ep = rampfit.ramp_fit(g["data"], rdq, pdq, g["gain"], g["read"], meta, ef, jp)
+    assert_same_bits(slope, g["slope"], "slope")
+    assert_same_bits(er, g["err_read"], "err_read")
+    assert_same_bits(ep, g["err_poisson"], "err_poisson")
+    assert_same_bits(rdq, g["groupdq_out"], "groupdq")
+    assert_same_bits(pdq, g["pixeldq_out"], "pixeldq")
+    assert np.count_nonzero(rdq & 4) >= 10
+
+
+@pytest.mark.parametrize("name", ["flat_f32", "flat_g64"])
+def test_flat(name):
+    g = load_golden(name)
+    pdq = g["pixeldq"].copy()
+    out = finish.get_flat(g["flat"], g["gain"], g["K"], 4, pdq)
+    assert_same_bits(out, g["flat_out"], "flat")
+    assert_same_bits(pdq, g["pixeldq_out"], "pdq")
+    with np.errstate(divide="ignore", invalid="ignore"):
+        assert_same_bits(finish.get_flat(g["flat"], g["gain"], g["K"], 4, None), g["flat_out_nopdq"], "flat nopdq")
+    assert_same_bits(finish.get_flat(g["flat"], g["gain"], g["K"], 4, g["pixeldq"].copy(), ipc_deconvolve=False),
+                     g["flat_out_noipc"], "flat noipc")
+
+
+@pytest.mark.parametrize("name", ["refpix_full_a", "refpix_full_b"])
+def test_refpix_fullframe(name):
+    g = load_golden(name)
+    c = gc.refpix_fullframe_inputs(int(g["seed"]))
+    slope = refpix.optimal_refout_slope(c["M_PINK"], c["RU_PINK"], c["C_PINK"], c["std"])
+    assert slope == float(g["slope"])
+    out, diag = refpix.correct_group(c["data"], c["dark"], c["amp33"], c["med"], slope)
+    assert_same_bits(diag["amp33_median"], g["amp33_median"], "amp33 median")
+    assert_same_bits(diag["ref_med"], g["ref_med"], "ref_med")
+    assert_same_bits(np.float32(diag["ctr"]), g["ctr"], "ctr")
+    assert_same_bits(diag["channels"][:, :2].astype(np.float32), g["bottom_top"], "channel medians")
+    assert hashlib.sha256(out.tobytes()).hexdigest() == str(g["data_sha256"])
+    assert_same_bits(out[::257], g["sample_rows"], "rows")
+    assert_same_bits(out[:, ::331], g["sample_cols"], "cols")
+
+
+def test_refpix_row_polyfit():
+    g = load_golden("refpix_row_polyfit")
+    c = gc.refpix_fullframe_inputs(int(g["seed"]))
+    image = np.zeros((4096, 4224), dtype=np.float32)
+    image[:, :4096] = c["data"] - c["dark"]
+    image, _, _ = refpix.row_step(image, 4096, False, None)
+    assert hashlib.sha256(image.tobytes()).hexdigest() == str(g["image_sha256"])
+
+
+@pytest.mark.parametrize("name", ["chain_g8", "chain_g6_prod_dtypes"])
+def test_chain_composition(name):
+    """bias -> multilin -> correct_cube -> ramp_fit -> dark-rate deconvolution -> get_flat, composed by the
+    oracle's chain, against the same composition of the reference's functions."""
+    g = load_golden(name)
+    rp = json.loads(str(g["read_pattern"]))
+    ny, nx = g["gain"].shape
+    cal = {
+        "dark": {"data": np.zeros((len(rp), ny, nx), np.float32), "dark_slope": g["dark_slope"],
+                 "dq": np.zeros((ny, nx), np.uint32)},
+        "read": {"data": g["read"]},
+        "gain": {"data": g["gain"]},
+        "linearitylegendre": {"data": g["lin_data"], "Smin": g["Smin"], "Smax": g["Smax"], "Sref": g["Sref"],
+                              "dq": g["lin_dq"]},
+        "ipc4d": {"data": g["K4d"]}, "flat": {"data": g["flat"]}, "biascorr": {"data": g["biascorr"]},
+    }
+    ramp = {"data": g["data_u16"], "amp33": None, "groupdq": g["groupdq"], "pixeldq": g["pixeldq"],
+            "read_pattern": rp, "frame_time": synth.FRAME_TIME}
+    out = oracle.calibrate_arrays(ramp, cal, stages={"refpix": False})
+    assert_same_bits(out["data"], g["cube_out"], "cube")
+    assert_same_bits(out["K"], g["K"], "K")
+    assert_same_bits(out["groupdq"], g["groupdq_out"], "groupdq")
+    assert_same_bits(out["pixeldq"], g["pixeldq_out"], "pixeldq")
+    assert_same_bits(out["flat"], g["flat_out"], "flat")
+    # finish algebra from the reference's ramp-fit planes
+    nb = 4
+    s, er, ep = finish.finish(g["slope"].copy(), g["err_read"].copy(), g["err_poisson"].copy(),
+                              g["pixeldq_before_flat"].copy(), nb, g["dark_slope_ipc"], None, g["flat_out"], None)
+    assert_same_bits(out["slope"], s, "slope")
+    assert_same_bits(out["err_read"], er, "err_read")
+    assert_same_bits(out["err_poisson"], ep, "err_poisson")

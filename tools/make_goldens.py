@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own numerics.
+
+Runs only in the build container, where the reference is mounted read-only at /root/reference
+(it never travels to the GPU machine; the fixtures do).  The reference's L3 modules
+(``utils/fitting.py``, ``utils/ipc_linearity.py``, ``utils/flatutils.py``,
+``utils/reference_subtraction.py``) are imported UNMODIFIED; only their two I/O-only imports are
+replaced by in-memory stand-ins before import:
+  * ``asdf``                       -> ``asdf.open(path)`` is a context manager returning a nested
+                                       dict of numpy arrays registered under that path;
+  * ``roman_datamodels.dqflags``   -> ``pixel`` / ``group`` Enum classes with np.uint32 members
+                                       (bit values: SURVEY.md Appendix C).
+Inputs come from ``tests/golden_cases.py``; fixtures store inputs AND outputs.
+
+Usage:  python tools/make_goldens.py [case-prefix ...]
+"""
+
+import enum
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SRC = "/root/reference/src"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+sys.dont_write_bytecode = True
+
+# ---------------------------------------------------------------- stand-ins for the I/O imports
+_STORE = {}
+
+
+class _Tree:
+    def __init__(self, tree):
+        self.tree = tree
+
+    def __enter__(self):
+        return self.tree
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _install_stubs():
+    asdf = types.ModuleType("asdf")
+    asdf.open = lambda path, *a, **k: _Tree(_STORE[path])
+    sys.modules["asdf"] = asdf
+
+    class pixel(np.uint32, enum.Enum):
+        DO_NOT_USE = 2**0
+        SATURATED = 2**1
+        JUMP_DET = 2**2
+        NO_FLAT_FIELD = 2**18
+        NO_GAIN_VALUE = 2**19
+        NO_LIN_CORR = 2**20
+        REFERENCE_PIXEL = 2**31
+
+    class group(np.uint32, enum.Enum):
+        DO_NOT_USE = 2**0
+        SATURATED = 2**1
+        JUMP_DET = 2**2
+
+    rdm = types.ModuleType("roman_datamodels")
+    dq = types.ModuleType("roman_datamodels.dqflags")
+    dq.pixel, dq.group = pixel, group
+    rdm.dqflags = dq
+    sys.modules["roman_datamodels"] = rdm
+    sys.modules["roman_datamodels.dqflags"] = dq
+
+
+def register(path, roman):
+    _STORE[path] = {"roman": roman}
+    return path
+
+
+class _Log:
+    def __init__(self):
+        self.output = ""
+
+    def append(self, s):
+        self.output += s
+
+
+_install_stubs()
+sys.path.insert(0, REF_SRC)
+from romanimpreprocess.utils import fitting as ref_fit  # noqa: E402
+from romanimpreprocess.utils import flatutils as ref_flat  # noqa: E402
+from romanimpreprocess.utils import ipc_linearity as ref_il  # noqa: E402
+from romanimpreprocess.utils import reference_subtraction as ref_rs  # noqa: E402
+
+import golden_cases as gc  # noqa: E402
+from romanimpreprocess_amd import synth  # noqa: E402
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz  {os.path.getsize(path)/1024:.0f} KiB")
+
+
+def ref_meta(read_pattern, frame_time):
+    """meta dict exactly as gen_cal_image.py:123-140 builds it (restated; that file cannot be imported)."""
+    meta = {"frame_time": frame_time, "read_pattern": read_pattern}
+    meta["ngrp"] = len(read_pattern)
+    meta["tbar"] = np.zeros(meta["ngrp"], dtype=np.float32)
+    meta["tau"] = np.zeros(meta["ngrp"], dtype=np.float32)
+    meta["N"] = np.zeros(meta["ngrp"], dtype=np.int16)
+    for i in range(meta["ngrp"]):
+        meta["N"][i] = len(read_pattern[i])
+        t0 = read_pattern[i][0]
+        meta["tbar"][i] = (t0 + (meta["N"][i] - 1) / 2.0) * frame_time
+        meta["tau"][i] = (t0 + (meta["N"][i] - 1) * (2 * meta["N"][i] - 1) / (6.0 * meta["N"][i])) * frame_time
+    return meta
+
+
+# ---------------------------------------------------------------- cases
+def case_lin_known_answer():
+    # the reference's own literal vector: tests/romanimpreprocess/test_linutils.py:9-48
+    z = np.linspace(-1.5, 1.5, 31).reshape((1, 31))
+    coefs = np.zeros((4, 1, 31))
+    coefs[3] = 1.0
+    phi, ex = ref_il._lin(z, coefs)
+    literal = np.array([-4.0, -3.4, -2.8, -2.2, -1.6, -1.0, -0.4725, -0.08, 0.1925, 0.36, 0.4375, 0.44, 0.3825,
+                        0.28, 0.1475, 0.0, -0.1475, -0.28, -0.3825, -0.44, -0.4375, -0.36, -0.1925, 0.08, 0.4725,
+                        1.0, 1.6, 2.2, 2.8, 3.4, 4.0]).reshape(phi.shape)
+    assert np.all(np.abs(phi - literal) < 1e-6)
+    save("lin_known_answer", z=z, coefs=coefs, phi=phi, ex=ex, literal=literal)
+
+
+def case_multilin():
+    for name, rp, p, seed, dnff, use_ac in (
+        ("multilin_p3_g6", synth.READ_PATTERN_6, 3, 11, True, True),
+        ("multilin_p8_g8", synth.READ_PATTERN_8, 8, 12, True, True),
+        ("multilin_p8_g8_flagfirst", synth.READ_PATTERN_8, 8, 13, False, False),
+        ("multilin_p10_g16", synth.READ_PATTERN_16, 10, 14, True, True),
+    ):
+        c = gc.lin_case(rp, p, seed)
+        f = register(f"/mem/{name}_lin.asdf", {"data": c["coefs"], "Smin": c["Smin"], "Smax": c["Smax"],
+                                               "Sref": c["Sref"], "dq": c["lin_dq"]})
+        ac = (~c["groupdq"] & ref_il.pixel.SATURATED) if use_ac else None
+        phi, dq = ref_il.multilin(c["S"], f, do_not_flag_first=dnff, attempt_corr=ac)
+        save(name, **c, do_not_flag_first=dnff, use_attempt_corr=use_ac, phi=phi, dq=dq)
+
+
+def case_ipc():
+    for name, seed, gdt, kdt in (("ipc_f32", 21, np.float32, np.float32), ("ipc_k64", 22, np.float32, np.float64),
+                                 ("ipc_g64", 23, np.float64, np.float32), ("ipc_g64_k64", 24, np.float64, np.float64)):
+        c = gc.ipc_case(seed, gdt, kdt)
+        fk = register(f"/mem/{name}_ipc.asdf", {"data": c["K"]})
+        fg = register(f"/mem/{name}_gain.asdf", {"data": c["gain"]})
+        act = c["cube"][0, 4:-4, 4:-4]
+        fwd = ref_il.ipc_fwd(act, c["K"])
+        fwd_g = ref_il.ipc_fwd(act, c["K"], gain=c["gain"][4:-4, 4:-4])
+        rev = ref_il.ipc_rev(act, c["K"])
+        rev_g = ref_il.ipc_rev(act, c["K"], gain=c["gain"][4:-4, 4:-4])
+        cube_g = c["cube"].copy()
+        log = _Log()
+        ref_il.correct_cube(cube_g, fk, log, gain_file=fg)
+        cube_n = c["cube"].copy()
+        ref_il.correct_cube(cube_n, fk, None, gain_file=None)
+        save(name, **c, fwd=fwd, fwd_g=fwd_g, rev=rev, rev_g=rev_g, cube_gain=cube_g, cube_nogain=cube_n)
+
+
+def case_weights():
+    out = {}
+    for tag, rp in (("g6", synth.READ_PATTERN_6), ("g8", synth.READ_PATTERN_8), ("g16", synth.READ_PATTERN_16)):
+        meta = ref_meta(rp, synth.FRAME_TIME)
+        out[f"{tag}_tbar"], out[f"{tag}_tau"], out[f"{tag}_N"] = meta["tbar"], meta["tau"], meta["N"]
+        for ef in (True, False):
+            for utag, u in (("udef", 0.4 / 1.8 / 6.5**2), ("ubig", 0.05)):
+                out[f"{tag}_{'ex' if ef else 'in'}_{utag}"] = ref_fit.construct_weights(u, meta, exclude_first=ef)
+    save("weights", **out)
+
+
+def case_rampfit():
+    u_def = 0.4 / 1.8 / 6.5**2
+    for name, rp, seed, ef, gdt, jp in (
+        ("rampfit_g8", synth.READ_PATTERN_8, 31, True, np.float32, None),
+        ("rampfit_g6_custom", synth.READ_PATTERN_6, 32, True, np.float32,
+         {"SthreshA": 4.0, "SthreshB": 3.0, "IthreshA": 2.0, "IthreshB": 500.0}),
+        ("rampfit_g16", synth.READ_PATTERN_16, 33, True, np.float32, None),
+        ("rampfit_g8_include_first", synth.READ_PATTERN_8, 34, False, np.float32, None),
+        ("rampfit_g8_gain64", synth.READ_PATTERN_8, 35, True, np.float64, None),
+        ("rampfit_g4", [[0], [1, 2], [3, 4, 5], [6]], 36, True, np.float32, None),
+    ):
+        c = gc.rampfit_case(rp, seed, exclude_first=ef, gain_dtype=gdt)
+        meta = ref_meta(rp, synth.FRAME_TIME)
+        meta["nborder"] = 4
+        meta["K"] = ref_fit.construct_weights(u_def, meta, exclude_first=ef)
+        if jp is not None:
+            meta["jump_detect_pars"] = jp
+        caldir = {"gain": register(f"/mem/{name}_gain.asdf", {"data": c["gain"]}),
+                  "read": register(f"/mem/{name}_read.asdf", {"data": c["read"]})}
+        rdq = c["groupdq"].copy()
+        pdq = c["pixeldq"].copy()
+        log = _Log()
+        slope, er, ep = ref_fit.ramp_fit(c["data"], rdq, pdq, meta, caldir, log, exclude_first=ef)
+        # one plain jump_detect pass too (full ramp), to pin smap and the untruncated flags
+        loc = np.zeros_like(rdq)
+        s0, er0, ep0, smap = ref_fit.jump_detect(c["data"], loc, pdq, meta, caldir, _Log(), ef, truncate_ramp=None)
+        save(name, **c, read_pattern=json.dumps(rp), exclude_first=ef, K=meta["K"],
+             jump_pars=json.dumps(jp), slope=slope, err_read=er, err_poisson=ep, groupdq_out=rdq, pixeldq_out=pdq,
+             jd_slope=s0, jd_err_read=er0, jd_err_poisson=ep0, jd_smap=smap, jd_flags=loc)
+
+
+def case_flat():
+    for name, seed, gdt in (("flat_f32", 41, np.float32), ("flat_g64", 42, np.float64)):
+        c = gc.flat_case(seed, gdt)
+        caldir = {"flat": register(f"/mem/{name}_flat.asdf", {"data": c["flat"]}),
+                  "gain": register(f"/mem/{name}_gain.asdf", {"data": c["gain"]}),
+                  "ipc4d": register(f"/mem/{name}_ipc.asdf", {"data": c["K"]})}
+        pdq = c["pixeldq"].copy()
+        out = ref_flat.get_flat(caldir, {"nborder": 4}, pdq)
+        out_nopdq = ref_flat.get_flat(caldir, {"nborder": 4}, None)
+        out_noipc = ref_flat.get_flat(caldir, {"nborder": 4}, c["pixeldq"].copy(), ipc_deconvolve=False)
+        save(name, **c, flat_out=out, pixeldq_out=pdq, flat_out_nopdq=out_nopdq, flat_out_noipc=out_noipc)
+
+
+def case_refpix():
+    """Full 4096 x 4224 frames (the reference hard-codes the geometry); inputs are regenerated from
+    the seed by golden_cases.refpix_fullframe_inputs, outputs are reduced to tables + hashes."""
+    for name, seed in (("refpix_full_a", 51), ("refpix_full_b", 52)):
+        c = gc.refpix_fullframe_inputs(seed)
+        n = 4096
+        image = np.zeros((n, n + 128), dtype=np.float32)
+        image[:, :n] = c["data"] - c["dark"]
+        image[:, -128:] = c["amp33"] - c["med"]
+        gmed = np.median(image[:, -128:])
+        image[:, -128:] -= gmed
+        cvar = c["C_PINK"] ** 2
+        slope = (c["M_PINK"] * cvar / (c["M_PINK"] ** 2 * cvar + c["RU_PINK"] ** 2
+                                       + np.median(c["std"]) ** 2 / 128 / np.log(4096)))
+        ref_med = np.array([np.median(image[r, n:]) for r in range(n)])
+        ctr = np.median(ref_med)
+        image = ref_rs.ref_subtraction_row(image, use_ref_channel=True, slope=slope)
+        after_row_hash = hashlib.sha256(image.tobytes()).hexdigest()
+        bt = np.array([[np.median(image[0:4, ch * 128:(ch + 1) * 128]), np.median(image[4092:4096, ch * 128:(ch + 1) * 128])]
+                       for ch in range(33)])
+        image = ref_rs.ref_subtraction_channel(image, use_ref_channel=True)
+        out = image[:, :n] + c["dark"]
+        save(name, seed=seed, slope=np.float64(slope), amp33_median=gmed, ref_med=ref_med.astype(np.float32),
+             ctr=np.float32(ctr), bottom_top=bt.astype(np.float32),
+             after_row_sha256=after_row_hash, image_sha256=hashlib.sha256(image.tobytes()).hexdigest(),
+             data_sha256=hashlib.sha256(out.tobytes()).hexdigest(),
+             sample_rows=out[::257].copy(), sample_cols=out[:, ::331].copy())
+    # the polyfit / border-pixel variant of the row step (reference unit test test_ref.py)
+    c = gc.refpix_fullframe_inputs(53)
+    image = np.zeros((4096, 4224), dtype=np.float32)
+    image[:, :4096] = c["data"] - c["dark"]
+    image = ref_rs.ref_subtraction_row(image, use_ref_channel=False)
+    save("refpix_row_polyfit", seed=53, image_sha256=hashlib.sha256(image.tobytes()).hexdigest(),
+         sample_rows=image[::257].copy())
+
+
+def case_chain():
+    """multilin -> correct_cube -> construct_weights -> ramp_fit -> get_flat on one small frame, composed
+    in the order of calibrateimage (gen_cal_image.py:559-629) with the reference's own functions."""
+    for name, rp, p, seed, gdt, kdt in (("chain_g8", synth.READ_PATTERN_8, 8, 61, np.float32, np.float32),
+                                        ("chain_g6_prod_dtypes", synth.READ_PATTERN_6, 3, 62, np.float32, np.float64)):
+        cal = gc.small_cal(rp, p, seed, gain_dtype=gdt, ipc_dtype=kdt)
+        ramp = synth.make_ramp(cal, read_pattern=rp, seed=seed + 1, cr_frac=0.02)
+        data = ramp["data"].astype(np.float32)
+        rdq, pdq = ramp["groupdq"].copy(), ramp["pixeldq"].copy()
+        nb = 4
+        L = cal["linearitylegendre"]
+        files = {
+            "linearitylegendre": register(f"/mem/{name}_lin.asdf", {k: L[k] for k in ("data", "Smin", "Smax", "Sref", "dq")}),
+            "gain": register(f"/mem/{name}_gain.asdf", {"data": cal["gain"]["data"]}),
+            "read": register(f"/mem/{name}_read.asdf", {"data": cal["read"]["data"]}),
+            "ipc4d": register(f"/mem/{name}_ipc.asdf", {"data": cal["ipc4d"]["data"]}),
+            "flat": register(f"/mem/{name}_flat.asdf", {"data": cal["flat"]["data"]}),
+        }
+        b = cal["biascorr"]["data"]
+        data[:, nb:-nb, nb:-nb] -= b[b.shape[0] - data.shape[0]:]
+        data, dq_lin = ref_il.multilin(data, files["linearitylegendre"], do_not_flag_first=rp[0] == [0],
+                                       attempt_corr=~rdq & ref_il.pixel.SATURATED)
+        pdq |= dq_lin
+        ref_il.correct_cube(data, files["ipc4d"], _Log(), gain_file=files["gain"])
+        meta = ref_meta(rp, synth.FRAME_TIME)
+        meta["nborder"] = nb
+        meta["K"] = ref_fit.construct_weights(0.4 / 1.8 / 6.5**2, meta, exclude_first=True)
+        slope, er, ep = ref_fit.ramp_fit(data, rdq, pdq, meta, files, _Log(), exclude_first=True)
+        dslope = np.array(cal["dark"]["dark_slope"], dtype=np.float32)[None]
+        ref_il.correct_cube(dslope, files["ipc4d"], None, gain_file=files["gain"])
+        pdq_before_flat = pdq.copy()
+        flat = ref_flat.get_flat(files, meta, pdq)
+        save(name, data_u16=ramp["data"], amp33=ramp["amp33"], groupdq=ramp["groupdq"], pixeldq=ramp["pixeldq"],
+             read_pattern=json.dumps(rp),
+             gain=cal["gain"]["data"], read=cal["read"]["data"], K4d=cal["ipc4d"]["data"], flat=cal["flat"]["data"],
+             lin_data=L["data"], Smin=L["Smin"], Smax=L["Smax"], Sref=L["Sref"], lin_dq=L["dq"],
+             biascorr=b, dark_slope=cal["dark"]["dark_slope"],
+             cube_out=data, slope=slope, err_read=er, err_poisson=ep, groupdq_out=rdq,
+             pixeldq_before_flat=pdq_before_flat, pixeldq_out=pdq, dark_slope_ipc=dslope[0], flat_out=flat, K=meta["K"])
+
+
+CASES = {
+    "lin_known_answer": case_lin_known_answer, "multilin": case_multilin, "ipc": case_ipc,
+    "weights": case_weights, "rampfit": case_rampfit, "flat": case_flat, "refpix": case_refpix,
+    "chain": case_chain,
+}
+
+if __name__ == "__main__":
+    want = sys.argv[1:] or list(CASES)
+    for k in want:
+        print(k)
+        CASES[k]()
