@@ -1,0 +1,203 @@
+/*
+ * romanhip.h -- C-ABI of libromanhip.so: the MI355X (gfx950) implementation of the per-pixel
+ * L1->L2 detector-calibration path of romanimpreprocess.
+ *
+ * The reference has no FFI layer; its seam is the Python-function level of
+ *   src/romanimpreprocess/utils/reference_subtraction.py:16,77   (ref_subtraction_channel/_row)
+ *   src/romanimpreprocess/utils/ipc_linearity.py:37,102,145,276  (ipc_fwd, ipc_rev, correct_cube, multilin)
+ *   src/romanimpreprocess/utils/fitting.py:89,258                (jump_detect, ramp_fit)
+ *   src/romanimpreprocess/utils/flatutils.py:20                  (get_flat)
+ *   src/romanimpreprocess/L1_to_L2/gen_cal_image.py:531-629      (the in-line per-pixel arithmetic of calibrateimage)
+ * Each entry point below names the reference callable it replaces.  The Python binding a
+ * reference maintainer would add is shown in INTEGRATION.md (ctypes).
+ *
+ * Conventions
+ *   - plain C types only; all arrays are C-order, dense.
+ *   - a frame has `ny` rows and `nx` science columns (4096 x 4096 in flight); the reference
+ *     pixel border is `nborder` (4); the active region is (ny-2nb) x (nx-2nb); the reference
+ *     output ("amp33") has `ny` rows x 128 columns.  nx must be a multiple of 128 when the
+ *     reference-pixel stage is used.
+ *   - the caller owns every buffer it passes; the library copies CALDIR arrays to the device at
+ *     rip_caldir_upload and owns those copies.
+ *   - `location` says where ramp/output buffers live: RIP_HOST (the library stages them through
+ *     HBM) or RIP_DEVICE (pointers into this process's HIP address space, e.g. torch tensors).
+ *   - every function returns 0 on success, a negative rip_status otherwise; rip_last_error()
+ *     gives the message.  No exceptions or longjmp cross this boundary.
+ *   - one rip_ctx per GPU; a ctx is not thread-safe (one calling thread at a time).
+ */
+#ifndef ROMANHIP_H
+#define ROMANHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RIP_VERSION 100 /* 0.1.0 */
+#define RIP_MAX_GROUPS 64
+#define RIP_CHANNEL_WIDTH 128
+
+typedef struct rip_ctx rip_ctx;
+
+typedef enum { RIP_OK = 0, RIP_EINVAL = -1, RIP_ENOMEM = -2, RIP_EHIP = -3, RIP_ESTATE = -4 } rip_status;
+typedef enum { RIP_F32 = 0, RIP_F64 = 1, RIP_U16 = 2 } rip_dtype;
+typedef enum { RIP_HOST = 0, RIP_DEVICE = 1 } rip_location;
+
+/* stages of the chain (bit mask), in the order of calibrateimage (gen_cal_image.py:531-629) */
+enum {
+    RIP_STAGE_REFPIX = 1 << 0,  /* :531-556  reference-pixel row/channel correction              */
+    RIP_STAGE_BIAS = 1 << 1,    /* :559-565  data[act] -= biascorr                                  */
+    RIP_STAGE_LIN = 1 << 2,     /* :580-588  multilin + pdq |= dq_lin                               */
+    RIP_STAGE_IPC = 1 << 3,     /* :594-597  correct_cube                                           */
+    RIP_STAGE_RAMPFIT = 1 << 4, /* :600      ramp_fit (slope, errors, jump flags, flag propagation) */
+    RIP_STAGE_DARK = 1 << 5,    /* :603      slope[act] -= IPC-deconvolved dark rate                 */
+    RIP_STAGE_FLAT = 1 << 6,    /* :616-629  get_flat flags + divide by flat/AreaFactor              */
+    RIP_STAGE_ALL = 0x7f
+};
+
+/* ---- CALDIR arrays of one SCA (host pointers) ------------------------- */
+typedef struct {
+    int32_t ny, nx, nborder;
+    /* dark file: data (ngrp_dark,ny,nx) f32, dark_slope (ny,nx) f32, dq (ny,nx) u32 or NULL */
+    int32_t ngrp_dark;
+    const float *dark_data;
+    const float *dark_slope;
+    const uint32_t *dark_dq;
+    /* read file: data (ny,nx) f32; amp33.med (ny,128) f32 or NULL; refout_slope = the scalar of
+       gen_cal_image.py:542-553 (computed by the host from M_PINK, RU_PINK, C_PINK, median(std)) */
+    const float *read_noise;
+    const float *amp33_med;
+    double refout_slope;
+    /* gain file: data (ny,nx), f32 or f64 */
+    const void *gain;
+    int32_t gain_dtype;
+    /* linearitylegendre file: data (lin_nplanes,ny,nx) f32; Smin,Smax,Sref (ny,nx) f32; dq u32 */
+    int32_t lin_nplanes;
+    const float *lin_coefs;
+    const float *lin_smin, *lin_smax, *lin_sref;
+    const uint32_t *lin_dq;
+    /* ipc4d file: data (3,3,ny-2nb,nx-2nb), f32 or f64; NULL = no IPC correction */
+    const void *ipc4d;
+    int32_t ipc_dtype;
+    /* flat (pflat) file: data (ny,nx) f32; NULL = no flat division */
+    const float *flat;
+    /* biascorr file: data (ngrp_bias,ny-2nb,nx-2nb) f32; NULL = skip */
+    int32_t ngrp_bias;
+    const float *biascorr;
+} rip_caldir_desc;
+
+/* ---- ramp-fit plan: MA table, weights, thresholds (host scalars) --- */
+typedef struct {
+    int32_t ngrp;
+    int32_t exclude_first;     /* config EXCLUDE_FIRST (gen_cal_image.py:142, fitting.py:159-161)     */
+    int32_t do_not_flag_first; /* read_pattern[0] == [0] (gen_cal_image.py:583-584)                   */
+    float tbar[RIP_MAX_GROUPS]; /* meta["tbar"], f32 (gen_cal_image.py:137)                           */
+    float tau[RIP_MAX_GROUPS];  /* meta["tau"],  f32 (:138)                                            */
+    int16_t nreads[RIP_MAX_GROUPS]; /* meta["N"], int16 (:135)                                          */
+    float K[RIP_MAX_GROUPS];    /* fitting.construct_weights(...) cast f32 (fitting.py:86)             */
+    /* per fit variant v: v = 0 is the full ramp; v = 1.. are ramps truncated to [0, g_v) for
+       g_v = ngrp-1 ... 3+start (fitting.py:326).  coef = Poisson coefficient (fitting.py:196-200),
+       rfac = sqrt(sum K^2/N) (fitting.py:209); both f32 scalars computed by the host exactly as the
+       reference computes them. */
+    int32_t nvariants;
+    int32_t variant_g[RIP_MAX_GROUPS];
+    float variant_coef[RIP_MAX_GROUPS];
+    float variant_rfac[RIP_MAX_GROUPS];
+    /* jump thresholds (fitting.py:172-184) */
+    double sthresh_a, sthresh_b, ithresh_a, ithresh_b;
+} rip_plan_desc;
+
+/* ---- one ramp in, one calibrated image out ---------------------------------------------- */
+typedef struct {
+    int32_t location;      /* rip_location of every pointer in this struct                             */
+    int32_t ngrp;
+    const void *data;      /* (ngrp,ny,nx) u16 (Level-1) or f32 (after dq-init)                        */
+    int32_t data_dtype;    /* RIP_U16 or RIP_F32                                                       */
+    const uint16_t *amp33; /* (ngrp,ny,128) or NULL                                                    */
+    const uint8_t *groupdq;  /* (ngrp,ny,nx) after dq-init + saturation flagging                       */
+    const uint32_t *pixeldq; /* (ny,nx)                                                                */
+    const double *area_factor; /* (ny,nx) f64 pixel-area ratio (gen_cal_image.py:618-622) or NULL = 1  */
+    /* optional override of the channel-step line fit: (ngrp,nx/128,2) f64 (m,c) computed by the
+       host with LAPACK exactly as reference_subtraction.py:57-60; NULL = fitted on the device */
+    const double *channel_lines;
+} rip_ramp_desc;
+
+typedef struct {
+    int32_t location;
+    float *slope;        /* (ny,nx) DN/s                                  */
+    float *err_read;     /* (ny,nx)                                       */
+    float *err_poisson;  /* (ny,nx)                                       */
+    uint32_t *pixeldq;   /* (ny,nx)                                       */
+    uint8_t *groupdq;    /* (ngrp,ny,nx) or NULL                          */
+    float *cube;         /* (ngrp,ny,nx) corrected cube (after the last cube stage run) or NULL */
+} rip_outputs;
+
+/* ---- life cycle ------------------------------------------------------------------------- */
+int rip_version(void);
+int rip_ctx_create(int device_id, rip_ctx **out);
+void rip_ctx_destroy(rip_ctx *ctx);
+const char *rip_last_error(const rip_ctx *ctx); /* ctx may be NULL: message of the last failed create */
+int rip_synchronize(rip_ctx *ctx);
+/* the HIP stream all work of this ctx is enqueued on (hipStream_t as void*) */
+void *rip_stream(rip_ctx *ctx);
+
+/* CALDIR: replaces the per-call asdf.open(caldir[...]) of the reference with device-resident
+   copies (plus the per-SCA constants derived from them: IPC-deconvolved dark rate
+   gen_cal_image.py:217-221 and the flat of flatutils.get_flat) */
+int rip_caldir_upload(rip_ctx *ctx, int sca_slot, const rip_caldir_desc *desc);
+int rip_caldir_drop(rip_ctx *ctx, int sca_slot);
+
+/* plan: replaces meta{ngrp,N,tbar,tau,K,jump_detect_pars} of gen_cal_image.py:123-145,439-444 */
+int rip_plan_create(rip_ctx *ctx, const rip_plan_desc *desc, int *plan_id);
+int rip_plan_destroy(rip_ctx *ctx, int plan_id);
+
+/* the chain: replaces gen_cal_image.py:531-629 (stages selects a sub-chain).  Asynchronous with
+   respect to the host when location == RIP_DEVICE (use rip_synchronize / the stream). */
+int rip_calibrate(rip_ctx *ctx, int sca_slot, int plan_id, unsigned stages, const rip_ramp_desc *in,
+                  const rip_outputs *out);
+
+/* ---- stage-level entry points (host arrays; for function-level drop-in and parity tests) ----- */
+
+/* reference_subtraction.ref_subtraction_row(image, use_ref_channel=True, slope) followed by
+   ref_subtraction_channel(image, use_ref_channel=True) on one (ny, nx+128) f32 image, in place.
+   do_row / do_channel select the steps; medians out (optional): ref_med (ny) f32, ctr (1) f32,
+   bottom_top (nx/128+1, 2) f32; lines in (optional, (nx/128+1,2) f64 (m,c)) override the fit. */
+int rip_stage_refpix_image(rip_ctx *ctx, float *image, int ny, int nx, double slope, int do_row, int do_channel,
+                           const double *lines, float *ref_med, float *ctr, float *bottom_top);
+
+/* ipc_linearity.multilin: S (ngrp,ny,nx) f32 -> phi (ngrp,ny,nx) f32, dq (ny,nx) u32.
+   attempt_corr (ngrp,ny,nx) u8 nonzero = flag when extrapolated, or NULL = all. */
+int rip_stage_multilin(rip_ctx *ctx, const float *S, int ngrp, int ny, int nx, int nplanes, const float *coefs,
+                       const float *smin, const float *smax, const float *sref, const uint32_t *lin_dq,
+                       int do_not_flag_first, const uint8_t *attempt_corr, float *phi, uint32_t *dq);
+
+/* ipc_linearity.ipc_fwd / ipc_rev on one (ny,nx) image with kernel (3,3,ny,nx); gain NULL or (ny,nx).
+   image/out dtype = img_dtype (f32|f64); kernel k_dtype; gain g_dtype; out dtype = promote(all). */
+int rip_stage_ipc_image(rip_ctx *ctx, int reverse, int order, const void *image, int img_dtype, int ny, int nx,
+                        const void *kernel, int k_dtype, const void *gain, int g_dtype, void *out);
+
+/* ipc_linearity.correct_cube: data (ngrp,ny,nx) f32 in place; kernel (3,3,ny-2nb,nx-2nb); gain (ny,nx) or NULL */
+int rip_stage_correct_cube(rip_ctx *ctx, float *data, int ngrp, int ny, int nx, int nb, const void *kernel,
+                           int k_dtype, const void *gain, int g_dtype);
+
+/* fitting.ramp_fit: data (ngrp,ny,nx) f32; rdq u8 and pdq u32 updated in place; outputs (ny,nx) f32 */
+int rip_stage_ramp_fit(rip_ctx *ctx, int plan_id, const float *data, uint8_t *rdq, uint32_t *pdq, int ny, int nx,
+                       int nb, const void *gain, int g_dtype, const float *read_noise, float *slope,
+                       float *err_read, float *err_poisson);
+
+/* flatutils.get_flat: flat (ny,nx) f32, gain, kernel; pdq updated in place (may be NULL) */
+int rip_stage_get_flat(rip_ctx *ctx, const float *flat, int ny, int nx, int nb, const void *gain, int g_dtype,
+                       const void *kernel, int k_dtype, int ipc_deconvolve, uint32_t *pdq, float *out);
+
+/* ---- diagnostics ------------------------------------------------------------------------- */
+/* relative half-width of the band around the jump threshold inside which the significance is
+   re-evaluated in the reference's exact operation order (default 1e-5; INFINITY = always exact).
+   Results do not depend on it unless it is set below ~1e-6; it exists so that tests can force
+   either path. */
+void rip_set_guard_band(double rel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROMANHIP_H */

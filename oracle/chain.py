@@ -40,13 +40,14 @@ def calibrate_arrays(ramp, cal, exclude_first=True, ramp_opt_pars=None, jump_par
     # reference pixels (gen_cal_image.py:531-556)
     rd = cal["read"]
     a33 = rd.get("amp33")
+    refdiag = None
     if stages is not None and not stages.get("refpix", True):
         pass
     elif a33 is not None:
         slope_ref = refpix.optimal_refout_slope(a33["M_PINK"], a33["RU_PINK"], rd["anc"]["C_PINK"], a33["std"])
-        data, _ = refpix.correct_cube(data, cal["dark"]["data"], ramp["amp33"], a33["med"], slope_ref)
+        data, refdiag = refpix.correct_cube(data, cal["dark"]["data"], ramp["amp33"], a33["med"], slope_ref)
     else:
-        data, _ = refpix.correct_cube(data, cal["dark"]["data"], None, None, None)
+        data, refdiag = refpix.correct_cube(data, cal["dark"]["data"], None, None, None)
 
     # bias (:559-565)
     if "biascorr" in cal:
@@ -90,5 +91,5 @@ def calibrate_arrays(ramp, cal, exclude_first=True, ramp_opt_pars=None, jump_par
         ep /= flat
     return {
         "slope": slope, "err_read": er, "err_poisson": ep, "pixeldq": pdq, "groupdq": rdq,
-        "data": data, "K": meta["K"], "meta": meta, "flat": flat_dn,
+        "data": data, "K": meta["K"], "meta": meta, "flat": flat_dn, "refpix_diag": refdiag,
     }

@@ -1,0 +1,813 @@
+// C-ABI of libromanhip.so (include/romanhip.h): context, device-resident CALDIR, ramp-fit plans,
+// the chain driver and the stage-level entry points.  Host code only; kernels live in the other
+// translation units.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cmath>
+
+#include "rip_common.h"
+
+double rip_guard_band = 1e-5;  // relative half-width of the exact-order re-evaluation band (rampfit.hip)
+static std::string g_create_error;
+
+int rip_fail(rip_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+void *rip_ws(rip_ctx *ctx, int slot, size_t bytes) {
+    if (ctx->ws_bytes[slot] >= bytes && ctx->ws[slot]) return ctx->ws[slot];
+    if (ctx->ws[slot]) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->ws[slot]);
+        ctx->ws[slot] = nullptr;
+        ctx->ws_bytes[slot] = 0;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        rip_fail(ctx, RIP_ENOMEM, "hipMalloc(%zu bytes, workspace %d): %s", bytes, slot, hipGetErrorString(e));
+        return nullptr;
+    }
+    ctx->ws[slot] = p;
+    ctx->ws_bytes[slot] = bytes;
+    return p;
+}
+
+namespace {
+
+struct DevBuf {  // scoped device allocation for the stage-level entry points
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(rip_ctx *ctx, size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) return rip_fail(ctx, RIP_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        return RIP_OK;
+    }
+    int upload(rip_ctx *ctx, const void *src, size_t bytes) {
+        int rc = alloc(ctx, bytes);
+        if (rc) return rc;
+        RIP_HIP(ctx, hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return RIP_OK;
+    }
+    template <typename T>
+    T *as() {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
+size_t dsize(int dtype) { return dtype == RIP_F64 ? 8 : (dtype == RIP_U16 ? 2 : 4); }
+
+int dev_copy_in(rip_ctx *ctx, void **dst, const void *src, size_t bytes) {
+    *dst = nullptr;
+    if (!src) return RIP_OK;
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return rip_fail(ctx, RIP_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    RIP_HIP(ctx, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return RIP_OK;
+}
+
+void free_cal(RipCal &c) {
+    void *ptrs[] = {c.dark_data, c.dark_slope, c.dark_rate, c.dark_dq,  c.read_noise, c.amp33_med, c.gain,      c.lin_coefs,
+                    c.lin_smin,  c.lin_smax,   c.lin_sref,  c.lin_dq,   c.ipc,        c.flat_dn,   c.flat_flags, c.bias};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    c = RipCal();
+}
+
+}  // namespace
+
+extern "C" {
+
+int rip_version(void) { return RIP_VERSION; }
+
+const char *rip_last_error(const rip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rip_ctx_create(int device_id, rip_ctx **out) {
+    if (!out) return rip_fail(nullptr, RIP_EINVAL, "rip_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return rip_fail(nullptr, RIP_EHIP, "no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return rip_fail(nullptr, RIP_EINVAL, "device %d out of range [0,%d)", device_id, ndev);
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return rip_fail(nullptr, RIP_EHIP, "hipSetDevice(%d): %s", device_id, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return rip_fail(nullptr, RIP_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return rip_fail(nullptr, RIP_EHIP, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id,
+                        prop.gcnArchName);
+    rip_ctx *ctx = new rip_ctx();
+    ctx->device = device_id;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return rip_fail(nullptr, RIP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return RIP_OK;
+}
+
+void rip_ctx_destroy(rip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &c : ctx->cals) free_cal(c);
+    for (auto *p : ctx->plans)
+        if (p) {
+            if (p->dev) (void)hipFree(p->dev);
+            delete p;
+        }
+    for (int i = 0; i < 8; ++i)
+        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rip_synchronize(rip_ctx *ctx) {
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RIP_OK;
+}
+
+void *rip_stream(rip_ctx *ctx) { return (void *)ctx->stream; }
+
+void rip_set_guard_band(double rel) { rip_guard_band = rel; }
+
+// --------------------------------------------------------------------------- CALDIR
+int rip_caldir_drop(rip_ctx *ctx, int slot) {
+    if (slot < 0 || slot >= (int)ctx->cals.size() || !ctx->cals[slot].valid)
+        return rip_fail(ctx, RIP_EINVAL, "caldir slot %d is empty", slot);
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_cal(ctx->cals[slot]);
+    return RIP_OK;
+}
+
+int rip_caldir_upload(rip_ctx *ctx, int slot, const rip_caldir_desc *d) {
+    if (!d || slot < 0 || slot > 255) return rip_fail(ctx, RIP_EINVAL, "caldir upload: bad arguments");
+    if (d->ny < 16 || d->nx < 16 || d->nborder < 0 || 2 * d->nborder + 3 > d->ny || 2 * d->nborder + 3 > d->nx)
+        return rip_fail(ctx, RIP_EINVAL, "caldir upload: bad geometry %dx%d border %d", d->ny, d->nx, d->nborder);
+    if (!d->gain || !d->read_noise) return rip_fail(ctx, RIP_EINVAL, "caldir upload: gain and read noise are required");
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    if ((int)ctx->cals.size() <= slot) ctx->cals.resize(slot + 1);
+    if (ctx->cals[slot].valid) {
+        RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        free_cal(ctx->cals[slot]);
+    }
+    RipCal c;
+    c.ny = d->ny;
+    c.nx = d->nx;
+    c.nb = d->nborder;
+    const size_t npix = (size_t)c.ny * c.nx;
+    const int nya = c.ny - 2 * c.nb, nxa = c.nx - 2 * c.nb;
+    c.gain_dtype = d->gain_dtype;
+    c.ipc_dtype = d->ipc_dtype;
+    c.refout_slope = d->refout_slope;
+    int rc;
+#define UP(dst, src, bytes)                                         \
+    if ((rc = dev_copy_in(ctx, (void **)&(dst), (src), (bytes)))) { \
+        free_cal(c);                                                \
+        return rc;                                                  \
+    }
+    if (d->dark_data) {
+        c.ngrp_dark = d->ngrp_dark;
+        UP(c.dark_data, d->dark_data, npix * 4 * (size_t)d->ngrp_dark);
+    }
+    UP(c.dark_slope, d->dark_slope, npix * 4);
+    UP(c.dark_dq, d->dark_dq, npix * 4);
+    UP(c.read_noise, d->read_noise, npix * 4);
+    UP(c.amp33_med, d->amp33_med, (size_t)c.ny * RIP_CW * 4);
+    c.has_amp33 = d->amp33_med != nullptr;
+    UP(c.gain, d->gain, npix * dsize(d->gain_dtype));
+    if (d->lin_coefs) {
+        if (!d->lin_smin || !d->lin_smax || !d->lin_sref || !d->lin_dq || d->lin_nplanes < 1) {
+            free_cal(c);
+            return rip_fail(ctx, RIP_EINVAL, "caldir upload: incomplete linearity arrays");
+        }
+        c.lin_nplanes = d->lin_nplanes;
+        UP(c.lin_coefs, d->lin_coefs, npix * 4 * (size_t)d->lin_nplanes);
+        UP(c.lin_smin, d->lin_smin, npix * 4);
+        UP(c.lin_smax, d->lin_smax, npix * 4);
+        UP(c.lin_sref, d->lin_sref, npix * 4);
+        UP(c.lin_dq, d->lin_dq, npix * 4);
+    }
+    // dark dq: only kept if any bit is set (every dark file the reference writes has dq == 0)
+    if (d->dark_dq) {
+        bool any = false;
+        for (size_t i = 0; i < npix && !any; ++i) any = d->dark_dq[i] != 0;
+        c.has_dark_dq = any;
+    }
+    // ipc4d (3,3,nya,nxa) -> (9,ny,nx), biascorr (g,nya,nxa) -> (g,ny,nx): zero border, aligned rows
+    if (d->ipc4d) {
+        const size_t es = dsize(d->ipc_dtype);
+        void *tmp = rip_ws(ctx, 2, (size_t)9 * nya * nxa * es);
+        hipError_t e = tmp ? hipMalloc(&c.ipc, 9 * npix * es) : hipErrorOutOfMemory;
+        if (e != hipSuccess) {
+            free_cal(c);
+            return rip_fail(ctx, RIP_ENOMEM, "caldir upload: ipc4d allocation failed");
+        }
+        RIP_HIP(ctx, hipMemcpyAsync(tmp, d->ipc4d, (size_t)9 * nya * nxa * es, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = rip_launch_embed(ctx, tmp, c.ipc, 9, c.ny, c.nx, c.nb, (int)es))) {
+            free_cal(c);
+            return rc;
+        }
+        c.has_ipc = true;
+    }
+    if (d->biascorr) {
+        c.ngrp_bias = d->ngrp_bias;
+        const size_t nb_in = (size_t)d->ngrp_bias * nya * nxa * 4;
+        void *tmp = rip_ws(ctx, 2, nb_in);
+        hipError_t e = tmp ? hipMalloc((void **)&c.bias, (size_t)d->ngrp_bias * npix * 4) : hipErrorOutOfMemory;
+        if (e != hipSuccess) {
+            free_cal(c);
+            return rip_fail(ctx, RIP_ENOMEM, "caldir upload: biascorr allocation failed");
+        }
+        RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // tmp may still feed the ipc embed
+        RIP_HIP(ctx, hipMemcpyAsync(tmp, d->biascorr, nb_in, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = rip_launch_embed(ctx, tmp, c.bias, d->ngrp_bias, c.ny, c.nx, c.nb, 4))) {
+            free_cal(c);
+            return rc;
+        }
+        c.has_bias = true;
+    }
+    // IPC-deconvolved dark rate (gen_cal_image.py:217-221)
+    if (c.dark_slope) {
+        if (hipMalloc((void **)&c.dark_rate, npix * 4) != hipSuccess) {
+            free_cal(c);
+            return rip_fail(ctx, RIP_ENOMEM, "caldir upload: dark_rate allocation failed");
+        }
+        if (c.has_ipc) {
+            IpcArgs ia{c.dark_slope, c.dark_rate, c.ipc, c.gain, c.ipc_dtype, c.gain_dtype, c.ny, c.nx, c.nb, 1};
+            if ((rc = rip_launch_ipc_cube(ctx, ia))) {
+                free_cal(c);
+                return rc;
+            }
+        } else {
+            RIP_HIP(ctx, hipMemcpyAsync(c.dark_rate, c.dark_slope, npix * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    }
+    // flat in DN units (flatutils.get_flat with pdq given) + the flags it would OR into pdq
+    if (d->flat) {
+        DevBuf raw, padded, gclip;
+        if ((rc = raw.upload(ctx, d->flat, npix * 4)) || (rc = padded.alloc(ctx, npix * 4)) ||
+            (rc = gclip.alloc(ctx, npix * dsize(c.gain_dtype)))) {
+            free_cal(c);
+            return rc;
+        }
+        if (hipMalloc((void **)&c.flat_dn, npix * 4) != hipSuccess ||
+            hipMalloc((void **)&c.flat_flags, npix * 4) != hipSuccess) {
+            free_cal(c);
+            return rip_fail(ctx, RIP_ENOMEM, "caldir upload: flat allocation failed");
+        }
+        rc = rip_launch_flat_prepare(ctx, raw.as<float>(), c.gain, c.gain_dtype, c.ny, c.nx, c.nb, padded.as<float>(),
+                                     gclip.p, c.flat_flags, c.has_ipc ? 1 : 0);
+        if (!rc) {
+            if (c.has_ipc) {
+                IpcArgs ia{padded.as<float>(), c.flat_dn, c.ipc, gclip.p, c.ipc_dtype, c.gain_dtype, c.ny, c.nx, c.nb, 1};
+                rc = rip_launch_ipc_cube(ctx, ia);
+            } else {
+                hipError_t e = hipMemcpyAsync(c.flat_dn, padded.p, npix * 4, hipMemcpyDeviceToDevice, ctx->stream);
+                if (e != hipSuccess) rc = rip_fail(ctx, RIP_EHIP, "flat copy: %s", hipGetErrorString(e));
+            }
+        }
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (!rc && e != hipSuccess) rc = rip_fail(ctx, RIP_EHIP, "caldir upload: %s", hipGetErrorString(e));
+        if (rc) {
+            free_cal(c);
+            return rc;
+        }
+        c.has_flat = true;
+    }
+#undef UP
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        free_cal(c);
+        return rip_fail(ctx, RIP_EHIP, "caldir upload: %s", hipGetErrorString(e));
+    }
+    c.valid = true;
+    ctx->cals[slot] = c;
+    return RIP_OK;
+}
+
+// --------------------------------------------------------------------------- plans
+int rip_plan_create(rip_ctx *ctx, const rip_plan_desc *d, int *plan_id) {
+    if (!d || !plan_id) return rip_fail(ctx, RIP_EINVAL, "plan: NULL argument");
+    const int G = d->ngrp, start = d->exclude_first ? 1 : 0;
+    if (G < 2 + start || G > RIP_MAX_GROUPS) return rip_fail(ctx, RIP_EINVAL, "plan: %d groups unsupported", G);
+    const int nvar = 1 + (G - 3 - start > 0 ? G - 3 - start : 0);
+    if (d->nvariants != nvar) return rip_fail(ctx, RIP_EINVAL, "plan: expected %d fit variants, got %d", nvar, d->nvariants);
+    RipPlan *p = new RipPlan();
+    RipPlanHeader &h = p->h;
+    memset(&h, 0, sizeof h);
+    h.ngrp = G;
+    h.start = start;
+    h.nvariants = nvar;
+    h.do_not_flag_first = d->do_not_flag_first;
+    h.sa = d->sthresh_a;
+    h.dsb = d->sthresh_b - d->sthresh_a;
+    h.loglen = std::log(d->ithresh_b / d->ithresh_a);
+    h.ia = (float)d->ithresh_a;
+    h.ib = (float)d->ithresh_b;
+    for (int i = 0; i < G; ++i) {
+        h.tbar[i] = d->tbar[i];
+        h.tau[i] = d->tau[i];
+        h.nreads[i] = (float)d->nreads[i];
+    }
+    for (int v = 0; v < nvar; ++v) {
+        const int g = (v == 0) ? G : G - v;  // G, G-1, ..., 3+start  (fitting.py:326)
+        if (d->variant_g[v] != g) {
+            delete p;
+            return rip_fail(ctx, RIP_EINVAL, "plan: variant %d covers %d groups, expected %d", v, d->variant_g[v], g);
+        }
+        RipVariant rv;
+        rv.g = g;
+        rv.coef = d->variant_coef[v];
+        rv.rfac = d->variant_rfac[v];
+        rv.k_ofs = (int)p->kvals.size();
+        std::vector<float> K(g, 0.0f);
+        if (v == 0) {
+            for (int i = 0; i < g; ++i) K[i] = d->K[i];
+        } else {  // fitting.py:165-169
+            K[g - 1] = 1.0f / (d->tbar[g - 1] - d->tbar[start]);
+            K[start] = -K[g - 1];
+        }
+        p->kvals.insert(p->kvals.end(), K.begin(), K.end());
+        rv.diff_ofs = (int)p->diffs.size();
+        rv.ndiff = 0;
+        for (int i = start; i < g - 1; ++i) {  // fitting.py:225-229
+            const int dimax = (i == g - 2 || g - 1 - start == 2) ? 1 : 2;
+            for (int di = 1; di <= dimax; ++di) {
+                RipDiff df;
+                df.i = i;
+                df.j = i + di;
+                df.dt = d->tbar[i + di] - d->tbar[i];
+                const float inv = 1.0f / df.dt;
+                // fast-path variance coefficients: var = A*read^2 + B*dvardt, sums in f64
+                double A = 0.0, B = 0.0;
+                for (int a = 0; a < g; ++a) {
+                    const double wa = ((a == df.j) ? (double)inv : (a == df.i) ? (double)(-inv) : 0.0) - (double)K[a];
+                    A += wa * wa / (double)d->nreads[a];
+                    B += wa * wa * (double)d->tau[a];
+                    for (int b = 0; b < a; ++b) {
+                        const double wb = ((b == df.j) ? (double)inv : (b == df.i) ? (double)(-inv) : 0.0) - (double)K[b];
+                        B += 2.0 * wa * wb * (double)d->tbar[b];
+                    }
+                }
+                df.A = (float)A;
+                df.B = (float)B;
+                p->diffs.push_back(df);
+                rv.ndiff++;
+            }
+        }
+        p->variants.push_back(rv);
+    }
+    // device image: header | variants | K | diffs (each section 16-byte aligned)
+    auto al = [](size_t x) { return (x + 15) / 16 * 16; };
+    const size_t o_var = al(sizeof(RipPlanHeader));
+    const size_t o_k = o_var + al(p->variants.size() * sizeof(RipVariant));
+    const size_t o_d = o_k + al(p->kvals.size() * sizeof(float));
+    p->bytes = o_d + al(p->diffs.size() * sizeof(RipDiff));
+    std::vector<char> img(p->bytes, 0);
+    memcpy(img.data(), &h, sizeof h);
+    memcpy(img.data() + o_var, p->variants.data(), p->variants.size() * sizeof(RipVariant));
+    memcpy(img.data() + o_k, p->kvals.data(), p->kvals.size() * sizeof(float));
+    if (!p->diffs.empty()) memcpy(img.data() + o_d, p->diffs.data(), p->diffs.size() * sizeof(RipDiff));
+    hipError_t e = hipMalloc(&p->dev, p->bytes);
+    if (e == hipSuccess) e = hipMemcpy(p->dev, img.data(), p->bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (p->dev) (void)hipFree(p->dev);
+        delete p;
+        return rip_fail(ctx, RIP_EHIP, "plan upload: %s", hipGetErrorString(e));
+    }
+    p->d_variants = reinterpret_cast<const RipVariant *>((char *)p->dev + o_var);
+    p->d_k = reinterpret_cast<const float *>((char *)p->dev + o_k);
+    p->d_diffs = reinterpret_cast<const RipDiff *>((char *)p->dev + o_d);
+    int id = -1;
+    for (size_t i = 0; i < ctx->plans.size(); ++i)
+        if (!ctx->plans[i]) {
+            id = (int)i;
+            break;
+        }
+    if (id < 0) {
+        ctx->plans.push_back(nullptr);
+        id = (int)ctx->plans.size() - 1;
+    }
+    ctx->plans[id] = p;
+    *plan_id = id;
+    return RIP_OK;
+}
+
+int rip_plan_destroy(rip_ctx *ctx, int id) {
+    if (id < 0 || id >= (int)ctx->plans.size() || !ctx->plans[id]) return rip_fail(ctx, RIP_EINVAL, "plan %d does not exist", id);
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->plans[id]->dev);
+    delete ctx->plans[id];
+    ctx->plans[id] = nullptr;
+    return RIP_OK;
+}
+
+static RipPlan *get_plan(rip_ctx *ctx, int id) {
+    if (id < 0 || id >= (int)ctx->plans.size() || !ctx->plans[id]) {
+        rip_fail(ctx, RIP_EINVAL, "plan %d does not exist", id);
+        return nullptr;
+    }
+    return ctx->plans[id];
+}
+
+// --------------------------------------------------------------------------- the chain
+int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const rip_ramp_desc *in, const rip_outputs *out) {
+    if (!in || !out) return rip_fail(ctx, RIP_EINVAL, "calibrate: NULL argument");
+    if (slot < 0 || slot >= (int)ctx->cals.size() || !ctx->cals[slot].valid)
+        return rip_fail(ctx, RIP_EINVAL, "calibrate: caldir slot %d is empty", slot);
+    if (in->location != out->location) return rip_fail(ctx, RIP_EINVAL, "calibrate: inputs and outputs must share a location");
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    const RipCal &c = ctx->cals[slot];
+    const int G = in->ngrp, ny = c.ny, nx = c.nx;
+    const size_t npix = (size_t)ny * nx;
+    if (G < 1 || G > RIP_MAX_GROUPS) return rip_fail(ctx, RIP_EINVAL, "calibrate: %d groups unsupported", G);
+    if (!in->data || (in->data_dtype != RIP_U16 && in->data_dtype != RIP_F32))
+        return rip_fail(ctx, RIP_EINVAL, "calibrate: data must be u16 or f32");
+    RipPlan *plan = nullptr;
+    const bool do_fit = stages & RIP_STAGE_RAMPFIT;
+    if (do_fit || (stages & RIP_STAGE_LIN)) {
+        plan = get_plan(ctx, plan_id);
+        if (!plan) return RIP_EINVAL;
+        if (plan->h.ngrp != G) return rip_fail(ctx, RIP_EINVAL, "calibrate: ramp has %d groups, plan %d", G, plan->h.ngrp);
+    }
+    const bool do_ref = stages & RIP_STAGE_REFPIX, do_bias = (stages & RIP_STAGE_BIAS) && c.has_bias;
+    const bool do_lin = stages & RIP_STAGE_LIN, do_ipc = (stages & RIP_STAGE_IPC) && c.has_ipc;
+    if (do_ref && (!c.dark_data || c.ngrp_dark < G)) return rip_fail(ctx, RIP_EINVAL, "calibrate: dark.data has %d groups, ramp %d", c.ngrp_dark, G);
+    if (do_bias && c.ngrp_bias < G) return rip_fail(ctx, RIP_EINVAL, "calibrate: biascorr has %d groups, ramp %d", c.ngrp_bias, G);
+    if (do_lin && !c.lin_coefs) return rip_fail(ctx, RIP_EINVAL, "calibrate: no linearity arrays in caldir slot %d", slot);
+    if ((do_fit || do_lin) && (!in->groupdq || !in->pixeldq)) return rip_fail(ctx, RIP_EINVAL, "calibrate: groupdq/pixeldq required");
+    if (do_fit && (!out->slope || !out->err_read || !out->err_poisson || !out->pixeldq))
+        return rip_fail(ctx, RIP_EINVAL, "calibrate: output planes required");
+    if ((stages & RIP_STAGE_DARK) && !c.dark_rate) return rip_fail(ctx, RIP_EINVAL, "calibrate: no dark_slope in caldir");
+
+    // ---- inputs on the device
+    const bool host = in->location == RIP_HOST;
+    const size_t b_data = (size_t)G * npix * dsize(in->data_dtype), b_a33 = (size_t)G * ny * RIP_CW * 2;
+    const size_t b_gdq = (size_t)G * npix, b_pdq = npix * 4, b_area = npix * 8;
+    const void *d_data = in->data;
+    const uint16_t *d_a33 = in->amp33;
+    const uint8_t *d_gdq = in->groupdq;
+    const uint32_t *d_pdq = in->pixeldq;
+    const double *d_area = in->area_factor;
+    const double *d_lines_ovr = in->channel_lines;
+    const int nch = nx / RIP_CW;
+    if (host) {
+        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+        size_t tot = al(b_data) + al(b_a33) + al(b_gdq) + al(b_pdq) + al(b_area) + al((size_t)G * nch * 16);
+        char *w = (char *)rip_ws(ctx, 2, tot);
+        if (!w) return RIP_ENOMEM;
+        size_t o = 0;
+        auto put = [&](const void *src, size_t bytes) -> const void * {
+            if (!src) return nullptr;
+            void *dst = w + o;
+            o += al(bytes);
+            (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+            return dst;
+        };
+        d_data = put(in->data, b_data);
+        d_a33 = (const uint16_t *)put(in->amp33, b_a33);
+        d_gdq = (const uint8_t *)put(in->groupdq, b_gdq);
+        d_pdq = (const uint32_t *)put(in->pixeldq, b_pdq);
+        d_area = (const double *)put(in->area_factor, b_area);
+        d_lines_ovr = (const double *)put(in->channel_lines, (size_t)G * nch * 16);
+        RIP_HIP(ctx, hipGetLastError());
+    }
+    // ---- outputs on the device
+    float *o_slope = out->slope, *o_er = out->err_read, *o_ep = out->err_poisson, *o_cube = out->cube;
+    uint32_t *o_pdq = out->pixeldq;
+    uint8_t *o_gdq = out->groupdq;
+    if (host) {
+        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+        size_t tot = 4 * al(npix * 4) + (out->groupdq ? al(b_gdq) : 0);
+        char *w = (char *)rip_ws(ctx, 7, tot);
+        if (!w) return RIP_ENOMEM;
+        o_slope = (float *)w;
+        o_er = (float *)(w + al(npix * 4));
+        o_ep = (float *)(w + 2 * al(npix * 4));
+        o_pdq = (uint32_t *)(w + 3 * al(npix * 4));
+        o_gdq = out->groupdq ? (uint8_t *)(w + 4 * al(npix * 4)) : nullptr;
+        o_cube = nullptr;  // taken from the workspace cube below
+    }
+
+    int rc;
+    // ---- reference-pixel tables
+    double *rowcorr = nullptr, *lines = nullptr;
+    if (do_ref) {
+        if (nx % RIP_CW) return rip_fail(ctx, RIP_EINVAL, "calibrate: nx=%d is not a multiple of 128", nx);
+        char *w = (char *)rip_ws(ctx, 3, (size_t)G * ny * 8 + (size_t)G * nch * 16 + npix * 4 + 512);
+        if (!w) return RIP_ENOMEM;
+        rowcorr = (double *)w;
+        lines = rowcorr + (size_t)G * ny;
+        RefpixArgs ra{d_data, in->data_dtype, c.dark_data, c.has_amp33 ? d_a33 : nullptr, c.amp33_med, c.refout_slope,
+                      d_lines_ovr, rowcorr, lines, ny, nx, G};
+        if (c.has_amp33 && !d_a33) return rip_fail(ctx, RIP_EINVAL, "calibrate: the read file has amp33 but the ramp has none");
+        if ((rc = rip_launch_refpix_prepass(ctx, ra))) return rc;
+    }
+    // ---- cube stage: refpix apply + bias + linearity (or a plain conversion to f32)
+    const float *cur = nullptr;
+    const uint32_t *pdq_mid = d_pdq;
+    const bool need_cube_stage = do_ref || do_bias || do_lin || in->data_dtype != RIP_F32;
+    if (need_cube_stage) {
+        float *cubeA = (float *)rip_ws(ctx, 0, (size_t)G * npix * 4 + npix * 4);
+        if (!cubeA) return RIP_ENOMEM;
+        uint32_t *pdq_ws = (uint32_t *)(cubeA + (size_t)G * npix);
+        LinArgs la;
+        memset(&la, 0, sizeof la);
+        la.data = d_data;
+        la.data_dtype = in->data_dtype;
+        la.phi = cubeA;
+        la.gdq = d_gdq;
+        la.gdq_is_attempt = 0;
+        la.pdq_in = d_pdq;
+        la.pdq_out = do_lin ? pdq_ws : nullptr;
+        if (do_ref) {
+            la.dark_data = c.dark_data;
+            la.rowcorr = rowcorr;
+            la.lines = lines;
+        }
+        if (do_bias) la.bias = c.bias + (size_t)(c.ngrp_bias - G) * npix;  // biascorr[de:], gen_cal_image.py:561-562
+        if (do_lin) {
+            la.coefs = c.lin_coefs;
+            la.smin = c.lin_smin;
+            la.smax = c.lin_smax;
+            la.sref = c.lin_sref;
+            la.lin_dq = c.lin_dq;
+            la.nplanes = c.lin_nplanes;
+            la.do_not_flag_first = plan->h.do_not_flag_first;
+        }
+        la.ny = ny;
+        la.nx = nx;
+        la.nb = c.nb;
+        la.ngrp = G;
+        if ((rc = rip_launch_lin(ctx, la))) return rc;
+        cur = cubeA;
+        if (do_lin) pdq_mid = pdq_ws;
+    } else {
+        cur = (const float *)d_data;
+    }
+    // ---- IPC
+    if (do_ipc) {
+        float *cubeB = (float *)rip_ws(ctx, 1, (size_t)G * npix * 4);
+        if (!cubeB) return RIP_ENOMEM;
+        IpcArgs ia{cur, cubeB, c.ipc, c.gain, c.ipc_dtype, c.gain_dtype, ny, nx, c.nb, G};
+        if ((rc = rip_launch_ipc_cube(ctx, ia))) return rc;
+        cur = cubeB;
+    }
+    // ---- ramp fit + finish
+    if (do_fit) {
+        RampFitArgs fa;
+        memset(&fa, 0, sizeof fa);
+        fa.cube = cur;
+        fa.gdq_in = d_gdq;
+        fa.gdq_out = o_gdq;
+        fa.pdq_in = pdq_mid;
+        fa.pdq_out = o_pdq;
+        fa.gain = c.gain;
+        fa.read_noise = c.read_noise;
+        fa.slope = o_slope;
+        fa.err_read = o_er;
+        fa.err_poisson = o_ep;
+        fa.finish = (stages & (RIP_STAGE_DARK | RIP_STAGE_FLAT)) ? 1 : 0;
+        if (stages & RIP_STAGE_DARK) {
+            fa.dark_rate = c.dark_rate;
+            fa.dark_dq = c.has_dark_dq ? c.dark_dq : nullptr;
+        }
+        if ((stages & RIP_STAGE_FLAT) && c.has_flat) {
+            fa.flat = c.flat_dn;
+            fa.flat_flags = c.flat_flags;
+            if (d_area) {
+                float *fl = (float *)rip_ws(ctx, 3, (size_t)G * ny * 8 + (size_t)G * nch * 16 + npix * 4 + 512);
+                if (!fl) return RIP_ENOMEM;
+                fl = (float *)((char *)fl + ((size_t)G * ny * 8 + (size_t)G * nch * 16 + 255) / 256 * 256);
+                if ((rc = rip_launch_flat_area(ctx, c.flat_dn, d_area, fl, npix))) return rc;
+                fa.flat = fl;
+            }
+        }
+        fa.ny = ny;
+        fa.nx = nx;
+        fa.nb = c.nb;
+        fa.ngrp = G;
+        if ((rc = rip_launch_rampfit(ctx, plan, fa, c.gain_dtype))) return rc;
+    }
+    // ---- results back
+    if (host) {
+        if (do_fit) {
+            RIP_HIP(ctx, hipMemcpyAsync(out->slope, o_slope, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+            RIP_HIP(ctx, hipMemcpyAsync(out->err_read, o_er, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+            RIP_HIP(ctx, hipMemcpyAsync(out->err_poisson, o_ep, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+            RIP_HIP(ctx, hipMemcpyAsync(out->pixeldq, o_pdq, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (out->groupdq) RIP_HIP(ctx, hipMemcpyAsync(out->groupdq, o_gdq, b_gdq, hipMemcpyDeviceToHost, ctx->stream));
+        } else if (out->pixeldq) {
+            RIP_HIP(ctx, hipMemcpyAsync(out->pixeldq, pdq_mid, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (out->cube) RIP_HIP(ctx, hipMemcpyAsync(out->cube, cur, (size_t)G * npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        if (!do_fit && out->pixeldq && out->pixeldq != pdq_mid)
+            RIP_HIP(ctx, hipMemcpyAsync(out->pixeldq, pdq_mid, npix * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (o_cube && o_cube != cur)
+            RIP_HIP(ctx, hipMemcpyAsync(o_cube, cur, (size_t)G * npix * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return RIP_OK;
+}
+
+// --------------------------------------------------------------------------- stage-level entry points
+int rip_stage_refpix_image(rip_ctx *ctx, float *image, int ny, int nx, double slope, int do_row, int do_channel,
+                           const double *lines, float *ref_med, float *ctr, float *bottom_top) {
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    const int w = nx + RIP_CW, nch = w / RIP_CW;
+    const size_t n = (size_t)ny * w;
+    DevBuf img, ln, rm, ct, bt;
+    int rc;
+    if ((rc = img.upload(ctx, image, n * 4))) return rc;
+    if (lines && (rc = ln.upload(ctx, lines, (size_t)nch * 16))) return rc;
+    if ((rc = rm.alloc(ctx, (size_t)ny * 4)) || (rc = ct.alloc(ctx, 4)) || (rc = bt.alloc(ctx, (size_t)nch * 8))) return rc;
+    if ((rc = rip_refpix_image(ctx, img.as<float>(), ny, nx, slope, do_row, do_channel, lines ? ln.as<double>() : nullptr,
+                               rm.as<float>(), ct.as<float>(), bt.as<float>())))
+        return rc;
+    RIP_HIP(ctx, hipMemcpyAsync(image, img.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ref_med && do_row) RIP_HIP(ctx, hipMemcpyAsync(ref_med, rm.p, (size_t)ny * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctr && do_row) RIP_HIP(ctx, hipMemcpyAsync(ctr, ct.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (bottom_top && do_channel) RIP_HIP(ctx, hipMemcpyAsync(bottom_top, bt.p, (size_t)nch * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RIP_OK;
+}
+
+int rip_stage_multilin(rip_ctx *ctx, const float *S, int ngrp, int ny, int nx, int nplanes, const float *coefs,
+                       const float *smin, const float *smax, const float *sref, const uint32_t *lin_dq,
+                       int do_not_flag_first, const uint8_t *attempt_corr, float *phi, uint32_t *dq) {
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)ny * nx;
+    DevBuf dS, dC, dmin, dmax, dref, ddq, dac, dphi, dout;
+    int rc;
+    if ((rc = dS.upload(ctx, S, (size_t)ngrp * npix * 4)) || (rc = dC.upload(ctx, coefs, (size_t)nplanes * npix * 4)) ||
+        (rc = dmin.upload(ctx, smin, npix * 4)) || (rc = dmax.upload(ctx, smax, npix * 4)) ||
+        (rc = dref.upload(ctx, sref, npix * 4)) || (rc = ddq.upload(ctx, lin_dq, npix * 4)) ||
+        (rc = dphi.alloc(ctx, (size_t)ngrp * npix * 4)) || (rc = dout.alloc(ctx, npix * 4)))
+        return rc;
+    if (attempt_corr && (rc = dac.upload(ctx, attempt_corr, (size_t)ngrp * npix))) return rc;
+    LinArgs la;
+    memset(&la, 0, sizeof la);
+    la.data = dS.p;
+    la.data_dtype = RIP_F32;
+    la.phi = dphi.as<float>();
+    la.gdq = attempt_corr ? dac.as<uint8_t>() : nullptr;
+    la.gdq_is_attempt = 1;
+    la.pdq_out = dout.as<uint32_t>();
+    la.coefs = dC.as<float>();
+    la.smin = dmin.as<float>();
+    la.smax = dmax.as<float>();
+    la.sref = dref.as<float>();
+    la.lin_dq = ddq.as<uint32_t>();
+    la.nplanes = nplanes;
+    la.do_not_flag_first = do_not_flag_first;
+    la.ny = ny;
+    la.nx = nx;
+    la.nb = 0;
+    la.ngrp = ngrp;
+    if ((rc = rip_launch_lin(ctx, la))) return rc;
+    RIP_HIP(ctx, hipMemcpyAsync(phi, dphi.p, (size_t)ngrp * npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipMemcpyAsync(dq, dout.p, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RIP_OK;
+}
+
+int rip_stage_ipc_image(rip_ctx *ctx, int reverse, int order, const void *image, int img_dtype, int ny, int nx,
+                        const void *kernel, int k_dtype, const void *gain, int g_dtype, void *outp) {
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)ny * nx;
+    const bool t64 = img_dtype == RIP_F64 || k_dtype == RIP_F64 || (gain && g_dtype == RIP_F64);
+    DevBuf di, dk, dg, dout;
+    int rc;
+    if ((rc = di.upload(ctx, image, npix * dsize(img_dtype))) || (rc = dk.upload(ctx, kernel, 9 * npix * dsize(k_dtype))) ||
+        (rc = dout.alloc(ctx, npix * (t64 ? 8 : 4))))
+        return rc;
+    if (gain && (rc = dg.upload(ctx, gain, npix * dsize(g_dtype)))) return rc;
+    if ((rc = rip_launch_ipc_image(ctx, reverse, order, di.p, img_dtype, ny, nx, dk.p, k_dtype, gain ? dg.p : nullptr, g_dtype,
+                                   dout.p, 0)))
+        return rc;
+    RIP_HIP(ctx, hipMemcpyAsync(outp, dout.p, npix * (t64 ? 8 : 4), hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RIP_OK;
+}
+
+int rip_stage_correct_cube(rip_ctx *ctx, float *data, int ngrp, int ny, int nx, int nb, const void *kernel, int k_dtype,
+                           const void *gain, int g_dtype) {
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)ny * nx;
+    const int nya = ny - 2 * nb, nxa = nx - 2 * nb;
+    const size_t es = dsize(k_dtype);
+    DevBuf din, dout, kraw, kemb, dg;
+    int rc;
+    if ((rc = din.upload(ctx, data, (size_t)ngrp * npix * 4)) || (rc = dout.alloc(ctx, (size_t)ngrp * npix * 4)) ||
+        (rc = kraw.upload(ctx, kernel, (size_t)9 * nya * nxa * es)) || (rc = kemb.alloc(ctx, 9 * npix * es)))
+        return rc;
+    if (gain && (rc = dg.upload(ctx, gain, npix * dsize(g_dtype)))) return rc;
+    if ((rc = rip_launch_embed(ctx, kraw.p, kemb.p, 9, ny, nx, nb, (int)es))) return rc;
+    IpcArgs ia{din.as<float>(), dout.as<float>(), kemb.p, gain ? dg.p : nullptr, k_dtype, g_dtype, ny, nx, nb, ngrp};
+    if ((rc = rip_launch_ipc_cube(ctx, ia))) return rc;
+    RIP_HIP(ctx, hipMemcpyAsync(data, dout.p, (size_t)ngrp * npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RIP_OK;
+}
+
+int rip_stage_ramp_fit(rip_ctx *ctx, int plan_id, const float *data, uint8_t *rdq, uint32_t *pdq, int ny, int nx, int nb,
+                       const void *gain, int g_dtype, const float *read_noise, float *slope, float *err_read,
+                       float *err_poisson) {
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    RipPlan *plan = get_plan(ctx, plan_id);
+    if (!plan) return RIP_EINVAL;
+    const int G = plan->h.ngrp;
+    const size_t npix = (size_t)ny * nx;
+    DevBuf dd, dr, dp, dg, dn, ds, de, dq2, dr2, dp2;
+    int rc;
+    if ((rc = dd.upload(ctx, data, (size_t)G * npix * 4)) || (rc = dr.upload(ctx, rdq, (size_t)G * npix)) ||
+        (rc = dp.upload(ctx, pdq, npix * 4)) || (rc = dg.upload(ctx, gain, npix * dsize(g_dtype))) ||
+        (rc = dn.upload(ctx, read_noise, npix * 4)) || (rc = ds.alloc(ctx, npix * 4)) || (rc = de.alloc(ctx, npix * 4)) ||
+        (rc = dq2.alloc(ctx, npix * 4)) || (rc = dr2.alloc(ctx, (size_t)G * npix)) || (rc = dp2.alloc(ctx, npix * 4)))
+        return rc;
+    RampFitArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.cube = dd.as<float>();
+    fa.gdq_in = dr.as<uint8_t>();
+    fa.gdq_out = dr2.as<uint8_t>();
+    fa.pdq_in = dp.as<uint32_t>();
+    fa.pdq_out = dp2.as<uint32_t>();
+    fa.gain = dg.p;
+    fa.read_noise = dn.as<float>();
+    fa.slope = ds.as<float>();
+    fa.err_read = de.as<float>();
+    fa.err_poisson = dq2.as<float>();
+    fa.finish = 0;
+    fa.ny = ny;
+    fa.nx = nx;
+    fa.nb = nb;
+    fa.ngrp = G;
+    if ((rc = rip_launch_rampfit(ctx, plan, fa, g_dtype))) return rc;
+    RIP_HIP(ctx, hipMemcpyAsync(slope, ds.p, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipMemcpyAsync(err_read, de.p, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipMemcpyAsync(err_poisson, dq2.p, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipMemcpyAsync(rdq, dr2.p, (size_t)G * npix, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipMemcpyAsync(pdq, dp2.p, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RIP_OK;
+}
+
+int rip_stage_get_flat(rip_ctx *ctx, const float *flat, int ny, int nx, int nb, const void *gain, int g_dtype,
+                       const void *kernel, int k_dtype, int ipc_deconvolve, uint32_t *pdq, float *outp) {
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)ny * nx;
+    const int nya = ny - 2 * nb, nxa = nx - 2 * nb;
+    const size_t es = dsize(k_dtype);
+    DevBuf raw, padded, dg, gclip, flags, kraw, kemb, dout;
+    int rc;
+    if ((rc = raw.upload(ctx, flat, npix * 4)) || (rc = padded.alloc(ctx, npix * 4)) || (rc = flags.alloc(ctx, npix * 4)) ||
+        (rc = dout.alloc(ctx, npix * 4)))
+        return rc;
+    int with_gain = 0;
+    if (ipc_deconvolve) {
+        if (!gain || !kernel) return rip_fail(ctx, RIP_EINVAL, "get_flat: gain and ipc4d needed for deconvolution");
+        with_gain = pdq ? 1 : 2;
+        if ((rc = dg.upload(ctx, gain, npix * dsize(g_dtype))) || (rc = gclip.alloc(ctx, npix * dsize(g_dtype))) ||
+            (rc = kraw.upload(ctx, kernel, (size_t)9 * nya * nxa * es)) || (rc = kemb.alloc(ctx, 9 * npix * es)))
+            return rc;
+        if ((rc = rip_launch_embed(ctx, kraw.p, kemb.p, 9, ny, nx, nb, (int)es))) return rc;
+    }
+    if ((rc = rip_launch_flat_prepare(ctx, raw.as<float>(), dg.p, g_dtype, ny, nx, nb, padded.as<float>(), gclip.p,
+                                      flags.as<uint32_t>(), with_gain)))
+        return rc;
+    const void *res = padded.p;
+    if (ipc_deconvolve) {
+        IpcArgs ia{padded.as<float>(), dout.as<float>(), kemb.p, gclip.p, k_dtype, g_dtype, ny, nx, nb, 1};
+        if ((rc = rip_launch_ipc_cube(ctx, ia))) return rc;
+        res = dout.p;
+    }
+    RIP_HIP(ctx, hipMemcpyAsync(outp, res, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (pdq) {
+        std::vector<uint32_t> fl(npix);
+        RIP_HIP(ctx, hipMemcpyAsync(fl.data(), flags.p, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < npix; ++i) pdq[i] |= fl[i];
+    }
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RIP_OK;
+}
+
+}  // extern "C"

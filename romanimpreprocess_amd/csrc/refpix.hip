@@ -1,0 +1,385 @@
+// Reference-pixel correction tables (exact medians) -- a small pre-pass in front of the cube kernel.
+//
+// Replaces (reference file:line):
+//   L1_to_L2/gen_cal_image.py:536-539        amp33 block = amp33 - med, minus its own np.median
+//   utils/reference_subtraction.py:104-123   ref_subtraction_row  (row medians of the reference output,
+//                                            their median `ctr`, per-row correction slope*(med-ctr))
+//   utils/reference_subtraction.py:50-60     ref_subtraction_channel (medians of the bottom/top 4 reference
+//                                            rows of every 128-column channel, line through them)
+// Only the tables are produced here: rowcorr[g][r] (f64) and lines[g][ch] = (m, c) (f64).  The
+// per-pixel application is fused into the cube kernel (linearity.hip).  What makes this possible:
+//   * with `slope` given (always, when read.amp33 exists) the science-row medians and the polyfit
+//     of reference_subtraction.py:107,114 are dead code;
+//   * x -> f32(x - M) is monotone, so the rank-63/64 elements of a row of (v - M) are the
+//     rank-63/64 elements of v, minus M: row medians and the global median M come from one pass;
+//   * the channel step only needs rows 0:4 and ny-4:ny of the row-corrected image.
+// All medians are exact selections (np.median: mean of the two middle elements in f32).
+// Arithmetic recipe: oracle/refpix.py.
+//
+// The line through (1.5, b), (ny-2.5, t) is m = (t-b)/(ny-4), c = b - 1.5 m in f64; the reference gets
+// it from LAPACK gelsd, which agrees to ~1e-13 relative but not bit for bit -- the caller may pass
+// LAPACK's (m, c) instead (`lines_override`).  See DESIGN.md "channel line fit".
+#include "rip_common.h"
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// np.median of vals[0..n) held in LDS, by rank counting; result broadcast through slot[0..1].
+// All threads of the block must call it.  Ties are ordered by index, so ranks are a permutation.
+__device__ float block_median(const float *vals, int n, float *slot) {
+    const int k_hi = n / 2, k_lo = (n & 1) ? n / 2 : n / 2 - 1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = vals[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float w = vals[j];
+            rank += (w < v || (w == v && j < i)) ? 1 : 0;
+        }
+        if (rank == k_lo) slot[0] = v;
+        if (rank == k_hi) slot[1] = v;
+    }
+    __syncthreads();
+    const float m = (slot[0] + slot[1]) * 0.5f;
+    __syncthreads();
+    return m;
+}
+
+// ---- 1. per (group,row): rank-63 / rank-64 elements of v = f32(amp33) - med -----------------------
+__global__ __launch_bounds__(RIP_CW) void amp33_rows_kernel(const uint16_t *__restrict__ amp33,
+                                                            const float *__restrict__ med, float *__restrict__ lohi,
+                                                            int ny) {
+    __shared__ float v[RIP_CW];
+    const int r = blockIdx.x, g = blockIdx.y, c = threadIdx.x;
+    const float mine = (float)amp33[((size_t)g * ny + r) * RIP_CW + c] - med[(size_t)r * RIP_CW + c];
+    v[c] = mine;
+    __syncthreads();
+    int rank = 0;
+    for (int j = 0; j < RIP_CW; ++j) {
+        const float w = v[j];
+        rank += (w < mine || (w == mine && j < c)) ? 1 : 0;
+    }
+    float *o = lohi + ((size_t)g * ny + r) * 2;
+    if (rank == RIP_CW / 2 - 1) o[0] = mine;
+    if (rank == RIP_CW / 2) o[1] = mine;
+}
+
+// ---- 2. exact selection of two ranks among the ny*128 values of each group (3-level radix) -------
+struct SelState {
+    uint32_t prefix[2];
+    uint32_t rank[2];
+};
+
+#define SEL_BINS 2048
+__device__ __forceinline__ int sel_shift(int level) { return level == 0 ? 21 : (level == 1 ? 10 : 0); }
+__device__ __forceinline__ int sel_bits(int level) { return level == 2 ? 10 : 11; }
+
+__global__ __launch_bounds__(256) void sel_hist_kernel(const uint16_t *__restrict__ amp33, const float *__restrict__ med,
+                                                       const SelState *__restrict__ st, uint32_t *__restrict__ ghist,
+                                                       int ny, int level, int chunk) {
+    __shared__ uint32_t h[2][SEL_BINS];
+    const int g = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const size_t n = (size_t)ny * RIP_CW;
+    const size_t lo = (size_t)blockIdx.x * chunk;
+    const size_t hi = (lo + chunk < n) ? lo + chunk : n;
+    const int shift = sel_shift(level);
+    const uint32_t mask = (1u << sel_bits(level)) - 1u;
+    const int above = shift + sel_bits(level);  // bits above this level's field
+    const uint32_t p0 = st[g].prefix[0], p1 = st[g].prefix[1];
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t key = f2key((float)amp33[(size_t)g * n + i] - med[i]);
+        const uint32_t bin = (key >> shift) & mask;
+        const bool m0 = (above >= 32) || (((key ^ p0) >> above) == 0);
+        const bool m1 = (above >= 32) || (((key ^ p1) >> above) == 0);
+        if (m0) atomicAdd(&h[0][bin], 1u);
+        if (m1) atomicAdd(&h[1][bin], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * SEL_BINS; i += blockDim.x) {
+        const uint32_t c = (&h[0][0])[i];
+        if (c) atomicAdd(&ghist[(size_t)g * 2 * SEL_BINS + i], c);
+    }
+}
+
+__global__ __launch_bounds__(256) void sel_scan_kernel(SelState *__restrict__ st, uint32_t *__restrict__ ghist, int level) {
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t found[2];
+    const int g = blockIdx.x, t = blockIdx.y;
+    uint32_t *h = ghist + ((size_t)g * 2 + t) * SEL_BINS;
+    const int per = SEL_BINS / 256;
+    uint32_t s = 0;
+    for (int k = 0; k < per; ++k) s += h[threadIdx.x * per + k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t rank = st[g].rank[t], cum = 0;
+        int c = 0;
+        while (c < 255 && cum + part[c] <= rank) cum += part[c++];
+        int b = c * per;
+        while (b < c * per + per - 1 && cum + h[b] <= rank) cum += h[b++];
+        found[0] = (uint32_t)b;
+        found[1] = rank - cum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st[g].prefix[t] |= found[0] << sel_shift(level);
+        st[g].rank[t] = found[1];
+    }
+    __syncthreads();
+    for (int k = 0; k < per; ++k) h[threadIdx.x * per + k] = 0;  // ready for the next level
+}
+
+__global__ void sel_init_kernel(SelState *st, uint32_t *ghist, int ngrp, uint32_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)ngrp * 2 * SEL_BINS) ghist[i] = 0;
+    if (i < (size_t)ngrp) {
+        st[i].prefix[0] = st[i].prefix[1] = 0;
+        st[i].rank[0] = n / 2 - 1;
+        st[i].rank[1] = n / 2;
+    }
+}
+
+// ---- 3. per group: global median M, row medians, ctr, rowcorr ------------------------------------
+__global__ __launch_bounds__(1024) void rowcorr_kernel(const SelState *__restrict__ st, const float *__restrict__ lohi,
+                                                       double slope, double *__restrict__ rowcorr,
+                                                       float *__restrict__ dbg_refmed, float *__restrict__ dbg_scal,
+                                                       int ny) {
+    extern __shared__ float rm[];  // [ny] + 2
+    float *slot = rm + ny;
+    const int g = blockIdx.x;
+    const float M = (key2f(st[g].prefix[0]) + key2f(st[g].prefix[1])) * 0.5f;  // np.median of the block
+    for (int r = threadIdx.x; r < ny; r += blockDim.x) {
+        const float a = lohi[((size_t)g * ny + r) * 2] - M;
+        const float b = lohi[((size_t)g * ny + r) * 2 + 1] - M;
+        rm[r] = (a + b) * 0.5f;
+    }
+    __syncthreads();
+    const float ctr = block_median(rm, ny, slot);
+    for (int r = threadIdx.x; r < ny; r += blockDim.x) {
+        const float d = rm[r] - ctr;
+        rowcorr[(size_t)g * ny + r] = slope * (double)d;
+        if (dbg_refmed) dbg_refmed[(size_t)g * ny + r] = rm[r];
+    }
+    if (dbg_scal && threadIdx.x == 0) {
+        dbg_scal[g * 2] = M;
+        dbg_scal[g * 2 + 1] = ctr;
+    }
+}
+
+// ---- 4. per (group, channel): bottom/top medians of the row-corrected image, line fit ---------
+template <typename DT>
+__global__ __launch_bounds__(1024) void chan_kernel(const DT *__restrict__ data, const float *__restrict__ dark,
+                                                    const double *__restrict__ rowcorr,
+                                                    const double *__restrict__ lines_override,
+                                                    double *__restrict__ lines, float *__restrict__ dbg_bt, int ny,
+                                                    int nx) {
+    __shared__ float v[1024];
+    __shared__ float slot[2];
+    __shared__ float bt[2];
+    const int ch = blockIdx.x, g = blockIdx.y, nch = gridDim.x;
+    const int e = threadIdx.x & 511, half = threadIdx.x >> 9;
+    const int row = (half ? ny - 4 : 0) + e / RIP_CW;
+    const size_t idx = ((size_t)g * ny + row) * nx + (size_t)ch * RIP_CW + e % RIP_CW;
+    float val = (float)data[idx] - dark[idx];
+    val = (float)((double)val - rowcorr[(size_t)g * ny + row]);
+    v[threadIdx.x] = val;
+    __syncthreads();
+    // each half of the block ranks its own 512 values
+    const float *mine = v + half * 512;
+    int rank = 0;
+    for (int j = 0; j < 512; ++j) {
+        const float w = mine[j];
+        rank += (w < val || (w == val && j < e)) ? 1 : 0;
+    }
+    __shared__ float lh[2][2];
+    if (rank == 255) lh[half][0] = val;
+    if (rank == 256) lh[half][1] = val;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float b = (lh[0][0] + lh[0][1]) * 0.5f;
+        const float t = (lh[1][0] + lh[1][1]) * 0.5f;
+        double m, c;
+        if (lines_override) {
+            m = lines_override[((size_t)g * nch + ch) * 2];
+            c = lines_override[((size_t)g * nch + ch) * 2 + 1];
+        } else {
+            m = ((double)t - (double)b) / (double)(ny - 4);
+            c = (double)b - 1.5 * m;
+        }
+        lines[((size_t)g * nch + ch) * 2] = m;
+        lines[((size_t)g * nch + ch) * 2 + 1] = c;
+        if (dbg_bt) {
+            dbg_bt[((size_t)g * nch + ch) * 2] = b;
+            dbg_bt[((size_t)g * nch + ch) * 2 + 1] = t;
+        }
+    }
+    (void)slot;
+    (void)bt;
+}
+
+int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a) {
+    if (a.nx % RIP_CW) return rip_fail(ctx, RIP_EINVAL, "refpix: nx=%d is not a multiple of 128", a.nx);
+    if (a.ny < 8) return rip_fail(ctx, RIP_EINVAL, "refpix: ny=%d too small", a.ny);
+    const int G = a.ngrp, ny = a.ny, nch = a.nx / RIP_CW;
+    if (a.amp33) {
+        // scratch: lohi (G,ny,2) f32 | SelState[G] | ghist (G,2,2048) u32
+        const size_t lohi_b = (size_t)G * ny * 2 * sizeof(float);
+        const size_t st_b = ((size_t)G * sizeof(SelState) + 255) / 256 * 256;
+        const size_t gh_b = (size_t)G * 2 * SEL_BINS * sizeof(uint32_t);
+        char *ws = (char *)rip_ws(ctx, 4, lohi_b + st_b + gh_b);
+        if (!ws) return RIP_ENOMEM;
+        float *lohi = (float *)ws;
+        SelState *st = (SelState *)(ws + lohi_b);
+        uint32_t *ghist = (uint32_t *)(ws + lohi_b + st_b);
+        const uint32_t n = (uint32_t)ny * RIP_CW;
+        hipLaunchKernelGGL(amp33_rows_kernel, dim3(ny, G), dim3(RIP_CW), 0, ctx->stream, a.amp33, a.amp33_med, lohi, ny);
+        const size_t ninit = (size_t)G * 2 * SEL_BINS;
+        hipLaunchKernelGGL(sel_init_kernel, dim3((unsigned)((ninit + 255) / 256)), dim3(256), 0, ctx->stream, st, ghist,
+                           G, n);
+        const int chunk = 8192;
+        const unsigned nblk = (unsigned)((n + chunk - 1) / chunk);
+        for (int level = 0; level < 3; ++level) {
+            hipLaunchKernelGGL(sel_hist_kernel, dim3(nblk, G), dim3(256), 0, ctx->stream, a.amp33, a.amp33_med, st,
+                               ghist, ny, level, chunk);
+            hipLaunchKernelGGL(sel_scan_kernel, dim3(G, 2), dim3(256), 0, ctx->stream, st, ghist, level);
+        }
+        const size_t lds = ((size_t)ny + 2) * sizeof(float);
+        if (lds > 48 * 1024)
+            RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rowcorr_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(rowcorr_kernel, dim3(G), dim3(1024), lds, ctx->stream, st, lohi, a.slope, a.rowcorr,
+                           (float *)nullptr, (float *)nullptr, ny);
+    } else {
+        // no reference output in the read file: the row step is the identity
+        RIP_HIP(ctx, hipMemsetAsync(a.rowcorr, 0, (size_t)G * ny * sizeof(double), ctx->stream));
+    }
+    if (a.data_dtype == RIP_U16)
+        hipLaunchKernelGGL(chan_kernel<uint16_t>, dim3(nch, G), dim3(1024), 0, ctx->stream, (const uint16_t *)a.data,
+                           a.dark_data, a.rowcorr, a.lines_override, a.lines, (float *)nullptr, ny, a.nx);
+    else
+        hipLaunchKernelGGL(chan_kernel<float>, dim3(nch, G), dim3(1024), 0, ctx->stream, (const float *)a.data,
+                           a.dark_data, a.rowcorr, a.lines_override, a.lines, (float *)nullptr, ny, a.nx);
+    RIP_HIP(ctx, hipGetLastError());
+    return RIP_OK;
+}
+
+// ------------------------------------------------------------------ image-level drop-ins
+// ref_subtraction_row(image, use_ref_channel=True, slope) / ref_subtraction_channel(image,
+// use_ref_channel=True) on one (ny, nx+128) f32 image resident on the device.
+
+__global__ __launch_bounds__(RIP_CW) void img_rowmed_kernel(const float *__restrict__ image, float *__restrict__ ref_med,
+                                                            int nx) {
+    __shared__ float v[RIP_CW];
+    __shared__ float slot[2];
+    const int r = blockIdx.x;
+    v[threadIdx.x] = image[(size_t)r * (nx + RIP_CW) + nx + threadIdx.x];
+    __syncthreads();
+    const float m = block_median(v, RIP_CW, slot);
+    if (threadIdx.x == 0) ref_med[r] = m;
+}
+
+__global__ __launch_bounds__(1024) void img_ctr_kernel(const float *__restrict__ ref_med, double slope,
+                                                       double *__restrict__ rowcorr, float *__restrict__ ctr_out, int ny) {
+    extern __shared__ float rm[];
+    float *slot = rm + ny;
+    for (int r = threadIdx.x; r < ny; r += blockDim.x) rm[r] = ref_med[r];
+    __syncthreads();
+    const float ctr = block_median(rm, ny, slot);
+    for (int r = threadIdx.x; r < ny; r += blockDim.x) rowcorr[r] = slope * (double)(rm[r] - ctr);
+    if (threadIdx.x == 0 && ctr_out) *ctr_out = ctr;
+}
+
+__global__ void img_rowapply_kernel(float *__restrict__ image, const double *__restrict__ rowcorr, int ny, int w) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ny * w) return;
+    image[i] = (float)((double)image[i] - rowcorr[i / w]);
+}
+
+__global__ __launch_bounds__(1024) void img_chan_kernel(const float *__restrict__ image,
+                                                        const double *__restrict__ lines_override,
+                                                        double *__restrict__ lines, float *__restrict__ bt_out, int ny,
+                                                        int w) {
+    __shared__ float v[1024];
+    __shared__ float lh[2][2];
+    const int ch = blockIdx.x;
+    const int e = threadIdx.x & 511, half = threadIdx.x >> 9;
+    const int row = (half ? ny - 4 : 0) + e / RIP_CW;
+    const float val = image[(size_t)row * w + (size_t)ch * RIP_CW + e % RIP_CW];
+    v[threadIdx.x] = val;
+    __syncthreads();
+    const float *mine = v + half * 512;
+    int rank = 0;
+    for (int j = 0; j < 512; ++j) {
+        const float q = mine[j];
+        rank += (q < val || (q == val && j < e)) ? 1 : 0;
+    }
+    if (rank == 255) lh[half][0] = val;
+    if (rank == 256) lh[half][1] = val;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float b = (lh[0][0] + lh[0][1]) * 0.5f;
+        const float t = (lh[1][0] + lh[1][1]) * 0.5f;
+        double m, c;
+        if (lines_override) {
+            m = lines_override[ch * 2];
+            c = lines_override[ch * 2 + 1];
+        } else {
+            m = ((double)t - (double)b) / (double)(ny - 4);
+            c = (double)b - 1.5 * m;
+        }
+        lines[ch * 2] = m;
+        lines[ch * 2 + 1] = c;
+        if (bt_out) {
+            bt_out[ch * 2] = b;
+            bt_out[ch * 2 + 1] = t;
+        }
+    }
+}
+
+__global__ void img_chanapply_kernel(float *__restrict__ image, const double *__restrict__ lines, int ny, int w) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ny * w) return;
+    const int r = (int)(i / w), c = (int)(i % w);
+    const double *ln = lines + (size_t)(c / RIP_CW) * 2;
+    const double iel = ln[0] * (double)r + ln[1];
+    image[i] = (float)((double)image[i] - iel);
+}
+
+int rip_refpix_image(rip_ctx *ctx, float *d_image, int ny, int nx, double slope, int do_row, int do_channel,
+                     const double *d_lines, float *d_ref_med, float *d_ctr, float *d_bottom_top) {
+    if (nx % RIP_CW) return rip_fail(ctx, RIP_EINVAL, "refpix: nx=%d is not a multiple of 128", nx);
+    const int w = nx + RIP_CW, nch = w / RIP_CW;
+    const size_t n = (size_t)ny * w;
+    char *ws = (char *)rip_ws(ctx, 4, (size_t)ny * (sizeof(double) + sizeof(float)) + (size_t)nch * 2 * sizeof(double) + 256);
+    if (!ws) return RIP_ENOMEM;
+    double *rowcorr = (double *)ws;
+    double *lines = rowcorr + ny;
+    float *refmed = (float *)(lines + nch * 2);
+    if (do_row) {
+        hipLaunchKernelGGL(img_rowmed_kernel, dim3(ny), dim3(RIP_CW), 0, ctx->stream, d_image, refmed, nx);
+        const size_t lds = ((size_t)ny + 2) * sizeof(float);
+        if (lds > 48 * 1024)
+            RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(img_ctr_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(img_ctr_kernel, dim3(1), dim3(1024), lds, ctx->stream, refmed, slope, rowcorr, d_ctr, ny);
+        hipLaunchKernelGGL(img_rowapply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_image,
+                           rowcorr, ny, w);
+        if (d_ref_med)
+            RIP_HIP(ctx, hipMemcpyAsync(d_ref_med, refmed, (size_t)ny * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (do_channel) {
+        hipLaunchKernelGGL(img_chan_kernel, dim3(nch), dim3(1024), 0, ctx->stream, d_image, d_lines, lines, d_bottom_top,
+                           ny, w);
+        hipLaunchKernelGGL(img_chanapply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_image,
+                           lines, ny, w);
+    }
+    RIP_HIP(ctx, hipGetLastError());
+    return RIP_OK;
+}

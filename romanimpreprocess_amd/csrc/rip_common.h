@@ -1,0 +1,189 @@
+// Shared declarations of libromanhip (host + device).  gfx950 only.
+//
+// Floating-point contract of every kernel in this library: one IEEE rounding per written
+// operation, in the written order.  The translation units are compiled with -ffp-contract=off
+// (hipcc would otherwise fuse a*b+c), IEEE divide/sqrt (hipcc default), no fast-math, f32
+// denormals preserved.  Where a fused multiply-add is wanted it is spelled fmaf()/fma().
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/romanhip.h"
+
+// DQ bits used on the path (SURVEY.md Appendix C / romanimpreprocess_amd/dqflags.py)
+#define DQ_DO_NOT_USE 0x1u
+#define DQ_SATURATED 0x2u
+#define DQ_JUMP_DET 0x4u
+#define DQ_NO_FLAT_FIELD (1u << 18)
+#define DQ_NO_GAIN_VALUE (1u << 19)
+#define DQ_NO_LIN_CORR (1u << 20)
+#define DQ_REFERENCE_PIXEL (1u << 31)
+
+#define RIP_CW RIP_CHANNEL_WIDTH
+
+// ---------------------------------------------------------------- device-side plan (ramp fit)
+struct RipDiff {
+    int32_t i, j;   // difference d[j]-d[i], flag lands on group i (fitting.py:230,249)
+    float dt;       // tbar[j]-tbar[i], f32
+    float A, B;     // fast-path variance: var ~= A*read^2 + B*dvardt (host f64 sums rounded to f32)
+};
+
+struct RipVariant {
+    int32_t g;      // groups [0,g) take part
+    int32_t ndiff, diff_ofs, k_ofs;
+    float coef, rfac;
+};
+
+struct RipPlanHeader {
+    int32_t ngrp, start, nvariants, do_not_flag_first;
+    double sa, dsb;        // SthreshA, (SthreshB - SthreshA)
+    double loglen;         // np.log(IthreshB / IthreshA), f64
+    float ia, ib;          // f32(IthreshA), f32(IthreshB)
+    float tbar[RIP_MAX_GROUPS], tau[RIP_MAX_GROUPS], nreads[RIP_MAX_GROUPS];  // nreads as f32(N)
+};
+
+// layout of the device plan buffer: header | variants[nvariants] | K floats | diffs
+struct RipPlan {
+    RipPlanHeader h;
+    std::vector<RipVariant> variants;
+    std::vector<float> kvals;
+    std::vector<RipDiff> diffs;
+    void *dev = nullptr;          // device copy
+    const RipVariant *d_variants = nullptr;
+    const float *d_k = nullptr;
+    const RipDiff *d_diffs = nullptr;
+    size_t bytes = 0;
+};
+
+// ---------------------------------------------------------------- device-resident CALDIR of one SCA
+struct RipCal {
+    bool valid = false;
+    int ny = 0, nx = 0, nb = 0;
+    int ngrp_dark = 0, ngrp_bias = 0, lin_nplanes = 0;
+    int gain_dtype = RIP_F32, ipc_dtype = RIP_F32;
+    bool has_amp33 = false, has_ipc = false, has_flat = false, has_bias = false, has_dark_dq = false;
+    double refout_slope = 0.0;
+    float *dark_data = nullptr;   // (ngrp_dark, ny, nx)
+    float *dark_slope = nullptr;  // raw (ny,nx)
+    float *dark_rate = nullptr;   // IPC-deconvolved dark rate (ny,nx)  [gen_cal_image.py:217-221]
+    uint32_t *dark_dq = nullptr;
+    float *read_noise = nullptr;
+    float *amp33_med = nullptr;   // (ny,128)
+    void *gain = nullptr;         // (ny,nx) f32|f64
+    float *lin_coefs = nullptr;   // (nplanes, ny, nx)
+    float *lin_smin = nullptr, *lin_smax = nullptr, *lin_sref = nullptr;
+    uint32_t *lin_dq = nullptr;
+    void *ipc = nullptr;          // (9, ny, nx) embedded in the full frame (border entries unused)
+    float *flat_dn = nullptr;     // output of get_flat (ny,nx); border = 1
+    uint32_t *flat_flags = nullptr;  // NO_FLAT_FIELD / NO_GAIN_VALUE bits get_flat would OR into pdq
+    float *bias = nullptr;        // (ngrp_bias, ny, nx) embedded in the full frame, border = 0
+    size_t bytes = 0;
+};
+
+struct rip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<RipCal> cals;
+    std::vector<RipPlan *> plans;
+    // workspace (grown on demand)
+    void *ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+// ---------------------------------------------------------------- host helpers
+int rip_fail(rip_ctx *ctx, int code, const char *fmt, ...);
+void *rip_ws(rip_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error recorded)
+
+#define RIP_HIP(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) return rip_fail(ctx, RIP_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------- kernel launchers (host side)
+// rampfit.hip
+struct RampFitArgs {
+    const float *cube;      // (G, ny, nx) corrected cube
+    const uint8_t *gdq_in;  // (G, ny, nx)
+    uint8_t *gdq_out;       // (G, ny, nx) or nullptr
+    const uint32_t *pdq_in; // (ny, nx)
+    uint32_t *pdq_out;      // (ny, nx)
+    const void *gain;       // (ny, nx)
+    const float *read_noise;
+    float *slope, *err_read, *err_poisson;
+    // finish (any may be null -> step skipped)
+    int finish;                  // 0: raw ramp_fit outputs (fitting.ramp_fit); 1: A11 algebra (+dark, +flat)
+    const float *dark_rate;      // subtract on the active region
+    const uint32_t *dark_dq;
+    const float *flat;           // divide (already flat_dn / area as f32)
+    const uint32_t *flat_flags;  // OR into pdq
+    int ny, nx, nb, ngrp;
+};
+int rip_launch_rampfit(rip_ctx *ctx, const RipPlan *plan, const RampFitArgs &a, int gain_dtype);
+
+// linearity.hip
+struct LinArgs {
+    const void *data;        // (G, ny, nx) u16 or f32
+    int data_dtype;
+    float *phi;              // (G, ny, nx)
+    const uint8_t *gdq;      // for attempt_corr = group not saturated; nullptr -> attempt everything
+    int gdq_is_attempt;      // 1: gdq holds attempt_corr bytes (nonzero = attempt) instead of groupdq
+    const uint32_t *pdq_in;  // may be null (treated as 0)
+    uint32_t *pdq_out;       // pdq_in | dq_lin
+    // refpix apply (null rowcorr -> skipped)
+    const float *dark_data;  // (>=G, ny, nx)
+    const double *rowcorr;   // (G, ny)   slope * f64(f32(ref_med - ctr))
+    const double *lines;     // (G, nx/128, 2)  (m, c)
+    // bias (null -> skipped); embedded full-frame planes, group offset applied by the caller
+    const float *bias;
+    // linearity (null coefs -> skipped: phi = data after refpix/bias)
+    const float *coefs, *smin, *smax, *sref;
+    const uint32_t *lin_dq;
+    int nplanes;
+    int do_not_flag_first;
+    int ny, nx, nb, ngrp;
+};
+int rip_launch_lin(rip_ctx *ctx, const LinArgs &a);
+
+// ipc.hip
+struct IpcArgs {
+    const float *in;   // (G, ny, nx)
+    float *out;        // (G, ny, nx)   (border copied through)
+    const void *kern;  // (9, ny, nx) embedded
+    const void *gain;  // (ny, nx) or nullptr (= 1)
+    int k_dtype, g_dtype;
+    int ny, nx, nb, ngrp;
+};
+int rip_launch_ipc_cube(rip_ctx *ctx, const IpcArgs &a);
+// generic single-image forward / reverse operator (stage API + CALDIR-derived planes)
+int rip_launch_ipc_image(rip_ctx *ctx, int reverse, int order, const void *img, int img_dtype, int ny, int nx,
+                         const void *kern /* (9,ny,nx) */, int k_dtype, const void *gain, int g_dtype, void *out,
+                         int gain_div_clip /*unused*/);
+
+// refpix.hip
+struct RefpixArgs {
+    const void *data;  // (G, ny, nx) u16|f32
+    int data_dtype;
+    const float *dark_data;
+    const uint16_t *amp33;   // (G, ny, 128)
+    const float *amp33_med;  // (ny, 128)
+    double slope;
+    const double *lines_override;  // device (G, nch, 2) or nullptr
+    double *rowcorr;  // out (G, ny)
+    double *lines;    // out (G, nch, 2)
+    int ny, nx, ngrp;
+};
+int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a);
+int rip_refpix_image(rip_ctx *ctx, float *d_image, int ny, int nx, double slope, int do_row, int do_channel,
+                     const double *d_lines, float *d_ref_med, float *d_ctr, float *d_bottom_top);
+
+// misc.hip
+int rip_launch_embed(rip_ctx *ctx, const void *src, void *dst, int nplanes, int ny, int nx, int nb, int elem_size);
+int rip_launch_flat_prepare(rip_ctx *ctx, const float *flat, const void *gain, int g_dtype, int ny, int nx, int nb,
+                            float *flat_padded, void *gain_clipped, uint32_t *flags, int with_gain);
+int rip_launch_flat_area(rip_ctx *ctx, const float *flat_dn, const double *area, float *out, size_t n);

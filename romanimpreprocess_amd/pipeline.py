@@ -1,0 +1,127 @@
+"""Array-level driver of the L1->L2 chain on one GPU.
+
+``Calibrator`` owns a context, the device-resident CALDIR sets (one slot per SCA) and the ramp-fit
+plans; ``calibrate`` runs the chain of ``calibrateimage`` (``gen_cal_image.py:531-629``) on numpy
+arrays (host) or on device pointers (e.g. torch tensors' ``data_ptr()``), through ``rip_calibrate``.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native, pars, plan as planmod
+from ._native import (STAGE_ALL, STAGE_BIAS, STAGE_DARK, STAGE_FLAT, STAGE_IPC, STAGE_LIN, STAGE_RAMPFIT,  # noqa: F401
+                      STAGE_REFPIX)
+
+
+class Calibrator:
+    def __init__(self, device=None, ctx=None):
+        self.ctx = ctx if ctx is not None else _native.default_context(device)
+        self.shapes = {}
+        self._plans = {}
+
+    # ---- CALDIR ---------------------------------------------------------------------------
+    def load_caldir(self, slot, cal, nborder=pars.nborder):
+        """Upload one SCA's calibration arrays (dict of dicts, ``roman`` branch layout) into ``slot``."""
+        rslope = planmod.refout_slope(cal["read"])
+        self.shapes[slot] = self.ctx.upload_caldir(slot, cal, nborder=nborder, refout_slope=rslope)
+        return self.shapes[slot]
+
+    # ---- plans ----------------------------------------------------------------------------
+    def plan_for(self, read_pattern, frame_time, exclude_first=True, ramp_opt_pars=None, jump_pars=None):
+        """(plan id, meta) for an MA table; cached per configuration."""
+        key = (repr(read_pattern), float(frame_time), bool(exclude_first), repr(ramp_opt_pars), repr(jump_pars))
+        if key in self._plans:
+            return self._plans[key]
+        meta = planmod.exposure_meta(read_pattern, frame_time)
+        meta["nborder"] = pars.nborder
+        meta["K"] = planmod.construct_weights(planmod.ramp_opt_u(ramp_opt_pars), meta, exclude_first)
+        if jump_pars:
+            meta["jump_detect_pars"] = jump_pars
+        desc = planmod.plan_desc(meta, meta["K"], exclude_first, list(read_pattern[0]) == [0], jump_pars)
+        pid = self.ctx.create_plan(desc)
+        self._plans[key] = (pid, meta)
+        return pid, meta
+
+    # ---- host arrays in, host arrays out --------------------------------------------------
+    def calibrate(self, slot, ramp, exclude_first=True, ramp_opt_pars=None, jump_pars=None, area_factor=None,
+                  stages=STAGE_ALL, want_groupdq=True, want_cube=False, channel_lines=None):
+        """Run the chain on one ramp given as numpy arrays.
+
+        ``ramp``: dict(data u16|f32 (G,ny,nx), amp33 u16 (G,ny,128)|None, groupdq u8, pixeldq u32,
+        read_pattern, frame_time).  Returns dict(slope, err_read, err_poisson, pixeldq[, groupdq][, cube], K, meta).
+        """
+        ny, nx = self.shapes[slot]
+        pid, meta = self.plan_for(ramp["read_pattern"], ramp["frame_time"], exclude_first, ramp_opt_pars, jump_pars)
+        data = np.ascontiguousarray(ramp["data"])
+        if data.dtype not in (np.uint16, np.float32):
+            data = data.astype(np.float32)
+        G = data.shape[0]
+        if data.shape != (G, ny, nx):
+            raise ValueError(f"ramp shape {data.shape} does not match the CALDIR frame {(ny, nx)}")
+        gdq = np.array(ramp["groupdq"], dtype=np.uint8, order="C", copy=True)
+        if exclude_first:
+            gdq[0] |= np.uint8(1)  # gen_cal_image.py:142-143
+        pdq = np.ascontiguousarray(ramp["pixeldq"], dtype=np.uint32)
+        amp33 = None if ramp.get("amp33") is None else np.ascontiguousarray(ramp["amp33"], dtype=np.uint16)
+        area = None if area_factor is None else np.ascontiguousarray(area_factor, dtype=np.float64)
+        lines = None if channel_lines is None else np.ascontiguousarray(channel_lines, dtype=np.float64)
+
+        rd = _native.RampDesc()
+        rd.location, rd.ngrp = _native.RIP_HOST, G
+        rd.data, rd.data_dtype = data.ctypes.data, _native.dtype_code(data)
+        rd.amp33 = None if amp33 is None else amp33.ctypes.data
+        rd.groupdq, rd.pixeldq = gdq.ctypes.data, pdq.ctypes.data
+        rd.area_factor = None if area is None else area.ctypes.data
+        rd.channel_lines = None if lines is None else lines.ctypes.data
+
+        res = {
+            "slope": np.empty((ny, nx), np.float32), "err_read": np.empty((ny, nx), np.float32),
+            "err_poisson": np.empty((ny, nx), np.float32), "pixeldq": np.empty((ny, nx), np.uint32),
+        }
+        out = _native.Outputs()
+        out.location = _native.RIP_HOST
+        out.slope, out.err_read = res["slope"].ctypes.data, res["err_read"].ctypes.data
+        out.err_poisson, out.pixeldq = res["err_poisson"].ctypes.data, res["pixeldq"].ctypes.data
+        if want_groupdq:
+            res["groupdq"] = np.empty((G, ny, nx), np.uint8)
+            out.groupdq = res["groupdq"].ctypes.data
+        if want_cube:
+            res["cube"] = np.empty((G, ny, nx), np.float32)
+            out.cube = res["cube"].ctypes.data
+        self.ctx.calibrate_raw(slot, pid, stages, rd, out)
+        if not (stages & STAGE_RAMPFIT):
+            for k in ("slope", "err_read", "err_poisson"):
+                res.pop(k)
+            res.pop("groupdq", None)
+        res["K"], res["meta"] = meta["K"], meta
+        return res
+
+    # ---- device pointers in, device pointers out (asynchronous) ---------------------------
+    def calibrate_device(self, slot, plan_id, ngrp, data_ptr, data_is_u16, amp33_ptr, groupdq_ptr, pixeldq_ptr,
+                         slope_ptr, err_read_ptr, err_poisson_ptr, pixeldq_out_ptr, groupdq_out_ptr=None,
+                         area_ptr=None, stages=STAGE_ALL):
+        rd = _native.RampDesc()
+        rd.location, rd.ngrp = _native.RIP_DEVICE, int(ngrp)
+        rd.data, rd.data_dtype = data_ptr, (_native.RIP_U16 if data_is_u16 else _native.RIP_F32)
+        rd.amp33, rd.groupdq, rd.pixeldq, rd.area_factor = amp33_ptr, groupdq_ptr, pixeldq_ptr, area_ptr
+        out = _native.Outputs()
+        out.location = _native.RIP_DEVICE
+        out.slope, out.err_read, out.err_poisson = slope_ptr, err_read_ptr, err_poisson_ptr
+        out.pixeldq, out.groupdq = pixeldq_out_ptr, groupdq_out_ptr
+        self.ctx.calibrate_raw(slot, plan_id, stages, rd, out)
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+
+def lapack_channel_lines(bottom_top, nrows):
+    """(m, c) of the line through (1.5, bottom), (nrows-2.5, top) from LAPACK's least squares, exactly as
+    ``reference_subtraction.py:57-60`` obtains it; ``bottom_top`` (..., 2) f32 -> (..., 2) f64."""
+    bt = np.asarray(bottom_top)
+    A = np.vstack([(1.5, nrows - 2.5), np.ones(2)]).T
+    out = np.zeros(bt.shape, dtype=np.float64)
+    flat_in, flat_out = bt.reshape(-1, 2), out.reshape(-1, 2)
+    for i in range(flat_in.shape[0]):
+        flat_out[i] = np.linalg.lstsq(A, (flat_in[i, 0], flat_in[i, 1]), rcond=None)[0]
+    return out

@@ -26,8 +26,8 @@ def golden():
     return load_golden
 
 
-def assert_same_bits(a, b, what=""):
-    """bit-for-bit equality (NaN == NaN, -0 != +0), dtype and shape included."""
+def assert_same_bits(a, b, what="", zero_sign_ok=False):
+    """bit-for-bit equality (NaN == NaN; -0 != +0 unless zero_sign_ok), dtype and shape included."""
     a, b = np.asarray(a), np.asarray(b)
     assert a.dtype == b.dtype, f"{what}: dtype {a.dtype} != {b.dtype}"
     assert a.shape == b.shape, f"{what}: shape {a.shape} != {b.shape}"
@@ -36,9 +36,17 @@ def assert_same_bits(a, b, what=""):
         # NaNs of any payload compare equal
         both_nan = np.isnan(a) & np.isnan(b)
         bad = (ai != bi) & ~both_nan
+        if zero_sign_ok:
+            bad &= ~((a == 0) & (b == 0))
     else:
         bad = a != b
     n = int(np.count_nonzero(bad))
     if n:
         idx = tuple(np.argwhere(bad)[0])
         raise AssertionError(f"{what}: {n} of {a.size} elements differ; first at {idx}: {a[idx]!r} vs {b[idx]!r}")
+
+
+def gpu_context():
+    """The process-wide libromanhip context; the test FAILS (not skips) if the library or GPU is missing."""
+    from romanimpreprocess_amd import _native
+    return _native.default_context(0)

@@ -1,0 +1,111 @@
+"""The whole chain (rip_calibrate) on the GPU vs the CPU oracle on seeded synthetic ramps."""
+
+import numpy as np
+import pytest
+from conftest import assert_same_bits, gpu_context
+
+import oracle
+from romanimpreprocess_amd import pipeline, synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # name, (ny, nx), read pattern, p_order, gain dtype, ipc dtype
+    ("g8_f32", (64, 256), synth.READ_PATTERN_8, 8, np.float32, np.float32),
+    ("g6_prod_dtypes", (48, 384), synth.READ_PATTERN_6, 3, np.float32, np.float64),
+    ("g16_test_dtypes", (40, 128), synth.READ_PATTERN_16, 10, np.float64, np.float32),
+]
+
+
+def _oracle_lines(out, G, nch):
+    """(G, nch, 2) LAPACK (m, c) the oracle used for the science channels."""
+    lines = np.zeros((G, nch, 2))
+    for g in range(G):
+        lines[g] = out["refpix_diag"][g]["channels"][:nch, 2:4]
+    return lines
+
+
+@pytest.mark.parametrize("name,shape,rp,p,gdt,kdt", CASES)
+def test_chain_vs_oracle(name, shape, rp, p, gdt, kdt):
+    ny, nx = shape
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=p, seed=77, gain_dtype=gdt, ipc_dtype=kdt,
+                            bias_amplitude=2.0, bad_lin_frac=0.01)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=78, cr_frac=0.02)
+    area = 1.0 + 0.01 * np.cos(np.arange(ny * nx, dtype=np.float64).reshape(ny, nx) / 50.0)
+    ref = oracle.calibrate_arrays(ramp, cal, area_factor=area)
+
+    cb = pipeline.Calibrator(ctx=gpu_context())
+    cb.load_caldir(3, cal)
+    # (1) with LAPACK's channel lines handed in: everything bit-identical to the oracle
+    lines = _oracle_lines(ref, len(rp), nx // 128)
+    got = cb.calibrate(3, ramp, area_factor=area, want_cube=True, channel_lines=lines)
+    assert_same_bits(got["K"], ref["K"], "K")
+    assert_same_bits(got["cube"], ref["data"], "corrected cube", zero_sign_ok=True)
+    assert_same_bits(got["groupdq"], ref["groupdq"], "groupdq")
+    assert_same_bits(got["pixeldq"], ref["pixeldq"], "pixeldq")
+    for k in ("slope", "err_read", "err_poisson"):
+        assert_same_bits(got[k], ref[k], k, zero_sign_ok=True)
+    assert np.count_nonzero(got["pixeldq"] & 4) > 5 and np.count_nonzero(got["pixeldq"] & 2) > 5
+
+    # (2) channel lines fitted on the device: DQ identical, floats within the north-star tolerance
+    got2 = cb.calibrate(3, ramp, area_factor=area)
+    assert_same_bits(got2["groupdq"], ref["groupdq"], "groupdq (device lines)")
+    assert_same_bits(got2["pixeldq"], ref["pixeldq"], "pixeldq (device lines)")
+    # tolerance: 1e-5 relative on the slope (BASELINE.json north star), errors relative to the total error
+    np.testing.assert_allclose(got2["slope"], ref["slope"], rtol=1e-5, atol=1e-7)
+    tot = np.hypot(ref["err_read"], ref["err_poisson"])
+    assert np.all(np.abs(got2["err_read"] - ref["err_read"]) <= 1e-5 * tot + 1e-12)
+    assert np.all(np.abs(got2["err_poisson"] - ref["err_poisson"]) <= 1e-5 * tot + 1e-12)
+    cb.ctx.drop_caldir(3)
+
+
+def test_stage_subsets_and_f32_input():
+    """stage mask: reduced chain of BASELINE config 1 (ramp fit + dark rate on an already-corrected f32 cube)."""
+    rp = synth.READ_PATTERN_8
+    ny, nx = 40, 128
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=3, seed=5)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=6, cr_frac=0.02)
+    full = oracle.calibrate_arrays(ramp, cal)
+    from oracle import finish, rampfit
+    meta = rampfit.ma_table_meta(rp, synth.FRAME_TIME)
+    meta["nborder"] = 4
+    meta["K"] = full["K"]
+    rdq = ramp["groupdq"].copy()
+    pdq = ramp["pixeldq"].copy()
+    s, er, ep = rampfit.ramp_fit(full["data"], rdq, pdq, cal["gain"]["data"], cal["read"]["data"], meta, True, None)
+    dark_rate = finish.dark_rate_deconvolved(cal["dark"]["dark_slope"], cal["ipc4d"]["data"], cal["gain"]["data"])
+    s, er, ep = finish.finish(s, er, ep, pdq, 4, dark_rate, None, None, None)
+
+    cb = pipeline.Calibrator(ctx=gpu_context())
+    cb.load_caldir(0, cal)
+    r2 = dict(ramp)
+    r2["data"] = full["data"]  # f32 cube, already corrected
+    got = cb.calibrate(0, r2, stages=pipeline.STAGE_RAMPFIT | pipeline.STAGE_DARK)
+    assert_same_bits(got["pixeldq"], pdq, "pixeldq")
+    assert_same_bits(got["groupdq"], rdq, "groupdq")
+    assert_same_bits(got["slope"], s, "slope", zero_sign_ok=True)
+    assert_same_bits(got["err_read"], er, "err_read", zero_sign_ok=True)
+    assert_same_bits(got["err_poisson"], ep, "err_poisson", zero_sign_ok=True)
+    # cube-only sub-chain: refpix + bias + linearity, no fit
+    lines = _oracle_lines(full, len(rp), nx // 128)
+    part = cb.calibrate(0, ramp, stages=pipeline.STAGE_REFPIX | pipeline.STAGE_BIAS | pipeline.STAGE_LIN, want_cube=True,
+                        channel_lines=lines)
+    assert "slope" not in part
+    ref_lin = oracle.calibrate_arrays(ramp, {k: v for k, v in cal.items() if k != "ipc4d"})
+    assert_same_bits(part["cube"], ref_lin["data"], "cube after linearity", zero_sign_ok=True)
+
+
+def test_bad_arguments():
+    cb = pipeline.Calibrator(ctx=gpu_context())
+    rp = synth.READ_PATTERN_6
+    cal = synth.make_caldir(32, 128, read_pattern=rp, p_order=3, seed=1)
+    cb.load_caldir(1, cal)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=2)
+    bad = dict(ramp)
+    bad["data"] = ramp["data"][:, :, :64]
+    with pytest.raises(ValueError):
+        cb.calibrate(1, bad)
+    with pytest.raises(ValueError):
+        cb.ctx.drop_caldir(9)
+    with pytest.raises(KeyError):
+        cb.calibrate(7, ramp)  # never loaded

@@ -1,0 +1,173 @@
+"""HIP stage kernels vs the reference's own outputs (golden fixtures) -- bit for bit.
+
+Every call goes through the C-ABI of libromanhip.so (ctypes) via the function-level drop-ins in
+romanimpreprocess_amd.utils.  Float planes are compared bit-exactly (the sign of an exact zero is
+not pinned: numpy's own maximum() is not consistent about it between SIMD body and scalar tail);
+integer DQ arrays bit-exactly.
+"""
+
+import hashlib
+import json
+
+import numpy as np
+import pytest
+from conftest import assert_same_bits, gpu_context, load_golden
+
+import golden_cases as gc
+from romanimpreprocess_amd import plan as planmod
+from romanimpreprocess_amd import synth
+from romanimpreprocess_amd.utils import fitting, flatutils, ipc_linearity, reference_subtraction
+from romanimpreprocess_amd.utils.processlog import ProcessLog
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["multilin_p3_g6", "multilin_p8_g8", "multilin_p8_g8_flagfirst", "multilin_p10_g16"])
+def test_multilin(name):
+    g = load_golden(name)
+    lin_file = {"roman": {"data": g["coefs"], "Smin": g["Smin"], "Smax": g["Smax"], "Sref": g["Sref"], "dq": g["lin_dq"]}}
+    ac = (~g["groupdq"] & np.uint8(2)) if bool(g["use_attempt_corr"]) else None
+    phi, dq = ipc_linearity.multilin(g["S"], lin_file, do_not_flag_first=bool(g["do_not_flag_first"]), attempt_corr=ac,
+                                     ctx=gpu_context())
+    assert_same_bits(phi, g["phi"], "phi", zero_sign_ok=True)
+    assert_same_bits(dq, g["dq"], "dq")
+
+
+def test_multilin_origin_window():
+    g = load_golden("multilin_p8_g8")
+    lin_file = {"roman": {"data": g["coefs"], "Smin": g["Smin"], "Smax": g["Smax"], "Sref": g["Sref"], "dq": g["lin_dq"]}}
+    sub = g["S"][:, 8:30, 16:50]
+    ac = (~g["groupdq"] & np.uint8(2))[:, 8:30, 16:50]
+    phi, dq = ipc_linearity.multilin(sub, lin_file, origin=(16, 8), attempt_corr=ac, ctx=gpu_context())
+    assert_same_bits(phi, g["phi"][:, 8:30, 16:50], "phi window", zero_sign_ok=True)
+    assert_same_bits(dq, g["dq"][8:30, 16:50], "dq window")
+
+
+@pytest.mark.parametrize("name", ["ipc_f32", "ipc_k64", "ipc_g64", "ipc_g64_k64"])
+def test_ipc(name):
+    g = load_golden(name)
+    ctx = gpu_context()
+    act = g["cube"][0, 4:-4, 4:-4]
+    gact = g["gain"][4:-4, 4:-4]
+    assert_same_bits(ipc_linearity.ipc_fwd(act, g["K"], ctx=ctx), g["fwd"], "fwd", zero_sign_ok=True)
+    assert_same_bits(ipc_linearity.ipc_fwd(act, g["K"], gain=gact, ctx=ctx), g["fwd_g"], "fwd_g", zero_sign_ok=True)
+    assert_same_bits(ipc_linearity.ipc_rev(act, g["K"], ctx=ctx), g["rev"], "rev", zero_sign_ok=True)
+    assert_same_bits(ipc_linearity.ipc_rev(act, g["K"], gain=gact, ctx=ctx), g["rev_g"], "rev_g", zero_sign_ok=True)
+    cube = g["cube"].copy()
+    log = ProcessLog()
+    ipc_linearity.correct_cube(cube, {"roman": {"data": g["K"]}}, log, gain_file={"roman": {"data": g["gain"]}}, ctx=ctx)
+    assert_same_bits(cube, g["cube_gain"], "correct_cube gain", zero_sign_ok=True)
+    assert "excluding 4 border pixels" in log.output
+    cube = g["cube"].copy()
+    ipc_linearity.correct_cube(cube, {"roman": {"data": g["K"]}}, None, gain_file=None, ctx=ctx)
+    assert_same_bits(cube, g["cube_nogain"], "correct_cube nogain", zero_sign_ok=True)
+    # no IPC file: no-op + log line (ipc_linearity.py:165-168)
+    cube2 = g["cube"].copy()
+    log = ProcessLog()
+    ipc_linearity.correct_cube(cube2, None, log)
+    assert np.array_equal(cube2, g["cube"]) and "skipping" in log.output
+
+
+RAMPFIT = ["rampfit_g8", "rampfit_g6_custom", "rampfit_g16", "rampfit_g8_include_first", "rampfit_g8_gain64", "rampfit_g4"]
+
+
+def _rampfit_inputs(g):
+    rp = json.loads(str(g["read_pattern"]))
+    ef = bool(g["exclude_first"])
+    jp = json.loads(str(g["jump_pars"]))
+    meta = planmod.exposure_meta(rp, synth.FRAME_TIME)
+    meta["nborder"] = 4
+    meta["K"] = fitting.construct_weights(0.4 / 1.8 / 6.5**2, meta, exclude_first=ef)
+    if jp:
+        meta["jump_detect_pars"] = jp
+    caldir = {"gain": {"roman": {"data": g["gain"]}}, "read": {"roman": {"data": g["read"]}}}
+    return meta, caldir, ef
+
+
+@pytest.mark.parametrize("guard", [1e-5, float("inf")])
+@pytest.mark.parametrize("name", RAMPFIT)
+def test_ramp_fit(name, guard):
+    """guard = inf forces the exact-order variance everywhere; 1e-5 is the production setting (f32 fast path with
+    exact re-evaluation inside the band): both must give the reference's flags."""
+    g = load_golden(name)
+    ctx = gpu_context()
+    meta, caldir, ef = _rampfit_inputs(g)
+    assert_same_bits(meta["K"], g["K"], "K")
+    rdq, pdq = g["groupdq"].copy(), g["pixeldq"].copy()
+    ctx.lib.rip_set_guard_band(guard)
+    try:
+        slope, er, ep = fitting.ramp_fit(g["data"], rdq, pdq, meta, caldir, ProcessLog(), exclude_first=ef, ctx=ctx)
+    finally:
+        ctx.lib.rip_set_guard_band(1e-5)
+    assert_same_bits(rdq, g["groupdq_out"], "groupdq")
+    assert_same_bits(pdq, g["pixeldq_out"], "pixeldq")
+    assert_same_bits(slope, g["slope"], "slope", zero_sign_ok=True)
+    assert_same_bits(er, g["err_read"], "err_read", zero_sign_ok=True)
+    assert_same_bits(ep, g["err_poisson"], "err_poisson", zero_sign_ok=True)
+
+
+def test_ramp_fit_errors():
+    g = load_golden("rampfit_g8")
+    meta, caldir, ef = _rampfit_inputs(g)
+    with pytest.raises(ValueError):
+        fitting.ramp_fit(g["data"][:5], g["groupdq"].copy(), g["pixeldq"].copy(), meta, caldir, None, ctx=gpu_context())
+    with pytest.raises(KeyError):
+        fitting.ramp_fit(g["data"], g["groupdq"].copy(), g["pixeldq"].copy(), meta, {"gain": caldir["gain"]}, None,
+                         ctx=gpu_context())
+
+
+@pytest.mark.parametrize("name", ["flat_f32", "flat_g64"])
+def test_get_flat(name):
+    g = load_golden(name)
+    ctx = gpu_context()
+    caldir = {"flat": {"roman": {"data": g["flat"]}}, "gain": {"roman": {"data": g["gain"]}},
+              "ipc4d": {"roman": {"data": g["K"]}}}
+    pdq = g["pixeldq"].copy()
+    out = flatutils.get_flat(caldir, {"nborder": 4}, pdq, ctx=ctx)
+    assert_same_bits(out, g["flat_out"], "flat")
+    assert_same_bits(pdq, g["pixeldq_out"], "pdq")
+    assert_same_bits(flatutils.get_flat(caldir, {"nborder": 4}, None, ctx=ctx), g["flat_out_nopdq"], "flat (no pdq)")
+    assert_same_bits(flatutils.get_flat(caldir, {"nborder": 4}, g["pixeldq"].copy(), ipc_deconvolve=False, ctx=ctx),
+                     g["flat_out_noipc"], "flat (no ipc)")
+
+
+@pytest.mark.parametrize("name", ["refpix_full_a", "refpix_full_b"])
+def test_refpix_fullframe(name):
+    """Full 4096 x 4224 frame through ref_subtraction_row + ref_subtraction_channel.  Medians are exact; the
+    channel line is (a) LAPACK's, passed in -> bit-identical image; (b) fitted on the device -> the image may
+    differ by one f32 ulp on a handful of pixels (the reference's own lstsq is only defined up to LAPACK rounding)."""
+    g = load_golden(name)
+    c = gc.refpix_fullframe_inputs(int(g["seed"]))
+    ctx = gpu_context()
+    n = 4096
+    image = np.zeros((n, n + 128), dtype=np.float32)
+    image[:, :n] = c["data"] - c["dark"]
+    image[:, -128:] = c["amp33"] - c["med"]
+    image[:, -128:] -= g["amp33_median"]
+    slope = planmod.refout_slope({"amp33": {"std": c["std"], "M_PINK": c["M_PINK"], "RU_PINK": c["RU_PINK"]},
+                                  "anc": {"C_PINK": c["C_PINK"]}})
+    assert slope == float(g["slope"])
+    ref_med = np.empty(n, np.float32)
+    ctr = np.empty(1, np.float32)
+    ctx.check(ctx.lib.rip_stage_refpix_image(ctx.h, image.ctypes.data, n, n, float(slope), 1, 0, None,
+                                             ref_med.ctypes.data, ctr.ctypes.data, None))
+    assert_same_bits(ref_med, g["ref_med"], "row medians")
+    assert_same_bits(ctr[0], g["ctr"], "ctr")
+    assert hashlib.sha256(image.tobytes()).hexdigest() == str(g["after_row_sha256"])
+    # (a) LAPACK lines from the exact medians
+    from romanimpreprocess_amd.pipeline import lapack_channel_lines
+    lines = lapack_channel_lines(g["bottom_top"], n)
+    img_a = image.copy()
+    bt = np.empty((33, 2), np.float32)
+    ctx.check(ctx.lib.rip_stage_refpix_image(ctx.h, img_a.ctypes.data, n, n, 0.0, 0, 1, lines.ctypes.data, None, None,
+                                             bt.ctypes.data))
+    assert_same_bits(bt, g["bottom_top"], "channel medians")
+    assert hashlib.sha256(img_a.tobytes()).hexdigest() == str(g["image_sha256"])
+    out = img_a[:, :n] + c["dark"]
+    assert hashlib.sha256(out.tobytes()).hexdigest() == str(g["data_sha256"])
+    # (b) device line fit
+    img_b = reference_subtraction.ref_subtraction_channel(image.copy(), use_ref_channel=True, ctx=ctx)
+    diff = img_b != img_a
+    assert np.count_nonzero(diff) < 2000, np.count_nonzero(diff)
+    ulp = np.abs(img_b.view(np.int32).astype(np.int64) - img_a.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 or np.abs(img_b - img_a).max() < 1e-5
