@@ -46,14 +46,14 @@ struct Promote<double, double> {
 
 // forward operator at one destination, reading the source image from an LDS tile `S` with row
 // stride `stride`, centred at S[0]; kk[k] = coefficient of term k, valid bit k = source k is active
-template <typename T, typename KT>
-__device__ __forceinline__ T fwd_at(const T *S, int stride, const KT (&kk)[9], unsigned valid) {
-    T acc = S[0] * (T)kk[0];
+template <typename T, typename ST, typename KT>
+__device__ __forceinline__ T fwd_at(const ST *S, int stride, const KT (&kk)[9], unsigned valid) {
+    T acc = (T)S[0] * (T)kk[0];
 #pragma unroll
     for (int k = 1; k < 9; ++k) {
         const int dy = (k == 1 || k == 5 || k == 6) ? 1 : (k == 2 || k == 7 || k == 8) ? -1 : 0;
         const int dx = (k == 3 || k == 5 || k == 7) ? 1 : (k == 4 || k == 6 || k == 8) ? -1 : 0;
-        T prod = S[-dy * stride - dx] * (T)kk[k];
+        T prod = (T)S[-dy * stride - dx] * (T)kk[k];
         T sum = acc + prod;
         acc = (valid >> k) & 1u ? sum : acc;
     }
@@ -80,8 +80,11 @@ __device__ __forceinline__ unsigned load_coeffs(const KT *__restrict__ kern, siz
 
 template <typename KT, typename GT, bool HAS_GAIN>
 __global__ __launch_bounds__(IPC_THREADS) void ipc_cube_kernel(IpcArgs a) {
-    using T = typename Promote<KT, GT>::type;
-    __shared__ T X[IPC_XH * IPC_XW];   // gain * data on tile + halo 2
+    // dtype walk of ipc_linearity.py:186,134-142: x = data*g in XT = promote(f32, gain); the first
+    // "output + image2" is still in XT; everything that touches the kernel is in T = promote(XT, kernel)
+    using XT = typename Promote<float, GT>::type;
+    using T = typename Promote<XT, KT>::type;
+    __shared__ XT X[IPC_XH * IPC_XW];  // gain * data on tile + halo 2
     __shared__ T O1[IPC_OH * IPC_OW];  // first Neumann iterate on tile + halo 1
     __shared__ GT GL[IPC_XH * IPC_XW];
 
@@ -134,10 +137,10 @@ __global__ __launch_bounds__(IPC_THREADS) void ipc_cube_kernel(IpcArgs a) {
         for (int idx = tid; idx < IPC_XH * IPC_XW; idx += IPC_THREADS) {
             const int y = Y0 - 2 + idx / IPC_XW, x = X0 - 2 + idx % IPC_XW;
             const bool ok = (y >= ay0 && y < ay1 && x >= ax0 && x < ax1);
-            T v = (T)0;
+            XT v = (XT)0;
             if (ok) {
-                v = (T)in[(size_t)y * nx + x];
-                if (HAS_GAIN) v = v * (T)GL[idx];
+                v = (XT)in[(size_t)y * nx + x];
+                if (HAS_GAIN) v = v * (XT)GL[idx];
             }
             X[idx] = v;
         }
@@ -146,14 +149,14 @@ __global__ __launch_bounds__(IPC_THREADS) void ipc_cube_kernel(IpcArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ly = tyb + 4 * q, lx = tx;  // tile coordinates
-            const T *c = &X[(ly + 2) * IPC_XW + (lx + 2)];
-            T f = fwd_at<T, KT>(c, IPC_XW, kt[q], vt[q]);
-            O1[(ly + 1) * IPC_OW + (lx + 1)] = (c[0] + c[0]) - f;
+            const XT *c = &X[(ly + 2) * IPC_XW + (lx + 2)];
+            T f = fwd_at<T, XT, KT>(c, IPC_XW, kt[q], vt[q]);
+            O1[(ly + 1) * IPC_OW + (lx + 1)] = (T)(c[0] + c[0]) - f;
         }
         if (tid < IPC_RING) {
-            const T *c = &X[(rly + 1) * IPC_XW + (rlx + 1)];
-            T f = fwd_at<T, KT>(c, IPC_XW, kr, vr);
-            O1[rly * IPC_OW + rlx] = (c[0] + c[0]) - f;
+            const XT *c = &X[(rly + 1) * IPC_XW + (rlx + 1)];
+            T f = fwd_at<T, XT, KT>(c, IPC_XW, kr, vr);
+            O1[rly * IPC_OW + rlx] = (T)(c[0] + c[0]) - f;
         }
         __syncthreads();
         // second iterate: out2 = (out1 + x) - fwd(out1); result / gain
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(IPC_THREADS) void ipc_cube_kernel(IpcArgs a) {
                 float res;
                 if (act) {
                     const T *c1 = &O1[(ly + 1) * IPC_OW + (lx + 1)];
-                    const T xc = X[(ly + 2) * IPC_XW + (lx + 2)];
-                    T f = fwd_at<T, KT>(c1, IPC_OW, kt[q], vt[q]);
+                    const T xc = (T)X[(ly + 2) * IPC_XW + (lx + 2)];
+                    T f = fwd_at<T, T, KT>(c1, IPC_OW, kt[q], vt[q]);
                     T o2 = (c1[0] + xc) - f;
                     if (HAS_GAIN) o2 = o2 / (T)GL[(ly + 2) * IPC_XW + (lx + 2)];
                     res = (float)o2;
@@ -210,31 +213,31 @@ int rip_launch_ipc_cube(rip_ctx *ctx, const IpcArgs &a) {
 // (function-level drop-ins for ipc_fwd / ipc_rev on an arbitrary image: any dtype mix, any order;
 //  straightforward global-memory kernels, not on the throughput path)
 
-template <typename T, typename IT, typename GT>
-__global__ void ipc_scale_kernel(const IT *img, const GT *gain, T *out, size_t n) {
+template <typename XT, typename IT, typename GT>
+__global__ void ipc_scale_kernel(const IT *img, const GT *gain, XT *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = gain ? (T)gain[i] * (T)img[i] : (T)img[i];
+    if (i < n) out[i] = gain ? (XT)gain[i] * (XT)img[i] : (XT)img[i];
 }
 
-// dst = fwd(src) (mode 0) or dst = (src + x) - fwd(src) (mode 1)
-template <typename T, typename KT>
-__global__ void ipc_fwd_image_kernel(const T *src, const T *x, const KT *kern, T *dst, int ny, int nx, int mode) {
+// dst = fwd(src) (mode 0) or dst = (src + x) - fwd(src) (mode 1); the sum is formed in the type of src
+template <typename T, typename ST, typename XT, typename KT>
+__global__ void ipc_fwd_image_kernel(const ST *src, const XT *x, const KT *kern, T *dst, int ny, int nx, int mode) {
     const int xx = blockIdx.x * blockDim.x + threadIdx.x, yy = blockIdx.y;
     if (xx >= nx || yy >= ny) return;
     const size_t plane = (size_t)ny * nx;
     const size_t c = (size_t)yy * nx + xx;
-    T acc = src[c] * (T)kern[4 * plane + c];
+    T acc = (T)src[c] * (T)kern[4 * plane + c];
 #pragma unroll
     for (int k = 1; k < 9; ++k) {
         const int dy = IPC_DY[k], dx = IPC_DX[k];
         const int sy = yy - dy, sx = xx - dx;
         if (sy >= 0 && sy < ny && sx >= 0 && sx < nx) {
             const size_t s = (size_t)sy * nx + sx;
-            T prod = src[s] * (T)kern[(size_t)(3 * (1 + dy) + (1 + dx)) * plane + s];
+            T prod = (T)src[s] * (T)kern[(size_t)(3 * (1 + dy) + (1 + dx)) * plane + s];
             acc = acc + prod;
         }
     }
-    dst[c] = mode ? (src[c] + x[c]) - acc : acc;
+    dst[c] = mode ? (T)(src[c] + (ST)x[c]) - acc : acc;
 }
 
 template <typename T, typename GT>
@@ -243,29 +246,33 @@ __global__ void ipc_unscale_kernel(T *buf, const GT *gain, size_t n) {
     if (i < n && gain) buf[i] = buf[i] / (T)gain[i];
 }
 
-template <typename T, typename IT, typename KT, typename GT>
+template <typename T, typename XT, typename IT, typename KT, typename GT>
 static int ipc_image_typed(rip_ctx *ctx, int reverse, int order, const void *img, int ny, int nx, const void *kern,
                            const void *gain, void *out) {
+    // XT = dtype of gain*image (image alone without gain); T = promote(XT, kernel) = output dtype
     const size_t n = (size_t)ny * nx;
-    T *xbuf = (T *)rip_ws(ctx, 5, n * sizeof(T));
+    XT *xbuf = (XT *)rip_ws(ctx, 5, n * sizeof(XT));
     T *abuf = (T *)rip_ws(ctx, 6, n * sizeof(T));
     T *bbuf = (T *)out;
     if (!xbuf || !abuf) return RIP_ENOMEM;
     const unsigned nb1 = (unsigned)((n + 255) / 256);
     dim3 g2((nx + 255) / 256, ny);
-    hipLaunchKernelGGL((ipc_scale_kernel<T, IT, GT>), dim3(nb1), dim3(256), 0, ctx->stream, (const IT *)img,
+    hipLaunchKernelGGL((ipc_scale_kernel<XT, IT, GT>), dim3(nb1), dim3(256), 0, ctx->stream, (const IT *)img,
                        (const GT *)gain, xbuf, n);
     if (!reverse) {
-        hipLaunchKernelGGL((ipc_fwd_image_kernel<T, KT>), g2, dim3(256), 0, ctx->stream, xbuf, xbuf, (const KT *)kern,
-                           bbuf, ny, nx, 0);
+        hipLaunchKernelGGL((ipc_fwd_image_kernel<T, XT, XT, KT>), g2, dim3(256), 0, ctx->stream, (const XT *)xbuf,
+                           (const XT *)xbuf, (const KT *)kern, bbuf, ny, nx, 0);
     } else {
-        // out_0 = x ; out_{n+1} = (out_n + x) - fwd(out_n)
-        const T *cur = xbuf;
+        // out_0 = x ; out_{n+1} = (out_n + x) - fwd(out_n); out_0 + x is still in the dtype of x
+        if (order == 0) return rip_fail(ctx, RIP_EINVAL, "ipc_rev: order must be >= 1");
         T *dst = (order % 2) ? bbuf : abuf;
-        if (order == 0) RIP_HIP(ctx, hipMemcpyAsync(bbuf, xbuf, n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
-        for (int it = 0; it < order; ++it) {
-            hipLaunchKernelGGL((ipc_fwd_image_kernel<T, KT>), g2, dim3(256), 0, ctx->stream, cur, xbuf,
-                               (const KT *)kern, dst, ny, nx, 1);
+        hipLaunchKernelGGL((ipc_fwd_image_kernel<T, XT, XT, KT>), g2, dim3(256), 0, ctx->stream, (const XT *)xbuf,
+                           (const XT *)xbuf, (const KT *)kern, dst, ny, nx, 1);
+        const T *cur = dst;
+        dst = (dst == abuf) ? bbuf : abuf;
+        for (int it = 1; it < order; ++it) {
+            hipLaunchKernelGGL((ipc_fwd_image_kernel<T, T, XT, KT>), g2, dim3(256), 0, ctx->stream, cur,
+                               (const XT *)xbuf, (const KT *)kern, dst, ny, nx, 1);
             cur = dst;
             dst = (dst == abuf) ? bbuf : abuf;
         }
@@ -278,11 +285,11 @@ static int ipc_image_typed(rip_ctx *ctx, int reverse, int order, const void *img
 int rip_launch_ipc_image(rip_ctx *ctx, int reverse, int order, const void *img, int img_dtype, int ny, int nx,
                          const void *kern, int k_dtype, const void *gain, int g_dtype, void *out, int) {
     const bool i64 = img_dtype == RIP_F64, k64 = k_dtype == RIP_F64, g64 = gain && g_dtype == RIP_F64;
-    const bool t64 = i64 || k64 || g64;
-#define RIP_IPC_CASE(TI, TK, TG)                                                                          \
-    if (i64 == (sizeof(TI) == 8) && k64 == (sizeof(TK) == 8) && g64 == (sizeof(TG) == 8)) {               \
-        if (t64) return ipc_image_typed<double, TI, TK, TG>(ctx, reverse, order, img, ny, nx, kern, gain, out); \
-        return ipc_image_typed<float, TI, TK, TG>(ctx, reverse, order, img, ny, nx, kern, gain, out);      \
+#define RIP_IPC_CASE(TI, TK, TG)                                                                      \
+    if (i64 == (sizeof(TI) == 8) && k64 == (sizeof(TK) == 8) && g64 == (sizeof(TG) == 8)) {           \
+        using XT_ = typename Promote<TI, TG>::type;                                                   \
+        using T_ = typename Promote<XT_, TK>::type;                                                   \
+        return ipc_image_typed<T_, XT_, TI, TK, TG>(ctx, reverse, order, img, ny, nx, kern, gain, out); \
     }
     RIP_IPC_CASE(float, float, float)
     RIP_IPC_CASE(float, float, double)
