@@ -190,6 +190,19 @@ int rip_stage_ramp_fit(rip_ctx *ctx, int plan_id, const float *data, uint8_t *rd
 int rip_stage_get_flat(rip_ctx *ctx, const float *flat, int ny, int nx, int nb, const void *gain, int g_dtype,
                        const void *kernel, int k_dtype, int ipc_deconvolve, uint32_t *pdq, float *out);
 
+/* ---- measurement -------------------------------------------------------------------------- */
+/* When enabled, rip_calibrate brackets each kernel group with HIP events on the ctx stream.
+   rip_profile_read synchronises and returns the summed device time (ms) since the last read:
+   out_ms[0] reference-pixel pre-pass, [1] cube stage (refpix apply + bias + linearity),
+   [2] IPC, [3] ramp fit + finish; *ncalls = number of rip_calibrate calls summed. */
+int rip_profile_enable(rip_ctx *ctx, int on);
+int rip_profile_read(rip_ctx *ctx, double out_ms[4], int *ncalls);
+
+/* options: "fused" (default 1) -- run linearity + IPC + ramp fit as the single fused kernel when the
+   configuration allows it (f32 gain; 4, 9 or 11 Legendre planes; LDS budget); 0 forces the
+   stage-by-stage kernels.  Both give identical results. */
+int rip_set_option(rip_ctx *ctx, const char *name, int value);
+
 /* ---- diagnostics ------------------------------------------------------------------------- */
 /* relative half-width of the band around the jump threshold inside which the significance is
    re-evaluated in the reference's exact operation order (default 1e-5; INFINITY = always exact).

@@ -88,6 +88,9 @@ SYMBOLS = {
     "rip_stage_ramp_fit": (_I, [_VP, _I, _VP, _VP, _VP, _I, _I, _I, _VP, _I, _VP, _VP, _VP, _VP]),
     "rip_stage_get_flat": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _VP, _I, _I, _VP, _VP]),
     "rip_set_guard_band": (None, [C.c_double]),
+    "rip_set_option": (_I, [_VP, C.c_char_p, _I]),
+    "rip_profile_enable": (_I, [_VP, _I]),
+    "rip_profile_read": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(_I)]),
 }
 
 _lib = None
@@ -171,6 +174,19 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.rip_synchronize(self.h))
+
+    def set_option(self, name, value):
+        self.check(self.lib.rip_set_option(self.h, name.encode(), int(value)))
+
+    def profile(self, on=True):
+        self.check(self.lib.rip_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self):
+        """(ms per stage [refpix pre-pass, cube stage, ipc, ramp fit], number of calls) since the last read."""
+        ms = (C.c_double * 4)()
+        n = C.c_int(0)
+        self.check(self.lib.rip_profile_read(self.h, ms, C.byref(n)))
+        return list(ms), n.value
 
     @property
     def stream(self):

@@ -80,8 +80,9 @@ int dev_copy_in(rip_ctx *ctx, void **dst, const void *src, size_t bytes) {
 }
 
 void free_cal(RipCal &c) {
-    void *ptrs[] = {c.dark_data, c.dark_slope, c.dark_rate, c.dark_dq,  c.read_noise, c.amp33_med, c.gain,      c.lin_coefs,
-                    c.lin_smin,  c.lin_smax,   c.lin_sref,  c.lin_dq,   c.ipc,        c.flat_dn,   c.flat_flags, c.bias};
+    // everything else (linearity planes, gain if f32, read noise, dark rate, flat planes) lives in the slab
+    void *ptrs[] = {c.dark_data, c.dark_slope, c.dark_dq, c.amp33_med, c.ipc, c.bias, c.slab,
+                    c.gain_dtype == RIP_F64 ? c.gain : nullptr};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     c = RipCal();
@@ -147,6 +148,35 @@ void *rip_stream(rip_ctx *ctx) { return (void *)ctx->stream; }
 
 void rip_set_guard_band(double rel) { rip_guard_band = rel; }
 
+int rip_set_option(rip_ctx *ctx, const char *name, int value) {
+    if (name && strcmp(name, "fused") == 0) {
+        ctx->use_fused = value != 0;
+        return RIP_OK;
+    }
+    return rip_fail(ctx, RIP_EINVAL, "unknown option %s", name ? name : "(null)");
+}
+
+int rip_profile_enable(rip_ctx *ctx, int on) {
+    ctx->prof = on != 0;
+    return RIP_OK;
+}
+
+int rip_profile_read(rip_ctx *ctx, double out_ms[4], int *ncalls) {
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; ++i) out_ms[i] = 0.0;
+    const size_t n = ctx->prof_events.size() / 5;
+    for (size_t c = 0; c < n; ++c)
+        for (int i = 0; i < 4; ++i) {
+            float ms = 0.f;
+            RIP_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_events[c * 5 + i], ctx->prof_events[c * 5 + i + 1]));
+            out_ms[i] += ms;
+        }
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    ctx->prof_events.clear();
+    if (ncalls) *ncalls = (int)n;
+    return RIP_OK;
+}
+
 // --------------------------------------------------------------------------- CALDIR
 int rip_caldir_drop(rip_ctx *ctx, int slot) {
     if (slot < 0 || slot >= (int)ctx->cals.size() || !ctx->cals[slot].valid)
@@ -182,27 +212,50 @@ int rip_caldir_upload(rip_ctx *ctx, int slot, const rip_caldir_desc *d) {
         free_cal(c);                                                \
         return rc;                                                  \
     }
+    if (d->lin_coefs && (!d->lin_smin || !d->lin_smax || !d->lin_sref || !d->lin_dq || d->lin_nplanes < 1))
+        return rip_fail(ctx, RIP_EINVAL, "caldir upload: incomplete linearity arrays");
+    const int NPl = d->lin_coefs ? d->lin_nplanes : 0;
+    if (hipMalloc((void **)&c.slab, (size_t)(NPl + 9) * npix * 4) != hipSuccess)
+        return rip_fail(ctx, RIP_ENOMEM, "caldir upload: %zu bytes for the per-pixel planes", (size_t)(NPl + 9) * npix * 4);
+    RIP_HIP(ctx, hipMemsetAsync(c.slab, 0, (size_t)(NPl + 9) * npix * 4, ctx->stream));
+    float *pl = c.slab;
+    auto plane = [&](int k) { return pl + (size_t)(NPl + k) * npix; };
+#define UPS(dst, src, bytes)                                                                           \
+    if (src) {                                                                                         \
+        hipError_t e_ = hipMemcpyAsync((void *)(dst), (src), (bytes), hipMemcpyHostToDevice, ctx->stream); \
+        if (e_ != hipSuccess) {                                                                        \
+            free_cal(c);                                                                               \
+            return rip_fail(ctx, RIP_EHIP, "caldir upload: %s", hipGetErrorString(e_));                \
+        }                                                                                              \
+    }
     if (d->dark_data) {
         c.ngrp_dark = d->ngrp_dark;
         UP(c.dark_data, d->dark_data, npix * 4 * (size_t)d->ngrp_dark);
     }
     UP(c.dark_slope, d->dark_slope, npix * 4);
     UP(c.dark_dq, d->dark_dq, npix * 4);
-    UP(c.read_noise, d->read_noise, npix * 4);
+    c.read_noise = plane(5);
+    UPS(c.read_noise, d->read_noise, npix * 4);
     UP(c.amp33_med, d->amp33_med, (size_t)c.ny * RIP_CW * 4);
     c.has_amp33 = d->amp33_med != nullptr;
-    UP(c.gain, d->gain, npix * dsize(d->gain_dtype));
+    if (d->gain_dtype == RIP_F64) {
+        UP(c.gain, d->gain, npix * 8);
+    } else {
+        c.gain = plane(4);
+        UPS(c.gain, d->gain, npix * 4);
+    }
     if (d->lin_coefs) {
-        if (!d->lin_smin || !d->lin_smax || !d->lin_sref || !d->lin_dq || d->lin_nplanes < 1) {
-            free_cal(c);
-            return rip_fail(ctx, RIP_EINVAL, "caldir upload: incomplete linearity arrays");
-        }
         c.lin_nplanes = d->lin_nplanes;
-        UP(c.lin_coefs, d->lin_coefs, npix * 4 * (size_t)d->lin_nplanes);
-        UP(c.lin_smin, d->lin_smin, npix * 4);
-        UP(c.lin_smax, d->lin_smax, npix * 4);
-        UP(c.lin_sref, d->lin_sref, npix * 4);
-        UP(c.lin_dq, d->lin_dq, npix * 4);
+        c.lin_coefs = pl;
+        c.lin_smin = plane(0);
+        c.lin_smax = plane(1);
+        c.lin_sref = plane(2);
+        c.lin_dq = (uint32_t *)plane(3);
+        UPS(c.lin_coefs, d->lin_coefs, npix * 4 * (size_t)d->lin_nplanes);
+        UPS(c.lin_smin, d->lin_smin, npix * 4);
+        UPS(c.lin_smax, d->lin_smax, npix * 4);
+        UPS(c.lin_sref, d->lin_sref, npix * 4);
+        UPS(c.lin_dq, d->lin_dq, npix * 4);
     }
     // dark dq: only kept if any bit is set (every dark file the reference writes has dq == 0)
     if (d->dark_dq) {
@@ -245,10 +298,7 @@ int rip_caldir_upload(rip_ctx *ctx, int slot, const rip_caldir_desc *d) {
     }
     // IPC-deconvolved dark rate (gen_cal_image.py:217-221)
     if (c.dark_slope) {
-        if (hipMalloc((void **)&c.dark_rate, npix * 4) != hipSuccess) {
-            free_cal(c);
-            return rip_fail(ctx, RIP_ENOMEM, "caldir upload: dark_rate allocation failed");
-        }
+        c.dark_rate = plane(6);
         if (c.has_ipc) {
             IpcArgs ia{c.dark_slope, c.dark_rate, c.ipc, c.gain, c.ipc_dtype, c.gain_dtype, c.ny, c.nx, c.nb, 1};
             if ((rc = rip_launch_ipc_cube(ctx, ia))) {
@@ -267,11 +317,8 @@ int rip_caldir_upload(rip_ctx *ctx, int slot, const rip_caldir_desc *d) {
             free_cal(c);
             return rc;
         }
-        if (hipMalloc((void **)&c.flat_dn, npix * 4) != hipSuccess ||
-            hipMalloc((void **)&c.flat_flags, npix * 4) != hipSuccess) {
-            free_cal(c);
-            return rip_fail(ctx, RIP_ENOMEM, "caldir upload: flat allocation failed");
-        }
+        c.flat_dn = plane(7);
+        c.flat_flags = (uint32_t *)plane(8);
         rc = rip_launch_flat_prepare(ctx, raw.as<float>(), c.gain, c.gain_dtype, c.ny, c.nx, c.nb, padded.as<float>(),
                                      gclip.p, c.flat_flags, c.has_ipc ? 1 : 0);
         if (!rc) {
@@ -292,6 +339,7 @@ int rip_caldir_upload(rip_ctx *ctx, int slot, const rip_caldir_desc *d) {
         c.has_flat = true;
     }
 #undef UP
+#undef UPS
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         free_cal(c);
@@ -356,18 +404,25 @@ int rip_plan_create(rip_ctx *ctx, const rip_plan_desc *d, int *plan_id) {
                 df.dt = d->tbar[i + di] - d->tbar[i];
                 const float inv = 1.0f / df.dt;
                 // fast-path variance coefficients: var = A*read^2 + B*dvardt, sums in f64
-                double A = 0.0, B = 0.0;
+                double A = 0.0, B = 0.0, Babs = 0.0;
                 for (int a = 0; a < g; ++a) {
                     const double wa = ((a == df.j) ? (double)inv : (a == df.i) ? (double)(-inv) : 0.0) - (double)K[a];
                     A += wa * wa / (double)d->nreads[a];
                     B += wa * wa * (double)d->tau[a];
+                    Babs += wa * wa * (double)d->tau[a];
                     for (int b = 0; b < a; ++b) {
                         const double wb = ((b == df.j) ? (double)inv : (b == df.i) ? (double)(-inv) : 0.0) - (double)K[b];
                         B += 2.0 * wa * wb * (double)d->tbar[b];
+                        Babs += std::fabs(2.0 * wa * wb) * (double)d->tbar[b];
                     }
                 }
+                // the reference rounds each term of the variance in f32/f64 as it goes; with cancellation between
+                // the terms of B the relative error of any evaluation order is amplified by Babs/B
+                const double amp = (B > 0.0) ? Babs / B : 1.0;
+                df.relerr = (float)(2.5e-7 * (1.0 + amp) + 5e-7);
                 df.A = (float)A;
                 df.B = (float)B;
+                df.inv_dt = inv;
                 p->diffs.push_back(df);
                 rv.ndiff++;
             }
@@ -507,6 +562,14 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     }
 
     int rc;
+    auto mark = [&]() {
+        if (!ctx->prof) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, ctx->stream);
+        ctx->prof_events.push_back(e);
+    };
+    mark();
     // ---- reference-pixel tables
     double *rowcorr = nullptr, *lines = nullptr;
     if (do_ref) {
@@ -520,9 +583,67 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         if (c.has_amp33 && !d_a33) return rip_fail(ctx, RIP_EINVAL, "calibrate: the read file has amp33 but the ramp has none");
         if ((rc = rip_launch_refpix_prepass(ctx, ra))) return rc;
     }
-    // ---- cube stage: refpix apply + bias + linearity (or a plain conversion to f32)
+    mark();
+    // flat plane the slope is divided by: f32(flat_dn / AreaFactor)  (gen_cal_image.py:622)
+    const float *flat_plane = nullptr;
+    if (do_fit && (stages & RIP_STAGE_FLAT) && c.has_flat) {
+        flat_plane = c.flat_dn;
+        if (d_area) {
+            float *fl = (float *)rip_ws(ctx, 3, (size_t)G * ny * 8 + (size_t)G * nch * 16 + npix * 4 + 512);
+            if (!fl) return RIP_ENOMEM;
+            fl = (float *)((char *)fl + ((size_t)G * ny * 8 + (size_t)G * nch * 16 + 255) / 256 * 256);
+            if ((rc = rip_launch_flat_area(ctx, c.flat_dn, d_area, fl, npix))) return rc;
+            flat_plane = fl;
+        }
+    }
     const float *cur = nullptr;
     const uint32_t *pdq_mid = d_pdq;
+    // the fused kernel covers the complete chain on a Level-1 (u16) cube; sub-chains and f32 cubes take the
+    // stage-by-stage kernels
+    const bool fused = ctx->use_fused && do_ref && do_bias && do_lin && do_ipc && do_fit && in->data_dtype == RIP_U16 &&
+                       rip_chain_supported(c.lin_nplanes, G, c.ipc_dtype, c.gain_dtype);
+    if (fused) {
+        // ---- one kernel: refpix apply + bias + linearity + IPC + ramp fit + finish (chain.hip)
+        ChainArgs ca;
+        memset(&ca, 0, sizeof ca);
+        ca.data = d_data;
+        ca.data_u16 = in->data_dtype == RIP_U16;
+        ca.gdq = d_gdq;
+        ca.pdq = d_pdq;
+        ca.dark_data = c.dark_data;
+        ca.rowcorr = rowcorr;
+        ca.lines = lines;
+        ca.bias = c.bias + (size_t)(c.ngrp_bias - G) * npix;
+        ca.planes = c.slab;
+        ca.do_not_flag_first = plan->h.do_not_flag_first;
+        ca.kern = c.ipc;
+        ca.finish = (stages & (RIP_STAGE_DARK | RIP_STAGE_FLAT)) ? 1 : 0;
+        if (stages & RIP_STAGE_DARK) {
+            ca.dark_rate = 1;
+            ca.dark_dq = c.has_dark_dq ? c.dark_dq : nullptr;
+        }
+        ca.flat = flat_plane;
+        ca.slope = o_slope;
+        ca.err_read = o_er;
+        ca.err_poisson = o_ep;
+        ca.pdq_out = o_pdq;
+        ca.gdq_out = o_gdq;
+        if (out->cube) {
+            float *cb = host ? (float *)rip_ws(ctx, 1, (size_t)G * npix * 4) : out->cube;
+            if (!cb) return RIP_ENOMEM;
+            ca.cube_out = cb;
+            cur = cb;
+        }
+        ca.ny = ny;
+        ca.nx = nx;
+        ca.nb = c.nb;
+        ca.ngrp = G;
+        if ((rc = rip_launch_chain(ctx, plan, ca, c.lin_nplanes, c.ipc_dtype))) return rc;
+        mark();
+        mark();
+        mark();
+    } else {
+    // ---- cube stage: refpix apply + bias + linearity (or a plain conversion to f32)
     const bool need_cube_stage = do_ref || do_bias || do_lin || in->data_dtype != RIP_F32;
     if (need_cube_stage) {
         float *cubeA = (float *)rip_ws(ctx, 0, (size_t)G * npix * 4 + npix * 4);
@@ -562,6 +683,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     } else {
         cur = (const float *)d_data;
     }
+    mark();
     // ---- IPC
     if (do_ipc) {
         float *cubeB = (float *)rip_ws(ctx, 1, (size_t)G * npix * 4);
@@ -570,6 +692,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         if ((rc = rip_launch_ipc_cube(ctx, ia))) return rc;
         cur = cubeB;
     }
+    mark();
     // ---- ramp fit + finish
     if (do_fit) {
         RampFitArgs fa;
@@ -589,23 +712,16 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
             fa.dark_rate = c.dark_rate;
             fa.dark_dq = c.has_dark_dq ? c.dark_dq : nullptr;
         }
-        if ((stages & RIP_STAGE_FLAT) && c.has_flat) {
-            fa.flat = c.flat_dn;
-            fa.flat_flags = c.flat_flags;
-            if (d_area) {
-                float *fl = (float *)rip_ws(ctx, 3, (size_t)G * ny * 8 + (size_t)G * nch * 16 + npix * 4 + 512);
-                if (!fl) return RIP_ENOMEM;
-                fl = (float *)((char *)fl + ((size_t)G * ny * 8 + (size_t)G * nch * 16 + 255) / 256 * 256);
-                if ((rc = rip_launch_flat_area(ctx, c.flat_dn, d_area, fl, npix))) return rc;
-                fa.flat = fl;
-            }
-        }
+        fa.flat = flat_plane;
+        fa.flat_flags = flat_plane ? c.flat_flags : nullptr;
         fa.ny = ny;
         fa.nx = nx;
         fa.nb = c.nb;
         fa.ngrp = G;
         if ((rc = rip_launch_rampfit(ctx, plan, fa, c.gain_dtype))) return rc;
     }
+    mark();
+    }  // unfused
     // ---- results back
     if (host) {
         if (do_fit) {

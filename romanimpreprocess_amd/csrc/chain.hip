@@ -1,0 +1,26 @@
+// Dispatch of the fused chain kernel (chain_kernel.h; instantiated per Legendre order in chain_np*.hip).
+#include "rip_common.h"
+
+int rip_launch_chain_np4(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int k_dtype);
+int rip_launch_chain_np9(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int k_dtype);
+int rip_launch_chain_np11(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int k_dtype);
+
+// f32 gain; 4 / 9 / 11 Legendre planes (P_ORDER 3 / 8 / 10); 6, 8 or 16 groups; LDS budget (see chain_kernel.h)
+bool rip_chain_supported(int nplanes, int G, int k_dtype, int gain_dtype) {
+    if (gain_dtype != RIP_F32) return false;
+    if (nplanes != 4 && nplanes != 9 && nplanes != 11) return false;
+    if (G != 6 && G != 8 && !(G == 16 && k_dtype == RIP_F32)) return false;
+    return true;
+}
+
+int rip_launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int nplanes, int k_dtype) {
+    switch (nplanes) {
+        case 4:
+            return rip_launch_chain_np4(ctx, plan, a, k_dtype);
+        case 9:
+            return rip_launch_chain_np9(ctx, plan, a, k_dtype);
+        case 11:
+            return rip_launch_chain_np11(ctx, plan, a, k_dtype);
+    }
+    return rip_fail(ctx, RIP_EINVAL, "fused chain: %d Legendre planes not instantiated", nplanes);
+}

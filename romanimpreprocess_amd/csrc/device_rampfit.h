@@ -1,0 +1,268 @@
+// Device functions of the ramp fit (shared by rampfit.hip and chain.hip).
+//   utils/fitting.py:89-255   jump_detect -> fit_variant()      (one pass over groups [0,g))
+//   utils/fitting.py:233-241  var_delta_slope in the reference's exact order -> exact_variance()
+// Arithmetic recipe: oracle/rampfit.py.
+#pragma once
+#include "rip_common.h"
+
+__device__ __forceinline__ float log_f32(float x) {
+    // np.log on an f32 array.  Evaluated in f64 and rounded: correctly rounded f32 logarithm.
+    // (numpy's AVX512F/AVX2 f32 log differs from the correctly rounded value by <= 2 ulp on ~4% of
+    // inputs; the result only feeds the jump threshold -- see DESIGN.md "log of the threshold".)
+    return (float)log((double)x);
+}
+
+__device__ __forceinline__ float hypot_f32(float a, float b) {
+    // np.hypot on f32 = libm hypotf = (float)sqrt((double)a*a + (double)b*b)  (glibc flt-32/e_hypotf.c)
+    if (isinf(a) || isinf(b)) return INFINITY;
+    double da = (double)a, db = (double)b;
+    return (float)sqrt(da * da + db * db);
+}
+
+template <typename T>
+__device__ __forceinline__ T clip_lo(T x, T lo) {  // np.clip(x, lo, None): NaN stays NaN
+    return x < lo ? lo : x;
+}
+template <typename T>
+__device__ __forceinline__ T clip2(T x, T lo, T hi) {  // np.clip(x, lo, hi)
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+
+template <typename GT>
+struct GainConst;
+template <>
+struct GainConst<float> {
+    static __device__ __forceinline__ float lo() { return 1e-4f; }
+    static __device__ __forceinline__ float hi() { return 1e4f; }
+};
+template <>
+struct GainConst<double> {
+    static __device__ __forceinline__ double lo() { return 1e-4; }
+    static __device__ __forceinline__ double hi() { return 1e4; }
+};
+
+// var_delta_slope exactly as fitting.py:233-241 (order of accumulation and dtype of every term)
+template <typename GT>
+__device__ __noinline__ double exact_variance(const RipPlanHeader *__restrict__ h, const float *__restrict__ kv, int g,
+                                              int di, int dj, float dt, GT dv, float s2) {
+    const float inv = 1.0f / dt;
+    double var = 0.0;
+    for (int a = 0; a < g; ++a) {
+        double wa = ((a == dj) ? (double)inv : (a == di) ? (double)(-inv) : 0.0) - (double)kv[a];
+        double inner;
+        if constexpr (sizeof(GT) == 4) {
+            float t1 = dv * h->tau[a];
+            float t2 = s2 / h->nreads[a];
+            inner = (double)(t1 + t2);
+        } else {
+            inner = dv * (double)h->tau[a] + (double)(s2 / h->nreads[a]);
+        }
+        var += (wa * wa) * inner;
+        double twa = 2.0 * wa;
+        for (int b = 0; b < a; ++b) {
+            double wb = ((b == dj) ? (double)inv : (b == di) ? (double)(-inv) : 0.0) - (double)kv[b];
+            var += ((twa * wb) * (double)dv) * (double)h->tbar[b];
+        }
+    }
+    return var;
+}
+
+// one jump_detect pass on the ramp D[t*STRIDE] (LDS column of this thread); ORs JUMP_DET into J[i*STRIDE] when `flag`
+template <typename GT, int STRIDE>
+__device__ __forceinline__ void fit_variant(const float *D, uint8_t *J, const RipPlanHeader *__restrict__ h,
+                                            const RipVariant v, const float *__restrict__ kv,
+                                            const RipDiff *__restrict__ df, GT gain, float rn, bool flag,
+                                            double guard, float &s_out, float &er_out, float &ep_out) {
+    const int g = v.g;
+    const float d1 = D[STRIDE];
+    float s = 0.0f;
+    for (int t = 0; t < g; ++t) {
+        float diff = D[t * STRIDE] - d1;
+        float prod = kv[t] * diff;
+        s = s + prod;
+    }
+    GT gc = clip2<GT>(gain, GainConst<GT>::lo(), GainConst<GT>::hi());
+    GT dv = clip_lo<GT>((GT)s / gc, (GT)0);
+    GT pv = clip_lo<GT>((GT)v.coef * dv, (GT)0);
+    float ep;
+    if constexpr (sizeof(GT) == 4)
+        ep = sqrtf(pv);
+    else
+        ep = (float)sqrt(pv);
+    s_out = s;
+    er_out = rn * v.rfac;
+    ep_out = ep;
+    if (!flag) return;
+
+    float xc = clip2<float>(s, h->ia, h->ib);
+    float lx = log_f32(xc / h->ia);
+    double sth = h->sa + h->dsb * ((double)lx / h->loglen);
+    float sth32 = (float)sth;
+    float band = (float)(guard * fabs(sth)) + 0.0f;
+    const float s2 = rn * rn;
+    const float dv32 = (float)dv;
+    for (int k = 0; k < v.ndiff; ++k) {
+        const RipDiff r = df[k];
+        float num = D[r.j * STRIDE] - D[r.i * STRIDE];
+        float delta = num / r.dt - s;
+        float var32 = r.A * s2 + r.B * dv32;
+        float sm = delta / sqrtf(var32);
+        bool hit;
+        if (fabsf(sm - sth32) > band) {
+            hit = sm > sth32;
+        } else {  // within the guard band of the threshold (or NaN): redo in the reference's exact order
+            double var = exact_variance<GT>(h, kv, g, r.i, r.j, r.dt, dv, s2);
+            float sme = delta / (float)sqrt(var);
+            hit = (double)sme > sth;
+        }
+        if (hit) J[r.i * STRIDE] |= (uint8_t)DQ_JUMP_DET;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// fitting.py:258-355 (ramp_fit) for one pixel whose ramp D[g*STRIDE], input group flags Q[g*STRIDE] and
+// (zeroed) new-flag accumulators J[g*STRIDE] sit in LDS.  Returns slope / errors of the selected fit
+// variant and the pixel DQ after flag propagation; writes the updated group flags to gdq_out (global,
+// element stride gstride) when it is not null.
+template <typename GT, int STRIDE>
+__device__ __forceinline__ void rampfit_pixel(const float *D, const uint8_t *Q, uint8_t *J, int G,
+                                              const RipPlanHeader *__restrict__ h, const RipVariant *__restrict__ vars,
+                                              const float *__restrict__ kvals, const RipDiff *__restrict__ diffs,
+                                              GT gain, float rn, bool active, double guard, uint32_t pdq_in,
+                                              uint8_t *gdq_out, size_t gstride, float &s, float &er, float &ep,
+                                              uint32_t &pdq_out) {
+    const int start = h->start;
+    // full ramp (fitting.py:313-320): jump flags kept only where the last group is not saturated
+    const bool unsat = (Q[(G - 1) * STRIDE] & DQ_SATURATED) == 0;
+    fit_variant<GT, STRIDE>(D, J, h, vars[0], kvals + vars[0].k_ofs, diffs + vars[0].diff_ofs, gain, rn,
+                            unsat && active, guard, s, er, ep);
+    // ramps truncated at the group where the pixel first saturates (fitting.py:326-337)
+    for (int vi = 1; vi < h->nvariants; ++vi) {
+        const RipVariant v = vars[vi];
+        const int iend = v.g;
+        const bool layer = ((Q[iend * STRIDE] & ~Q[(iend - 1) * STRIDE]) & DQ_SATURATED) != 0;
+        if (layer)
+            fit_variant<GT, STRIDE>(D, J, h, v, kvals + v.k_ofs, diffs + v.diff_ofs, gain, rn, active, guard, s, er, ep);
+    }
+    // flag propagation (fitting.py:339-353)
+    uint32_t or_unsat = 0, any_sat = 0;
+    bool all_dnu = true;
+    for (int g = 0; g < G; ++g) {
+        const uint32_t r = (uint32_t)Q[g * STRIDE] | (uint32_t)J[g * STRIDE];
+        if (gdq_out) gdq_out[(size_t)g * gstride] = (uint8_t)r;
+        if ((r & DQ_SATURATED) == 0) or_unsat |= r;
+        any_sat |= r & DQ_SATURATED;
+        all_dnu = all_dnu && ((r & DQ_DO_NOT_USE) != 0);
+    }
+    uint32_t pdq2 = or_unsat & ~DQ_DO_NOT_USE;
+    if (all_dnu) pdq2 |= DQ_DO_NOT_USE;
+    if (Q[(1 + start) * STRIDE] & DQ_SATURATED) pdq2 |= DQ_DO_NOT_USE;
+    pdq2 |= any_sat;
+    pdq_out = (pdq_in & DQ_REFERENCE_PIXEL) ? pdq_in : (pdq_in | pdq2);
+}
+
+// gen_cal_image.py:458-475 (err = hypot, var_poisson, trim + zero border), :213-229 (dark rate on the active
+// region), :607-613 (error split), :616-629 (flat flags + division).  Pointers may be null (step skipped).
+__device__ __forceinline__ void finish_pixel(bool active, size_t p, const float *__restrict__ dark_rate,
+                                             const uint32_t *__restrict__ dark_dq, const float *__restrict__ flat,
+                                             const uint32_t *__restrict__ flat_flags, float &s, float &er, float &ep,
+                                             uint32_t &pdq) {
+    float err = hypot_f32(er, ep);
+    float vp = ep * ep;
+    if (!active) {
+        s = 0.0f;
+        err = 0.0f;
+        vp = 0.0f;
+    }
+    if (active && dark_rate) s = s - dark_rate[p];
+    if (active && dark_dq) pdq |= dark_dq[p];
+    float ep2 = sqrtf(vp);
+    float e2 = err * err;
+    float p2 = ep2 * ep2;
+    float er2 = sqrtf(clip_lo<float>(e2 - p2, 0.0f));
+    if (flat) {
+        if (flat_flags) pdq |= flat_flags[p];
+        const float f = flat[p];
+        s = s / f;
+        er2 = er2 / f;
+        ep2 = ep2 / f;
+    }
+    er = er2;
+    ep = ep2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Register-resident fast path of the FULL-ramp fit (variant 0) for a compile-time group count.
+// Same results as fit_variant(): slope / errors are computed with the reference's exact operations;
+// each jump significance is first evaluated approximately (reciprocal multiply, rsq) and compared
+// with the threshold through a rigorous error band; only inside the band (or for NaN) is it
+// re-evaluated in the reference's exact operation order, so the flags are identical.
+//   d[G]    the pixel's ramp
+//   jmask   bit i set <=> JUMP_DET on group i (OR-ed in)
+template <int G>
+__device__ __forceinline__ void fit_full_regs(const float (&d)[G], const RipPlanHeader *__restrict__ h,
+                                              const RipVariant v, const float *__restrict__ kv,
+                                              const RipDiff *__restrict__ df, float gain, float rn, bool flag,
+                                              double guard, float &s_out, float &er_out, float &ep_out,
+                                              uint32_t &jmask) {
+    const float d1 = d[1];
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        const float diff = d[t] - d1;
+        const float prod = kv[t] * diff;
+        s = s + prod;
+    }
+    const float gc = clip2<float>(gain, 1e-4f, 1e4f);
+    const float dv = clip_lo<float>(s / gc, 0.0f);
+    const float pv = clip_lo<float>(v.coef * dv, 0.0f);
+    s_out = s;
+    er_out = rn * v.rfac;
+    ep_out = sqrtf(pv);
+    if (!__any(flag)) return;
+
+    const float xc = clip2<float>(s, h->ia, h->ib);
+    const bool need_log = xc != h->ia;  // log(1) = 0 exactly otherwise
+    float lx = 0.0f;
+    if (__any(need_log)) lx = need_log ? __logf(xc / h->ia) : 0.0f;
+    const float slope_th = (float)(h->dsb / h->loglen);
+    const float sth32 = (float)h->sa + slope_th * lx;
+    // error band of the approximate comparison (see DESIGN.md "jump significance fast path")
+    const float band0 = 2e-6f * fabsf(sth32) + 4e-6f * fabsf(slope_th) + 1e-30f;
+    const float s2 = rn * rn;
+    const bool force_exact = !(guard < 1e300);
+    const int start = h->start;
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < G - 1; ++i) {
+        if (i < start) continue;
+#pragma unroll
+        for (int di = 1; di <= 2; ++di) {
+            const int j = i + di;
+            if (j > G - 1) continue;
+            if (di == 2 && (i == G - 2 || G - 1 - start == 2)) continue;
+            const RipDiff r = df[k++];
+            const float num = d[j] - d[i];
+            const float q = num * r.inv_dt;
+            const float delta = q - s;
+            const float var32 = fmaf(r.B, dv, r.A * s2);
+            const float rs = __frsqrt_rn(var32);
+            const float sm = delta * rs;
+            const float band = band0 + r.relerr * fabsf(sm) + 4e-7f * (fabsf(q) + fabsf(s)) * rs;
+            bool hit = sm > sth32;
+            const bool unsure = force_exact || !(fabsf(sm - sth32) > band);
+            if (__any(unsure && flag)) {
+                if (unsure) {
+                    const float lxe = log_f32(xc / h->ia);
+                    const double sth = h->sa + h->dsb * ((double)lxe / h->loglen);
+                    const float de = num / r.dt - s;
+                    const double var = exact_variance<float>(h, kv, G, r.i, r.j, r.dt, dv, s2);
+                    const float sme = de / (float)sqrt(var);
+                    hit = (double)sme > sth;
+                }
+            }
+            if (hit && flag) jmask |= 1u << i;
+        }
+    }
+}

@@ -50,23 +50,64 @@ __device__ float block_median(const float *vals, int n, float *slot) {
     return m;
 }
 
-// ---- 1. per (group,row): rank-63 / rank-64 elements of v = f32(amp33) - med -----------------------
-__global__ __launch_bounds__(RIP_CW) void amp33_rows_kernel(const uint16_t *__restrict__ amp33,
-                                                            const float *__restrict__ med, float *__restrict__ lohi,
-                                                            int ny) {
-    __shared__ float v[RIP_CW];
-    const int r = blockIdx.x, g = blockIdx.y, c = threadIdx.x;
-    const float mine = (float)amp33[((size_t)g * ny + r) * RIP_CW + c] - med[(size_t)r * RIP_CW + c];
-    v[c] = mine;
+// np.median of vals[0..n) in LDS by an in-place bitonic sort; the buffer must hold npow2 >= n floats
+// (entries n.. are overwritten with +inf).  All threads of the block must call it.
+__device__ float block_median_sorted(float *vals, int n, int npow2) {
+    for (int i = n + threadIdx.x; i < npow2; i += blockDim.x) vals[i] = INFINITY;
     __syncthreads();
-    int rank = 0;
-    for (int j = 0; j < RIP_CW; ++j) {
-        const float w = v[j];
-        rank += (w < mine || (w == mine && j < c)) ? 1 : 0;
+    for (int k = 2; k <= npow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const float x = vals[i], y = vals[p];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) {
+                        vals[i] = y;
+                        vals[p] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    const int k_hi = n / 2, k_lo = (n & 1) ? n / 2 : n / 2 - 1;
+    return (vals[k_lo] + vals[k_hi]) * 0.5f;
+}
+
+// ---- 1. per (group,row): rank-63 / rank-64 elements of v = f32(amp33) - med -----------------------
+// one wave per row: the 128 values live two per lane (elements lane and lane+64) and are sorted by a
+// bitonic network of cross-lane exchanges; rank 63 ends in (lane 63, slot 0), rank 64 in (lane 0, slot 1)
+__global__ __launch_bounds__(256) void amp33_rows_kernel(const uint16_t *__restrict__ amp33,
+                                                         const float *__restrict__ med, float *__restrict__ lohi,
+                                                         int ny, int nrows_total) {
+    const int lane = threadIdx.x & 63;
+    const int row_id = blockIdx.x * 4 + (threadIdx.x >> 6);  // flattened (g, r)
+    if (row_id >= nrows_total) return;
+    const int r = row_id % ny;
+    const uint16_t *a = amp33 + (size_t)row_id * RIP_CW;
+    const float *m = med + (size_t)r * RIP_CW;
+    float v0 = (float)a[lane] - m[lane];
+    float v1 = (float)a[lane + 64] - m[lane + 64];
+#pragma unroll
+    for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == 64) {  // partner = the other slot of this lane; k = 128: ascending everywhere
+                const float lo = fminf(v0, v1), hi = fmaxf(v0, v1);
+                v0 = lo;
+                v1 = hi;
+            } else {
+                const float p0 = __shfl_xor(v0, j, 64), p1 = __shfl_xor(v1, j, 64);
+                const bool lower = (lane & j) == 0;
+                const bool up0 = (lane & k) == 0, up1 = ((lane + 64) & k) == 0;
+                v0 = (lower == up0) ? fminf(v0, p0) : fmaxf(v0, p0);
+                v1 = (lower == up1) ? fminf(v1, p1) : fmaxf(v1, p1);
+            }
+        }
     }
-    float *o = lohi + ((size_t)g * ny + r) * 2;
-    if (rank == RIP_CW / 2 - 1) o[0] = mine;
-    if (rank == RIP_CW / 2) o[1] = mine;
+    float *o = lohi + (size_t)row_id * 2;
+    if (lane == 63) o[0] = v0;
+    if (lane == 0) o[1] = v1;
 }
 
 // ---- 2. exact selection of two ranks among the ny*128 values of each group (3-level radix) -------
@@ -150,22 +191,21 @@ __global__ void sel_init_kernel(SelState *st, uint32_t *ghist, int ngrp, uint32_
 __global__ __launch_bounds__(1024) void rowcorr_kernel(const SelState *__restrict__ st, const float *__restrict__ lohi,
                                                        double slope, double *__restrict__ rowcorr,
                                                        float *__restrict__ dbg_refmed, float *__restrict__ dbg_scal,
-                                                       int ny) {
-    extern __shared__ float rm[];  // [ny] + 2
-    float *slot = rm + ny;
+                                                       int ny, int npow2) {
+    extern __shared__ float rm[];  // [npow2] sort buffer
     const int g = blockIdx.x;
     const float M = (key2f(st[g].prefix[0]) + key2f(st[g].prefix[1])) * 0.5f;  // np.median of the block
-    for (int r = threadIdx.x; r < ny; r += blockDim.x) {
+    auto refmed = [&](int r) {
         const float a = lohi[((size_t)g * ny + r) * 2] - M;
         const float b = lohi[((size_t)g * ny + r) * 2 + 1] - M;
-        rm[r] = (a + b) * 0.5f;
-    }
-    __syncthreads();
-    const float ctr = block_median(rm, ny, slot);
+        return (a + b) * 0.5f;
+    };
+    for (int r = threadIdx.x; r < ny; r += blockDim.x) rm[r] = refmed(r);
+    const float ctr = block_median_sorted(rm, ny, npow2);
     for (int r = threadIdx.x; r < ny; r += blockDim.x) {
-        const float d = rm[r] - ctr;
-        rowcorr[(size_t)g * ny + r] = slope * (double)d;
-        if (dbg_refmed) dbg_refmed[(size_t)g * ny + r] = rm[r];
+        const float v = refmed(r);
+        rowcorr[(size_t)g * ny + r] = slope * (double)(v - ctr);
+        if (dbg_refmed) dbg_refmed[(size_t)g * ny + r] = v;
     }
     if (dbg_scal && threadIdx.x == 0) {
         dbg_scal[g * 2] = M;
@@ -181,8 +221,6 @@ __global__ __launch_bounds__(1024) void chan_kernel(const DT *__restrict__ data,
                                                     double *__restrict__ lines, float *__restrict__ dbg_bt, int ny,
                                                     int nx) {
     __shared__ float v[1024];
-    __shared__ float slot[2];
-    __shared__ float bt[2];
     const int ch = blockIdx.x, g = blockIdx.y, nch = gridDim.x;
     const int e = threadIdx.x & 511, half = threadIdx.x >> 9;
     const int row = (half ? ny - 4 : 0) + e / RIP_CW;
@@ -220,8 +258,6 @@ __global__ __launch_bounds__(1024) void chan_kernel(const DT *__restrict__ data,
             dbg_bt[((size_t)g * nch + ch) * 2 + 1] = t;
         }
     }
-    (void)slot;
-    (void)bt;
 }
 
 int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a) {
@@ -239,7 +275,8 @@ int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a) {
         SelState *st = (SelState *)(ws + lohi_b);
         uint32_t *ghist = (uint32_t *)(ws + lohi_b + st_b);
         const uint32_t n = (uint32_t)ny * RIP_CW;
-        hipLaunchKernelGGL(amp33_rows_kernel, dim3(ny, G), dim3(RIP_CW), 0, ctx->stream, a.amp33, a.amp33_med, lohi, ny);
+        hipLaunchKernelGGL(amp33_rows_kernel, dim3((unsigned)((G * ny + 3) / 4)), dim3(256), 0, ctx->stream, a.amp33,
+                           a.amp33_med, lohi, ny, G * ny);
         const size_t ninit = (size_t)G * 2 * SEL_BINS;
         hipLaunchKernelGGL(sel_init_kernel, dim3((unsigned)((ninit + 255) / 256)), dim3(256), 0, ctx->stream, st, ghist,
                            G, n);
@@ -250,12 +287,14 @@ int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a) {
                                ghist, ny, level, chunk);
             hipLaunchKernelGGL(sel_scan_kernel, dim3(G, 2), dim3(256), 0, ctx->stream, st, ghist, level);
         }
-        const size_t lds = ((size_t)ny + 2) * sizeof(float);
+        int npow2 = 1;
+        while (npow2 < ny) npow2 <<= 1;
+        const size_t lds = (size_t)npow2 * sizeof(float);
         if (lds > 48 * 1024)
             RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rowcorr_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(rowcorr_kernel, dim3(G), dim3(1024), lds, ctx->stream, st, lohi, a.slope, a.rowcorr,
-                           (float *)nullptr, (float *)nullptr, ny);
+                           (float *)nullptr, (float *)nullptr, ny, npow2);
     } else {
         // no reference output in the read file: the row step is the identity
         RIP_HIP(ctx, hipMemsetAsync(a.rowcorr, 0, (size_t)G * ny * sizeof(double), ctx->stream));
@@ -286,13 +325,12 @@ __global__ __launch_bounds__(RIP_CW) void img_rowmed_kernel(const float *__restr
 }
 
 __global__ __launch_bounds__(1024) void img_ctr_kernel(const float *__restrict__ ref_med, double slope,
-                                                       double *__restrict__ rowcorr, float *__restrict__ ctr_out, int ny) {
+                                                       double *__restrict__ rowcorr, float *__restrict__ ctr_out, int ny,
+                                                       int npow2) {
     extern __shared__ float rm[];
-    float *slot = rm + ny;
     for (int r = threadIdx.x; r < ny; r += blockDim.x) rm[r] = ref_med[r];
-    __syncthreads();
-    const float ctr = block_median(rm, ny, slot);
-    for (int r = threadIdx.x; r < ny; r += blockDim.x) rowcorr[r] = slope * (double)(rm[r] - ctr);
+    const float ctr = block_median_sorted(rm, ny, npow2);
+    for (int r = threadIdx.x; r < ny; r += blockDim.x) rowcorr[r] = slope * (double)(ref_med[r] - ctr);
     if (threadIdx.x == 0 && ctr_out) *ctr_out = ctr;
 }
 
@@ -364,11 +402,14 @@ int rip_refpix_image(rip_ctx *ctx, float *d_image, int ny, int nx, double slope,
     float *refmed = (float *)(lines + nch * 2);
     if (do_row) {
         hipLaunchKernelGGL(img_rowmed_kernel, dim3(ny), dim3(RIP_CW), 0, ctx->stream, d_image, refmed, nx);
-        const size_t lds = ((size_t)ny + 2) * sizeof(float);
+        int npow2 = 1;
+        while (npow2 < ny) npow2 <<= 1;
+        const size_t lds = (size_t)npow2 * sizeof(float);
         if (lds > 48 * 1024)
             RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(img_ctr_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(img_ctr_kernel, dim3(1), dim3(1024), lds, ctx->stream, refmed, slope, rowcorr, d_ctr, ny);
+        hipLaunchKernelGGL(img_ctr_kernel, dim3(1), dim3(1024), lds, ctx->stream, refmed, slope, rowcorr, d_ctr, ny,
+                           npow2);
         hipLaunchKernelGGL(img_rowapply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_image,
                            rowcorr, ny, w);
         if (d_ref_med)

@@ -30,6 +30,9 @@ struct RipDiff {
     int32_t i, j;   // difference d[j]-d[i], flag lands on group i (fitting.py:230,249)
     float dt;       // tbar[j]-tbar[i], f32
     float A, B;     // fast-path variance: var ~= A*read^2 + B*dvardt (host f64 sums rounded to f32)
+    float inv_dt;   // f32(1/dt), approximate path only
+    float relerr;   // bound on the relative error of the approximate significance coming from the variance
+    float pad_[1];
 };
 
 struct RipVariant {
@@ -81,6 +84,11 @@ struct RipCal {
     float *flat_dn = nullptr;     // output of get_flat (ny,nx); border = 1
     uint32_t *flat_flags = nullptr;  // NO_FLAT_FIELD / NO_GAIN_VALUE bits get_flat would OR into pdq
     float *bias = nullptr;        // (ngrp_bias, ny, nx) embedded in the full frame, border = 0
+    // one allocation holding the per-pixel planes the fused kernel walks together, in this order:
+    //   [0,NP) Legendre planes | NP Smin | NP+1 Smax | NP+2 Sref | NP+3 lin dq (u32) | NP+4 gain (f32 only)
+    //   | NP+5 read noise | NP+6 dark rate | NP+7 flat_dn | NP+8 flat flags (u32)
+    // (lin_coefs, lin_smin, ..., read_noise, dark_rate, flat_dn, flat_flags point into it)
+    float *slab = nullptr;
     size_t bytes = 0;
 };
 
@@ -91,6 +99,10 @@ struct rip_ctx {
     std::vector<RipCal> cals;
     std::vector<RipPlan *> plans;
     // workspace (grown on demand)
+    // per-stage device timing (HIP events on `stream`), see rip_profile_enable / rip_profile_read
+    bool use_fused = true;  // rip_set_option("fused", 0) forces the stage-by-stage kernels
+    bool prof = false;
+    std::vector<hipEvent_t> prof_events;  // 5 per rip_calibrate call
     void *ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t ws_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -149,6 +161,32 @@ struct LinArgs {
     int ny, nx, nb, ngrp;
 };
 int rip_launch_lin(rip_ctx *ctx, const LinArgs &a);
+
+// chain.hip (the fused kernel)
+struct ChainArgs {
+    const void *data;  // (G, ny, nx) u16 | f32
+    int data_u16;
+    const uint8_t *gdq;   // (G, ny, nx)
+    const uint32_t *pdq;  // (ny, nx)
+    // reference-pixel tables (rowcorr null -> step skipped)
+    const float *dark_data;
+    const double *rowcorr, *lines;
+    const float *bias;  // embedded planes, already offset to the first group used; null -> skipped
+    const float *planes;  // RipCal::slab
+    int do_not_flag_first;
+    const void *kern;   // (9, ny, nx) embedded ipc4d
+    int finish;
+    int dark_rate;        // 1: subtract plane NP+6 on the active region
+    const uint32_t *dark_dq;
+    const float *flat;    // plane NP+7 or the per-exposure f32(flat_dn/area) plane; null -> no flat step
+    float *slope, *err_read, *err_poisson;
+    uint32_t *pdq_out;
+    uint8_t *gdq_out;  // may be null
+    float *cube_out;   // may be null
+    int ny, nx, nb, ngrp;
+};
+bool rip_chain_supported(int nplanes, int G, int k_dtype, int gain_dtype);
+int rip_launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int nplanes, int k_dtype);
 
 // ipc.hip
 struct IpcArgs {

@@ -272,3 +272,63 @@ def make_ramp(cal, read_pattern=None, frame_time=FRAME_TIME, seed=1, cr_frac=1e-
         "data": data, "amp33": amp33, "groupdq": groupdq, "pixeldq": pixeldq,
         "read_pattern": rp, "frame_time": frame_time, "rate": rate.astype(np.float32),
     }
+
+
+# ------------------------------------------------------------------ fast full-frame inputs for benchmarks
+def _tile_rows(strip, ny, nb, axis):
+    """Full-height array from a strip: strip's first/last nb rows stay the frame border, the strip's
+    interior rows are repeated to fill the interior."""
+    s = np.moveaxis(strip, axis, 0)
+    inner = s[nb:-nb]
+    reps = -(-(ny - 2 * nb) // inner.shape[0])
+    body = np.concatenate([inner] * reps, axis=0)[: ny - 2 * nb]
+    out = np.concatenate([s[:nb], body, s[-nb:]], axis=0)
+    return np.ascontiguousarray(np.moveaxis(out, 0, axis))
+
+
+def _tile_active_rows(strip, nya, axis):
+    s = np.moveaxis(strip, axis, 0)
+    reps = -(-nya // s.shape[0])
+    out = np.concatenate([s] * reps, axis=0)[:nya]
+    return np.ascontiguousarray(np.moveaxis(out, 0, axis))
+
+
+def make_tiled_inputs(ny=pars.nside, nx=pars.nside, read_pattern=None, p_order=8, seed=1, strip_rows=256,
+                      gain_dtype=np.float32, ipc_dtype=np.float32, cr_frac=1e-3, nb=pars.nborder):
+    """(cal, ramp) at full frame size, synthesised on a (strip_rows + 2*nb)-row strip and repeated down the
+    frame (seconds instead of minutes on the host; same per-pixel statistics, same dtypes and shapes)."""
+    rp = READ_PATTERN_8 if read_pattern is None else read_pattern
+    sy = min(strip_rows + 2 * nb, ny)
+    cal_s = make_caldir(sy, nx, read_pattern=rp, p_order=p_order, seed=1000 + seed, gain_dtype=gain_dtype,
+                        ipc_dtype=ipc_dtype, nb=nb)
+    ramp_s = make_ramp(cal_s, read_pattern=rp, seed=seed, cr_frac=cr_frac, nb=nb)
+    if sy == ny:
+        return cal_s, ramp_s
+    nya = ny - 2 * nb
+
+    def T(a, axis=0):
+        return _tile_rows(a, ny, nb, axis)
+
+    cal = {
+        "dark": {"data": T(cal_s["dark"]["data"], 1), "dq": T(cal_s["dark"]["dq"]),
+                 "dark_slope": T(cal_s["dark"]["dark_slope"]), "dark_slope_err": T(cal_s["dark"]["dark_slope_err"])},
+        "gain": {"data": T(cal_s["gain"]["data"]), "dq": T(cal_s["gain"]["dq"])},
+        "ipc4d": {"data": _tile_active_rows(cal_s["ipc4d"]["data"], nya, 2), "dq": T(cal_s["ipc4d"]["dq"])},
+        "linearitylegendre": {"data": T(cal_s["linearitylegendre"]["data"], 1),
+                              **{k: T(cal_s["linearitylegendre"][k]) for k in ("dq", "Smin", "Smax", "Sref")}},
+        "mask": {"dq": T(cal_s["mask"]["dq"])},
+        "flat": {"data": T(cal_s["flat"]["data"]), "dq": T(cal_s["flat"]["dq"])},
+        "read": {"anc": dict(cal_s["read"]["anc"]), "data": T(cal_s["read"]["data"]),
+                 "resetnoise": T(cal_s["read"]["resetnoise"]),
+                 "amp33": {**cal_s["read"]["amp33"], "med": T(cal_s["read"]["amp33"]["med"]),
+                           "std": T(cal_s["read"]["amp33"]["std"])}},
+        "saturation": {"data": T(cal_s["saturation"]["data"]), "dq": T(cal_s["saturation"]["dq"])},
+    }
+    if "biascorr" in cal_s:
+        cal["biascorr"] = {"data": _tile_active_rows(cal_s["biascorr"]["data"], nya, 1), "t0": cal_s["biascorr"]["t0"]}
+    ramp = {
+        "data": T(ramp_s["data"], 1), "amp33": T(ramp_s["amp33"], 1), "groupdq": T(ramp_s["groupdq"], 1),
+        "pixeldq": T(ramp_s["pixeldq"]), "read_pattern": rp, "frame_time": ramp_s["frame_time"],
+        "rate": T(ramp_s["rate"]),
+    }
+    return cal, ramp

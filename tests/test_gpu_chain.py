@@ -25,9 +25,12 @@ def _oracle_lines(out, G, nch):
     return lines
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("name,shape,rp,p,gdt,kdt", CASES)
-def test_chain_vs_oracle(name, shape, rp, p, gdt, kdt):
+def test_chain_vs_oracle(name, shape, rp, p, gdt, kdt, fused):
+    """fused = 1: the single fused kernel (chain.hip) where the configuration allows it; 0: stage kernels."""
     ny, nx = shape
+    gpu_context().set_option("fused", fused)
     cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=p, seed=77, gain_dtype=gdt, ipc_dtype=kdt,
                             bias_amplitude=2.0, bad_lin_frac=0.01)
     ramp = synth.make_ramp(cal, read_pattern=rp, seed=78, cr_frac=0.02)
@@ -57,6 +60,7 @@ def test_chain_vs_oracle(name, shape, rp, p, gdt, kdt):
     assert np.all(np.abs(got2["err_read"] - ref["err_read"]) <= 1e-5 * tot + 1e-12)
     assert np.all(np.abs(got2["err_poisson"] - ref["err_poisson"]) <= 1e-5 * tot + 1e-12)
     cb.ctx.drop_caldir(3)
+    gpu_context().set_option("fused", 1)
 
 
 def test_stage_subsets_and_f32_input():
