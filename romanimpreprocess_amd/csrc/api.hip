@@ -153,7 +153,29 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value) {
         ctx->use_fused = value != 0;
         return RIP_OK;
     }
+    if (name && strcmp(name, "chain_dbg") == 0) {
+        ctx->chain_dbg = value;
+        return RIP_OK;
+    }
     return rip_fail(ctx, RIP_EINVAL, "unknown option %s", name ? name : "(null)");
+}
+
+// diagnostic builds (-DCH_STAMP): per-phase cycle sums of the fused kernel, summed over waves; clears the buffer
+int rip_chain_stamps(rip_ctx *ctx, double out[6]) {
+    const size_t n = 4096 * 6;
+    if (!ctx->chain_dbg_buf) {
+        RIP_HIP(ctx, hipMalloc((void **)&ctx->chain_dbg_buf, n * 8));
+        RIP_HIP(ctx, hipMemset(ctx->chain_dbg_buf, 0, n * 8));
+        for (int i = 0; i < 6; ++i) out[i] = 0;
+        return RIP_OK;
+    }
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> h(n);
+    RIP_HIP(ctx, hipMemcpy(h.data(), ctx->chain_dbg_buf, n * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 6; ++i) out[i] = 0;
+    for (size_t k = 0; k < n; ++k) out[k % 6] += (double)h[k];
+    RIP_HIP(ctx, hipMemset(ctx->chain_dbg_buf, 0, n * 8));
+    return RIP_OK;
 }
 
 int rip_profile_enable(rip_ctx *ctx, int on) {
@@ -638,6 +660,8 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         ca.nx = nx;
         ca.nb = c.nb;
         ca.ngrp = G;
+        ca.dbg = ctx->chain_dbg;
+        ca.dbg_buf = ctx->chain_dbg_buf;
         if ((rc = rip_launch_chain(ctx, plan, ca, c.lin_nplanes, c.ipc_dtype))) return rc;
         mark();
         mark();

@@ -30,6 +30,19 @@
 #include "device_rampfit.h"
 
 #define CH_BT 256
+
+// Diagnostic build (-DCH_STAMP): per-phase cycle sums of every wave go to ChainArgs::dbg_buf (6 x u64 per wave).
+#ifdef CH_STAMP
+#define CH_T(i)                                                          \
+    {                                                                    \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                              \
+        st_[i] += t_ - tl_;                                              \
+        tl_ = t_;                                                        \
+    }
+#else
+#define CH_T(i)
+#endif
 #define CH_OUTW (CH_BT - 4)
 
 template <typename A, typename B>
@@ -97,11 +110,18 @@ __device__ __forceinline__ unsigned ch_load_coeffs(const KT *__restrict__ kern, 
     return valid;
 }
 
+// load through a uniform base pointer + 32-bit per-lane BYTE offset (global_load ... v_off, s[base] form: no 64-bit
+// address arithmetic per load); every array addressed this way is smaller than 4 GiB
+template <typename T>
+__device__ __forceinline__ T ldg(const void *base, unsigned byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 // raw bits of one row position, fetched one phase ahead of their use (no arithmetic on them in P)
 template <int NP, int G>
 struct RowRegs {
-    uint16_t S[G];
-    uint8_t q[G];
+    uint32_t S[G];
+    uint32_t q[G];
     float dk[G], bs[G];
     float cf[NP], smin, smax, sref, gain;
     uint32_t dq;
@@ -119,11 +139,14 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
     float *R = X + G * 3 * CH_BT;                              // [G][CH_BT]  ramp (saturated pixels' refits only)
     uint8_t *Q = reinterpret_cast<uint8_t *>(R + G * CH_BT);   // [G][CH_BT]
     uint8_t *J = Q + G * CH_BT;                                // [G][CH_BT]
+    double *LN = reinterpret_cast<double *>(J + G * CH_BT);    // [3][G][2]   channel lines of this strip
+    double *RC = LN + 3 * G * 2;                               // [a.rc_rows][G] row corrections of this row range
 
     const int tid = threadIdx.x;
     const int ny = a.ny, nx = a.nx, nb = a.nb;
     const int ay0 = nb, ay1 = ny - nb, ax0 = nb, ax1 = nx - nb;
     const unsigned npix = (unsigned)ny * (unsigned)nx;
+    const unsigned pl4 = npix * 4u;  // bytes per f32 plane
     const KT *__restrict__ kern = reinterpret_cast<const KT *>(a.kern);
     const int nch = nx / RIP_CW;
     const uint32_t bad = DQ_NO_LIN_CORR | DQ_REFERENCE_PIXEL;
@@ -159,67 +182,97 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
         const bool col_ok = (c >= 0 && c < nx);
         const bool col_act = (c >= ax0 && c < ax1);
         const int cc = col_ok ? c : 0;  // clamped: out-of-frame lanes load valid addresses and discard
-        const int chn = cc / RIP_CW;
+        const int ch0 = max(strip * CH_OUTW - 2, 0) / RIP_CW;  // first channel this strip touches
+        const int chr = cc / RIP_CW - ch0;                     // 0..2
+        // stage the reference-pixel tables of this (strip, row range): lines[g][ch0..ch0+2], rowcorr[g][R0-2..R1+1]
+        __syncthreads();
+        for (int i = tid; i < 3 * G * 2; i += CH_BT) {
+            const int ch = i / (G * 2), g = (i / 2) % G, w = i & 1;
+            LN[i] = (ch0 + ch < nch) ? a.lines[(g * nch + ch0 + ch) * 2 + w] : 0.0;
+        }
+        for (int i = tid; i < (R1 - R0 + 4) * G; i += CH_BT) {
+            const int y = R0 - 2 + i / G, g = i % G;
+            RC[i] = (y >= 0 && y < ny) ? a.rowcorr[g * ny + y] : 0.0;
+        }
+        __syncthreads();
 
         KT kA[9], kB[9], kC[9];
         unsigned vA = 0, vB = 0, vC = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) kA[k] = kB[k] = kC[k] = (KT)0;
         uint32_t d0 = 0, d1 = 0, d2 = 0;
-        RowRegs<NP, G> rr;
 
+#ifdef CH_STAMP
+        unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long tl_ = __builtin_amdgcn_s_memtime();
+#endif
         // march: step r ingests row r+3, forms O1 of row r+1 and finishes row r.  The three steps before
         // R0-2 only ingest (rows R0-2, R0-1, R0).
         int s0 = 0;  // LDS slot of row r; rows r+1, r+2 (and r-1 for O1) follow cyclically
         for (int r = R0 - 5; r < R1; ++r) {
-            const int s1 = (s0 + 1) % 3, s2 = (s0 + 2) % 3;
+            const int s1 = (s0 == 2) ? 0 : s0 + 1, s2 = (s1 == 2) ? 0 : s1 + 1;
             const int yi = r + 3;  // row ingested in this step
             const bool do_ingest = (yi >= R0 - 2) && (yi <= R1 + 1);
             const bool row_in = do_ingest && yi >= 0 && yi < ny;
             const bool do_c = (r + 1 >= R0 - 1) && (r + 1 <= R1);
             const bool do_e = (r >= R0);
 
-            // ---- P: issue loads (row yi raw inputs; IPC coefficients of row r+2; fit inputs of row r)
-            if (row_in) {
-                const unsigned p = (unsigned)(yi * nx + cc);
+            // ---- P: issue loads (row yi raw inputs; IPC coefficients of row r+2; fit inputs of row r).
+            // Straight-line: addresses are clamped into the frame and unused results are discarded later, so
+            // that no branch separates the loads from the code that runs while they are in flight.
+            const bool emit = do_e && tid >= 2 && tid < CH_BT - 2 && col_ok;
+            const unsigned pe = (unsigned)(min(max(r, 0), ny - 1) * nx + cc);
+            uint32_t qe[G];
 #pragma unroll
-                for (int L = 0; L < NP; ++L) rr.cf[L] = planes[(unsigned)L * npix + p];
-                rr.smin = planes[(unsigned)(NP + 0) * npix + p];
-                rr.smax = planes[(unsigned)(NP + 1) * npix + p];
-                rr.sref = planes[(unsigned)(NP + 2) * npix + p];
-                rr.dq = planes_u[(unsigned)(NP + 3) * npix + p];
-                rr.gain = planes[(unsigned)(NP + 4) * npix + p];
+            for (int g = 0; g < G; ++g) qe[g] = ldg<uint8_t>(gdq, (unsigned)g * npix + pe);
+            const float e_gain = ldg<float>(planes, (unsigned)(NP + 4) * pl4 + pe * 4u);
+            const float e_read = ldg<float>(planes, (unsigned)(NP + 5) * pl4 + pe * 4u);
+            const float e_dark = ldg<float>(planes, (unsigned)(NP + 6) * pl4 + pe * 4u);
+            const uint32_t e_ff = ldg<uint32_t>(planes, (unsigned)(NP + 8) * pl4 + pe * 4u);
+            const uint32_t e_pdq = ldg<uint32_t>(a.pdq, pe * 4u);
+            const float e_flat = a.flat ? ldg<float>(a.flat, pe * 4u) : 1.0f;
+
+            {
+                // coefficients of destination (r+2, c): raw loads at clamped source positions + validity mask
+                const int y2 = r + 2;
+                const bool want = tid >= 1 && tid < CH_BT - 1 && y2 >= R0 - 1 && y2 <= R1;
+                const bool dest_ok = want && (y2 >= ay0 && y2 < ay1 && c >= ax0 && c < ax1);
+                vC = 0;
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const unsigned q = (unsigned)g * npix + p;
-                    rr.S[g] = d16[q];
-                    rr.q[g] = gdq[q];
-                    rr.dk[g] = dark[q];
-                    rr.bs[g] = bias[q];
+                for (int k = 0; k < 9; ++k) {
+                    const int dy = (k == 1 || k == 5 || k == 6) ? 1 : (k == 2 || k == 7 || k == 8) ? -1 : 0;
+                    const int dx = (k == 3 || k == 5 || k == 7) ? 1 : (k == 4 || k == 6 || k == 8) ? -1 : 0;
+                    const int sy = y2 - dy, sx = c - dx;
+                    const bool ok = dest_ok && sy >= ay0 && sy < ay1 && sx >= ax0 && sx < ax1;
+                    const int syc = min(max(sy, 0), ny - 1), sxc = min(max(sx, 0), nx - 1);
+                    kC[k] = ldg<KT>(kern, ((unsigned)(3 * (1 + dy) + (1 + dx)) * npix + (unsigned)(syc * nx + sxc)) * (unsigned)sizeof(KT));
+                    vC |= ok ? (1u << k) : 0u;
                 }
             }
-            if (tid >= 1 && tid < CH_BT - 1 && r + 2 >= R0 - 1 && r + 2 <= R1)
-                vC = ch_load_coeffs<KT>(kern, npix, nx, r + 2, c, ay0, ay1, ax0, ax1, kC);
-            else
-                vC = 0;
-            const bool emit = do_e && tid >= 2 && tid < CH_BT - 2 && col_ok;
-            const unsigned pe = emit ? (unsigned)(r * nx + c) : 0u;
-            uint8_t qe[G];
-            float e_gain = 1.0f, e_read = 0.0f, e_dark = 0.0f, e_flat = 1.0f;
-            uint32_t e_pdq = 0, e_ff = 0;
-            if (emit) {
+            RowRegs<NP, G> rr;
+            {
+                const int yl = (a.dbg & 128) ? 0 : min(max(yi, 0), ny - 1);  // dbg 128: re-read row 0 (cache hits)
+                const unsigned p = (unsigned)(yl * nx + cc);
+                const unsigned p4 = p * 4u;
 #pragma unroll
-                for (int g = 0; g < G; ++g) qe[g] = gdq[(unsigned)g * npix + pe];
-                e_gain = planes[(unsigned)(NP + 4) * npix + pe];
-                e_read = planes[(unsigned)(NP + 5) * npix + pe];
-                e_dark = planes[(unsigned)(NP + 6) * npix + pe];
-                e_ff = planes_u[(unsigned)(NP + 8) * npix + pe];
-                e_pdq = a.pdq[pe];
-                if (a.flat) e_flat = a.flat[pe];
+                for (int L = 0; L < NP; ++L) rr.cf[L] = ldg<float>(planes, (unsigned)L * pl4 + p4);
+                rr.smin = ldg<float>(planes, (unsigned)(NP + 0) * pl4 + p4);
+                rr.smax = ldg<float>(planes, (unsigned)(NP + 1) * pl4 + p4);
+                rr.sref = ldg<float>(planes, (unsigned)(NP + 2) * pl4 + p4);
+                rr.dq = ldg<uint32_t>(planes, (unsigned)(NP + 3) * pl4 + p4);
+                rr.gain = ldg<float>(planes, (unsigned)(NP + 4) * pl4 + p4);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    rr.S[g] = ldg<uint16_t>(d16, (unsigned)g * (pl4 >> 1) + (p4 >> 1));
+                    rr.q[g] = ldg<uint8_t>(gdq, (unsigned)g * npix + p);
+                    rr.dk[g] = ldg<float>(dark, (unsigned)g * pl4 + p4);
+                    rr.bs[g] = ldg<float>(bias, (unsigned)g * pl4 + p4);
+                }
             }
 
+            CH_T(0)
             // ---- C: O1 of row r+1
-            if (do_c && vB) {
+            if (do_c && vB && !(a.dbg & 1)) {
                 const bool all = __all(vB == 0x1ffu);  // wave-uniform: every active lane is an interior pixel
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -231,12 +284,14 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                     O1[(g * 3 + s1) * CH_BT + tid] = (T)(xc + xc) - f;
                 }
             }
-            __syncthreads();
+            CH_T(1)
+            if (!(a.dbg & 64)) __syncthreads();
+            CH_T(2)
 
             // ---- E: O2 of row r, ramp fit, outputs
             if (emit) {
                 const bool act = col_act && r >= ay0 && r < ay1;
-                const bool fastdiv = rcp_safe(e_gain);
+                const bool fastdiv = __all(rcp_safe(e_gain) || !act);  // wave-uniform
                 const float rgain = 1.0f / e_gain;
                 const bool all = __all(vA == 0x1ffu || !act);  // wave-uniform
                 float d[G];
@@ -245,20 +300,24 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                 for (int g = 0; g < G; ++g) {
                     const float xc = X[(g * 3 + s0) * CH_BT + tid];
                     float val = xc;
-                    if (act) {
+                    if (act && !(a.dbg & 2)) {
                         const T *ob = O1 + g * 3 * CH_BT;
                         const T *om = ob + s2 * CH_BT, *o0 = ob + s0 * CH_BT, *op = ob + s1 * CH_BT;
                         const T f = all ? fwd_rows<T, T, KT, true>(om, o0, op, tid, kA, vA)
                                         : fwd_rows<T, T, KT, false>(om, o0, op, tid, kA, vA);
                         const T o2 = (o0[tid] + (T)xc) - f;
-                        if constexpr (sizeof(T) == 4)
-                            val = fastdiv ? div_rcp(o2, e_gain, rgain) : o2 / e_gain;
-                        else
+                        if constexpr (sizeof(T) == 4) {
+                            if (fastdiv)
+                                val = div_rcp(o2, e_gain, rgain);
+                            else
+                                val = o2 / e_gain;
+                        } else
                             val = (float)(o2 / (T)e_gain);
                     }
                     d[g] = val;
                     anyq |= qe[g];
                 }
+                if (a.dbg & 8) anyq = 0;
                 if (a.cube_out) {
 #pragma unroll
                     for (int g = 0; g < G; ++g) a.cube_out[(unsigned)g * npix + pe] = d[g];
@@ -278,8 +337,13 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                                                 guard, pdq_in, a.gdq_out ? a.gdq_out + pe : nullptr, npix, s, er, ep, pdq);
                 } else {
                     uint32_t jmask = 0;
-                    fit_full_regs<G>(d, h, vars[0], kvals + vars[0].k_ofs, diffs + vars[0].diff_ofs, e_gain, e_read, act,
-                                     guard, s, er, ep, jmask);
+                    if (a.dbg & 4) {
+                        s = d[G - 1] - d[1];
+                        er = e_read;
+                        ep = e_gain;
+                    } else
+                        fit_full_regs<G>(d, h, vars[0], kvals + vars[0].k_ofs, diffs + vars[0].diff_ofs, e_gain, e_read, act,
+                                         guard, s, er, ep, jmask);
                     // flag propagation (fitting.py:339-353) without saturation
                     uint32_t orq = 0;
                     bool all_dnu = true;
@@ -318,12 +382,13 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                     er = er2;
                     ep = ep2;
                 }
-                a.slope[pe] = s;
-                a.err_read[pe] = er;
-                a.err_poisson[pe] = ep;
-                a.pdq_out[pe] = pdq;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(a.slope) + pe * 4u) = s;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(a.err_read) + pe * 4u) = er;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(a.err_poisson) + pe * 4u) = ep;
+                *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.pdq_out) + pe * 4u) = pdq;
             }
 
+            CH_T(3)
             // ---- A: refpix apply + bias + linearity of row yi -> X slot of row r (its x was last read above,
             //         by this thread only); lin dq of the row enters the d-pipeline
             uint32_t d3 = 0;
@@ -336,7 +401,7 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                     const bool act = col_act && yi >= ay0 && yi < ay1;
                     const float smin = rr.smin;
                     const float span = rr.smax - smin;
-                    const bool fastdiv = rcp_safe(span);
+                    const bool fastdiv = __all(rcp_safe(span));  // wave-uniform
                     const float rspan = 1.0f / span;
                     uint32_t dq = rr.dq;
                     const double yd = (double)yi;
@@ -348,29 +413,35 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                         float S = (float)rr.S[g];
                         const float dk = rr.dk[g];
                         float v = S - dk;
-                        v = (float)((double)v - a.rowcorr[g * ny + yi]);
-                        const double *ln = a.lines + (g * nch + chn) * 2;
+                        v = (float)((double)v - RC[(yi - (R0 - 2)) * G + g]);
+                        const double *ln = LN + (chr * G + g) * 2;
                         const double iel = ln[0] * yd + ln[1];
                         v = (float)((double)v - iel);
                         S = v + dk;
                         if (act) S = S - rr.bs[g];
                         float t = S - smin;
                         t = 2.0f * t;
-                        const float quo = fastdiv ? div_rcp(t, span, rspan) : t / span;
+                        float quo;
+                        if (fastdiv)
+                            quo = div_rcp(t, span, rspan);
+                        else
+                            quo = t / span;
                         float z = -1.0f + quo;
                         if (g == 0 && a.do_not_flag_first) z = clip2<float>(z, -1.0f, 1.0f);
                         zz[g] = z;
                         SS[g] = S;
                         any_ex = any_ex || (fabsf(z) > 1.0f);
                     }
-                    const bool slow = __any(any_ex);  // some sample extrapolates: series with the linear branch
+                    const bool slow = __any(any_ex) && !(a.dbg & 32);  // some sample extrapolates: series with the linear branch
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const float z = zz[g];
                         float phi = rr.cf[0];
                         float pp = 1.0f, pc = z;
                         bool ex = false;
-                        if (slow) {
+                        if (a.dbg & 16) {
+                            phi = phi + z;
+                        } else if (slow) {
                             const float az = fabsf(z);
                             ex = az > 1.0f;
                             const float exc = az - 1.0f;
@@ -407,7 +478,9 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                     d3 = dq;
                 }
             }
-            __syncthreads();
+            CH_T(4)
+            if (!(a.dbg & 64)) __syncthreads();
+            CH_T(5)
             d0 = d1;
             d1 = d2;
             d2 = d3;
@@ -420,6 +493,12 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
             }
             s0 = s1;
         }
+#ifdef CH_STAMP
+        if ((tid & 63) == 0 && a.dbg_buf) {
+            unsigned long long *o = a.dbg_buf + ((size_t)blockIdx.x * (CH_BT / 64) + (tid >> 6)) * 6;
+            for (int i = 0; i < 6; ++i) o[i] += st_[i];
+        }
+#endif
     }
 }
 
@@ -427,23 +506,27 @@ static inline size_t chain_lds_bytes(int G, int k_dtype) {
     const size_t t = k_dtype == RIP_F64 ? 8 : 4;
     return (size_t)G * CH_BT * (3 * t + 3 * 4 + 4 + 2);
 }
+static inline size_t chain_lds_tables(int G, int rc_rows) { return (size_t)(3 * G * 2 + rc_rows * G) * 8; }
 
 template <int NP, int G, typename KT>
 static int launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
     extern double rip_guard_band;
-    const size_t lds = chain_lds_bytes(G, sizeof(KT) == 8 ? RIP_F64 : RIP_F32);
+    const size_t lds0 = chain_lds_bytes(G, sizeof(KT) == 8 ? RIP_F64 : RIP_F32);
     static int ncu = 0;
     if (!ncu) {
         hipDeviceProp_t prop;
         RIP_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
         ncu = prop.multiProcessorCount;
     }
-    const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+    const int per_cu = (int)((150 * 1024) / lds0) < 1 ? 1 : (int)((150 * 1024) / lds0);
     const int nstrips = (a.nx + CH_OUTW - 1) / CH_OUTW;
     long grid = (long)ncu * (per_cu > 4 ? 4 : per_cu);
     const long total_rows = (long)nstrips * a.ny;
     if (grid > (total_rows + 7) / 8) grid = (total_rows + 7) / 8;  // small frames: at least ~8 rows per workgroup
     if (grid < 1) grid = 1;
+    const long per = (total_rows + grid - 1) / grid;  // rows per workgroup (a range never spans more than `per` rows)
+    const size_t lds = lds0 + chain_lds_tables(G, (int)per + 4);
+    if (lds > 160 * 1024) return rip_fail(ctx, RIP_EINVAL, "fused chain: LDS budget exceeded (%zu bytes)", lds);
     if (lds > 48 * 1024)
         RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel<NP, G, KT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

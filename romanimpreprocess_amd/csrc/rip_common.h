@@ -100,6 +100,8 @@ struct rip_ctx {
     std::vector<RipPlan *> plans;
     // workspace (grown on demand)
     // per-stage device timing (HIP events on `stream`), see rip_profile_enable / rip_profile_read
+    int chain_dbg = 0;
+    unsigned long long *chain_dbg_buf = nullptr;  // 4096 waves x 6 phases (diagnostic builds)
     bool use_fused = true;  // rip_set_option("fused", 0) forces the stage-by-stage kernels
     bool prof = false;
     std::vector<hipEvent_t> prof_events;  // 5 per rip_calibrate call
@@ -183,6 +185,8 @@ struct ChainArgs {
     uint32_t *pdq_out;
     uint8_t *gdq_out;  // may be null
     float *cube_out;   // may be null
+    unsigned long long *dbg_buf;  // CH_STAMP builds only: per-wave phase cycle sums
+    int dbg;           // timing experiments only (rip_set_option "chain_dbg"): skips phases, results invalid
     int ny, nx, nb, ngrp;
 };
 bool rip_chain_supported(int nplanes, int G, int k_dtype, int gain_dtype);

@@ -1,0 +1,49 @@
+"""Timing experiment: the fused kernel with phases switched off (results invalid; timing only)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+
+from romanimpreprocess_amd import pipeline, synth
+
+rp = synth.READ_PATTERN_8
+N = 4096
+cal, ramp = synth.make_tiled_inputs(N, N, read_pattern=rp, p_order=8, seed=1, strip_rows=64)
+cb = pipeline.Calibrator(device=0)
+cb.load_caldir(0, cal)
+pid, meta = cb.plan_for(rp, ramp["frame_time"])
+dev = torch.device("cuda", 0)
+g = ramp["groupdq"].copy()
+g[0] |= 1
+t = [torch.from_numpy(ramp["data"].view(np.int16)).to(dev), torch.from_numpy(ramp["amp33"].view(np.int16)).to(dev),
+     torch.from_numpy(g).to(dev), torch.from_numpy(ramp["pixeldq"].view(np.int32)).to(dev)]
+o = [torch.empty((N, N), dtype=torch.float32, device=dev) for _ in range(3)] + [
+    torch.empty((N, N), dtype=torch.int32, device=dev), torch.empty((8, N, N), dtype=torch.uint8, device=dev)]
+torch.cuda.synchronize()
+
+
+def call():
+    cb.calibrate_device(0, pid, 8, t[0].data_ptr(), True, t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
+                        o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr())
+
+
+def run(mask, n=5):
+    cb.ctx.set_option("chain_dbg", mask)
+    for _ in range(2):
+        call()
+    cb.synchronize()
+    cb.ctx.profile(True)
+    cb.ctx.profile_read()
+    for _ in range(n):
+        call()
+    ms, nc = cb.ctx.profile_read()
+    cb.ctx.profile(False)
+    return ms[1] / nc
+
+
+names = {0: "full", 1: "no C (O1)", 2: "no E-ipc (O2)", 4: "no fit", 8: "no saturated path", 16: "no legendre",
+         32: "no lin slow branch", 3: "no ipc", 7: "no ipc, no fit", 23: "no ipc/fit/legendre", 12: "no fit/no sat"}
+for m in [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 8, 12, 16, 32, 7, 23]:
+    print(f"dbg={m:3d} {names.get(m, ''):28s} {run(m):8.3f} ms", flush=True)

@@ -1,0 +1,56 @@
+"""Diagnostic: per-phase cycle shares of the fused kernel (needs libromanhip_stamp.so built with -DCH_STAMP)."""
+import ctypes as C
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+from romanimpreprocess_amd import _native
+
+_native.LIB_PATH = os.path.join(REPO, "romanimpreprocess_amd", "libromanhip_stamp.so")
+import numpy as np
+import torch
+
+from romanimpreprocess_amd import pipeline, synth
+
+rp = synth.READ_PATTERN_8
+N = 4096
+cal, ramp = synth.make_tiled_inputs(N, N, read_pattern=rp, p_order=8, seed=1, strip_rows=64)
+cb = pipeline.Calibrator(device=0)
+lib = cb.ctx.lib
+lib.rip_chain_stamps.restype = C.c_int
+lib.rip_chain_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+cb.load_caldir(0, cal)
+pid, meta = cb.plan_for(rp, ramp["frame_time"])
+dev = torch.device("cuda", 0)
+g = ramp["groupdq"].copy()
+g[0] |= 1
+t = [torch.from_numpy(ramp["data"].view(np.int16)).to(dev), torch.from_numpy(ramp["amp33"].view(np.int16)).to(dev),
+     torch.from_numpy(g).to(dev), torch.from_numpy(ramp["pixeldq"].view(np.int32)).to(dev)]
+o = [torch.empty((N, N), dtype=torch.float32, device=dev) for _ in range(3)] + [
+    torch.empty((N, N), dtype=torch.int32, device=dev), torch.empty((8, N, N), dtype=torch.uint8, device=dev)]
+torch.cuda.synchronize()
+out = (C.c_double * 6)()
+lib.rip_chain_stamps(cb.ctx.h, out)  # allocates
+
+
+def call():
+    cb.calibrate_device(0, pid, 8, t[0].data_ptr(), True, t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
+                        o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr())
+
+
+names = ["P issue loads", "C O1", "barrier 1", "E O2+fit+out", "A lin", "barrier 2"]
+for mask in [int(x) for x in sys.argv[1:]] or [0]:
+    cb.ctx.set_option("chain_dbg", mask)
+    call()
+    cb.synchronize()
+    lib.rip_chain_stamps(cb.ctx.h, out)
+    n = 3
+    for _ in range(n):
+        call()
+    lib.rip_chain_stamps(cb.ctx.h, out)
+    tot = sum(out)
+    nw = 2048
+    print(f"dbg={mask}: total cycles per wave per launch {tot/n/nw:.0f}")
+    for i in range(6):
+        print(f"   {names[i]:16s} {out[i]/n/nw:10.0f} cycles/wave  {100*out[i]/tot:5.1f}%  ({out[i]/n/nw/141:.0f} per step)")
