@@ -1,0 +1,195 @@
+"""L1 -> L2 driver on the GPU: same entry point and configuration surface as the reference's
+``L1_to_L2/gen_cal_image.py`` (``calibrateimage(config, verbose=True)`` :480, CLI ``python -m
+romanimpreprocess_amd.L1_to_L2.gen_cal_image config.yaml`` :742-746).
+
+What runs where
+  * the per-pixel chain of ``calibrateimage`` lines 531-629 (reference pixels, bias, linearity, IPC, ramp fit
+    with jump detection, dark rate, error split, flat) -> one ``rip_calibrate`` call (HIP kernels);
+  * the host keeps what the reference does on the host in microseconds: metadata (:123-145), ramp weights
+    (:434-444), the process log, file I/O (ASDF through ``asdf`` when installed, else the in-repo reader/writer,
+    or ``.npz`` mirrors -- see ``calio``);
+  * steps whose source is NOT in the reference tree are restated from their call sites and documented
+    behaviour (parity unpinned): dq-init (:118, mask -> pixeldq, zero groupdq), saturation flagging
+    (:148-185, see ``flag_saturation``), and the L2 tree layout of ``romanisim.image.make_asdf`` (:653-662).
+  * not done here (outside the hot path): sky estimate / SKYORDER subtraction, WCS->gwcs and the
+    pixel-area map (pass ``AREAFACTOR``: file with an (N,N) f64 array, else 1), dark decay, WFI18 transient,
+    romancal likelihood ramp fit, FITS output.  Asking for one of those raises NotImplementedError.
+"""
+
+import sys
+
+import numpy as np
+
+from .. import calio, pars, pipeline, plan as planmod
+from ..dqflags import group, pixel
+from ..utils import processlog
+
+_cal_cache = {}  # (ctx id, tuple of CALDIR paths) -> slot
+
+
+def initializationstep(config, caldir, mylog):
+    """Read the L1 file and the mask: data (u16 cube), amp33, groupdq (zeros), pixeldq (mask dq), meta."""
+    with calio.open_tree(config["IN"]) as f:
+        r = f["roman"]
+        data = np.ascontiguousarray(r["data"])
+        amp33 = np.ascontiguousarray(r["amp33"]) if "amp33" in r else None
+        exposure = r["meta"]["exposure"]
+        frame_time = float(exposure["frame_time"])
+        read_pattern = [list(map(int, g)) for g in exposure["read_pattern"]]
+        l1meta = calio._materialise(r["meta"])
+    if data.dtype != np.uint16:
+        data = data.astype(np.float32)
+    if "mask" in caldir:
+        with calio.open_tree(caldir["mask"]) as f:
+            pixeldq = np.array(f["roman"]["dq"], dtype=np.uint32)
+    else:
+        pixeldq = np.zeros(data.shape[1:], dtype=np.uint32)
+    groupdq = np.zeros(data.shape, dtype=np.uint8)
+    meta = planmod.exposure_meta(read_pattern, frame_time)
+    if config.get("EXCLUDE_FIRST", True):
+        groupdq[0] |= np.uint8(group.DO_NOT_USE)
+    return {"data": data, "amp33": amp33, "groupdq": groupdq, "pixeldq": pixeldq, "meta": l1meta}, meta
+
+
+def flag_saturation(ramp, sat_threshold, backup=1, skip_firstn=1, n_pix_grow_sat=1, sat_dq=None):
+    """Saturation flags (restatement of the call at gen_cal_image.py:172-185; stcal's source is not available:
+    PARITY UNPINNED).  A resultant of group g >= skip_firstn is SATURATED where data >= threshold; the flag is
+    grown by ``n_pix_grow_sat`` pixels (3x3 box for 1), is sticky for all later groups, and is also set on the
+    ``backup`` preceding groups (but never on the first ``skip_firstn`` ones).  Pixels whose threshold is NaN or
+    flagged NO_SAT_CHECK are not checked.  pixeldq receives SATURATED where any group is flagged."""
+    data, gdq, pdq = ramp["data"], ramp["groupdq"], ramp["pixeldq"]
+    G = data.shape[0]
+    thr = np.array(sat_threshold, dtype=np.float32)
+    nocheck = ~np.isfinite(thr)
+    if sat_dq is not None:
+        nocheck |= (np.asarray(sat_dq) & np.uint32(pixel.NO_SAT_CHECK)) != 0
+    sat = np.zeros(data.shape, dtype=bool)
+    for g in range(skip_firstn, G):
+        s = (data[g] >= thr) & ~nocheck
+        for _ in range(n_pix_grow_sat):
+            grown = s.copy()
+            grown[1:, :] |= s[:-1, :]
+            grown[:-1, :] |= s[1:, :]
+            s = grown.copy()
+            s[:, 1:] |= grown[:, :-1]
+            s[:, :-1] |= grown[:, 1:]
+        sat[g] = s
+    for g in range(skip_firstn + 1, G):
+        sat[g] |= sat[g - 1]
+    for _ in range(int(backup)):
+        for g in range(skip_firstn, G - 1):
+            sat[g] |= sat[g + 1]
+    gdq |= np.where(sat, np.uint8(group.SATURATED), np.uint8(0))
+    pdq |= np.where(sat.any(axis=0), np.uint32(pixel.SATURATED), np.uint32(0))
+
+
+def saturation_check(ramp, caldir, mylog, backup=1, skip_firstn=1):
+    with calio.open_tree(caldir["saturation"]) as f:
+        r = f["roman"]
+        flag_saturation(ramp, np.asarray(r["data"]), backup=backup, skip_firstn=skip_firstn, n_pix_grow_sat=1,
+                        sat_dq=np.asarray(r["dq"]) if "dq" in r else None)
+
+
+def load_caldir_arrays(caldir):
+    """``roman`` branches of the CALDIR files the per-pixel chain needs (KeyError on a missing required key)."""
+    cal = {}
+    for key in ("dark", "read", "gain", "linearitylegendre", "ipc4d", "flat"):
+        cal[key] = calio.roman_branch(caldir[key])
+    if "biascorr" in caldir:
+        cal["biascorr"] = calio.roman_branch(caldir["biascorr"])
+    return cal
+
+
+def _caldir_slot(cb, caldir):
+    key = (id(cb.ctx), tuple(sorted((k, str(v)) for k, v in caldir.items() if isinstance(v, str))))
+    if key in _cal_cache:
+        return _cal_cache[key]
+    slot = len(_cal_cache) % 32
+    cb.load_caldir(slot, load_caldir_arrays(caldir))
+    _cal_cache[key] = slot
+    return slot
+
+
+def calibrateimage(config, verbose=True, calibrator=None):
+    """Run the calibrations specified by ``config`` (dict, normally from YAML) and write the L2 file."""
+    for unsupported in ("SKYORDER", "romancal_ramp_fit", "correct_wfi18_transient"):
+        if config.get(unsupported):
+            raise NotImplementedError(f"{unsupported} is outside the GPU L1->L2 path of this package")
+    if config.get("FITSOUT"):
+        raise NotImplementedError("FITSOUT needs astropy, which this package does not depend on")
+    mylog = processlog.ProcessLog()
+    caldir = config["CALDIR"]
+    if "dark_decay" in caldir:
+        raise NotImplementedError("dark_decay is a romancal step outside the GPU L1->L2 path of this package")
+    backup = config.get("SATURATION_BACKUP", 1)
+
+    ramp, meta = initializationstep(config, caldir, mylog)
+    meta["nborder"] = pars.nborder
+    nb = pars.nborder
+    mylog.append("Initialized data\n")
+    saturation_check(ramp, caldir, mylog, backup=backup)
+    mylog.append("Saturation check complete\n")
+
+    cb = calibrator or pipeline.Calibrator()
+    slot = _caldir_slot(cb, caldir)
+    exclude_first = config.get("EXCLUDE_FIRST", True)
+    area = None
+    if "AREAFACTOR" in config:
+        with calio.open_tree(config["AREAFACTOR"]) as f:
+            area = np.asarray(f["roman"]["data"], dtype=np.float64)
+    ramp["read_pattern"], ramp["frame_time"] = meta["read_pattern"], meta["frame_time"]
+    res = cb.calibrate(slot, ramp, exclude_first=exclude_first, ramp_opt_pars=config.get("RAMP_OPT_PARS"),
+                       jump_pars=config.get("JUMP_DETECT_PARS"), area_factor=area)
+    K = res["K"]
+    uopt = config.get("RAMP_OPT_PARS", planmod.DEFAULT_RAMP_OPT_PARS)
+    mylog.append(f"\n\nRamp fit optimized for u = {planmod.ramp_opt_u(uopt):11.5E} s**-1\n")
+    mylog.append(f"weights = {K}\n")
+    mylog.append("Reference pixels, bias, linearity, IPC, ramp fit, dark current, flat: complete (GPU)\n")
+
+    slope, pdq, rdq = res["slope"], res["pixeldq"], res["groupdq"]
+    err_read, err_poisson = res["err_read"], res["err_poisson"]
+    with calio.open_tree(caldir["gain"]) as g_:
+        medgain = float(np.median(g_["roman"]["data"]))
+    mylog.append(f"median gain = {medgain:8.5f} e/DN\n")
+
+    act = (slice(nb, -nb), slice(nb, -nb))
+    var_r, var_p = err_read[act] ** 2, err_poisson[act] ** 2
+    im2 = {
+        "meta": ramp["meta"],
+        "data": slope[act].copy(),
+        "dq": pdq[act].copy(),
+        "var_poisson": var_p,
+        "var_rnoise": var_r,
+        "var_flat": np.zeros_like(var_r),
+        "err": np.sqrt(var_r + var_p),
+        "data_withsky": slope[act].copy(),
+    }
+    if ramp["amp33"] is not None:
+        im2["amp33"] = ramp["amp33"]
+    processinfo = {
+        "medsky": None, "medgain": medgain, "skyorder": -1, "skycoefs": np.array([], dtype=np.float32),
+        "ramp_opt_pars": dict(uopt), "weights": K, "config": config, "log": mylog.output,
+        "exclude_first": bool(exclude_first),
+        "meta": {k: (v if not isinstance(v, np.ndarray) else v) for k, v in meta.items() if k != "read_pattern"},
+    }
+    if config.get("SLICEOUT"):
+        ngrp = rdq.shape[0]
+        if ngrp >= 128:
+            raise ValueError("too many groups")
+        endslice = np.zeros(slope[act].shape, dtype=np.int8) - 1
+        sat8 = np.uint8(group.SATURATED)
+        for iend in range(1, ngrp):
+            first = ((rdq[iend][act] & ~rdq[iend - 1][act]) & sat8) != 0
+            endslice = np.where(first, np.int8(iend - 1), endslice)
+        processinfo["endslice"] = endslice
+    calio.write_asdf(config["OUT"], {"roman": im2, "processinfo": processinfo})
+    if verbose:
+        print(mylog.output)
+    return
+
+
+if __name__ == "__main__":
+    import yaml
+
+    with open(sys.argv[1]) as f:
+        calibrateimage(yaml.safe_load(f))

@@ -16,6 +16,7 @@ import bz2
 import contextlib
 import hashlib
 import io
+import json
 import os
 import struct
 import zlib
@@ -189,8 +190,10 @@ def save_npz_tree(path, tree):
         if isinstance(node, dict):
             for k, v in node.items():
                 walk(f"{prefix}/{k}" if prefix else str(k), v)
-        else:
+        elif isinstance(node, np.ndarray) or np.isscalar(node) and not isinstance(node, (str, bool)):
             flat[prefix] = np.asarray(node)
+        else:  # lists (possibly ragged), strings, booleans, None: JSON text
+            flat["json:" + prefix] = np.array(json.dumps(node))
 
     walk("", tree)
     np.savez(path, **flat)
@@ -201,11 +204,12 @@ def _load_npz_tree(path):
     with np.load(path, allow_pickle=False) as f:
         for key in f.files:
             node = tree
-            parts = key.split("/")
+            is_json = key.startswith("json:")
+            parts = (key[5:] if is_json else key).split("/")
             for p in parts[:-1]:
                 node = node.setdefault(p, {})
             v = f[key]
-            node[parts[-1]] = v.item() if v.ndim == 0 else v
+            node[parts[-1]] = json.loads(str(v)) if is_json else (v.item() if v.ndim == 0 else v)
     return tree
 
 

@@ -113,3 +113,71 @@ def test_bad_arguments():
         cb.ctx.drop_caldir(9)
     with pytest.raises(KeyError):
         cb.calibrate(7, ramp)  # never loaded
+
+
+def test_fused_exact_everywhere_gives_same_flags():
+    """guard = inf makes the fused kernel re-evaluate EVERY jump significance in the reference's exact order;
+    the default (approximate evaluation + error band + exact inside the band) must give identical outputs."""
+    rp = synth.READ_PATTERN_8
+    cal = synth.make_caldir(64, 256, read_pattern=rp, p_order=8, seed=21, bias_amplitude=2.0)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=22, cr_frac=0.05)
+    ctx = gpu_context()
+    cb = pipeline.Calibrator(ctx=ctx)
+    cb.load_caldir(2, cal)
+    a = cb.calibrate(2, ramp)
+    ctx.lib.rip_set_guard_band(float("inf"))
+    try:
+        b = cb.calibrate(2, ramp)
+    finally:
+        ctx.lib.rip_set_guard_band(1e-5)
+    for k in ("slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
+        assert_same_bits(a[k], b[k], k)
+    assert np.count_nonzero(a["pixeldq"] & 4) > 100
+    cb.ctx.drop_caldir(2)
+
+
+def test_calibrateimage_files_end_to_end(tmp_path):
+    """config dict -> ASDF L1 + CALDIR files -> calibrateimage -> ASDF L2, against the oracle chain."""
+    from romanimpreprocess_amd import calio
+    from romanimpreprocess_amd.L1_to_L2 import gen_cal_image
+
+    rp = synth.READ_PATTERN_6
+    ny, nx = 48, 256
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=3, seed=31, bias_amplitude=1.0)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=32, cr_frac=0.02)
+    caldir = {}
+    names = {"dark": "dark", "read": "read", "gain": "gain", "linearitylegendre": "linearitylegendre", "ipc4d": "ipc4d",
+             "flat": "pflat", "biascorr": "biascorr", "mask": "mask", "saturation": "saturation"}
+    for key, fname in names.items():
+        path = tmp_path / f"roman_wfi_{fname}_TEST_SCA04.{'npz' if key == 'biascorr' else 'asdf'}"
+        if key == "biascorr":
+            calio.save_npz_tree(str(path), {"roman": cal[key]})
+        else:
+            calio.write_asdf(str(path), {"roman": cal[key]})
+        caldir[key] = str(path)
+    l1 = {"roman": {"data": ramp["data"], "amp33": ramp["amp33"],
+                    "meta": {"exposure": {"frame_time": synth.FRAME_TIME, "read_pattern": rp},
+                             "instrument": {"detector": "WFI04"}}}}
+    calio.write_asdf(str(tmp_path / "l1.asdf"), l1)
+    config = {"IN": str(tmp_path / "l1.asdf"), "OUT": str(tmp_path / "l2.asdf"), "CALDIR": caldir,
+              "JUMP_DETECT_PARS": {"SthreshA": 5.0, "IthreshB": 800.0}, "SLICEOUT": True}
+    gen_cal_image.calibrateimage(config, verbose=False, calibrator=pipeline.Calibrator(ctx=gpu_context()))
+    out = calio.read_asdf(config["OUT"])
+
+    # oracle on the same inputs (dq-init + this package's saturation flagging are host steps shared by both)
+    r0 = {"data": ramp["data"], "amp33": ramp["amp33"], "groupdq": np.zeros(ramp["data"].shape, np.uint8),
+          "pixeldq": cal["mask"]["dq"].copy(), "read_pattern": rp, "frame_time": synth.FRAME_TIME}
+    r0["groupdq"][0] |= 1
+    gen_cal_image.flag_saturation(r0, cal["saturation"]["data"], backup=1, skip_firstn=1, sat_dq=cal["saturation"]["dq"])
+    ref = oracle.calibrate_arrays(r0, cal, jump_pars=config["JUMP_DETECT_PARS"])
+    act = (slice(4, -4), slice(4, -4))
+    assert_same_bits(out["roman"]["dq"], ref["pixeldq"][act], "L2 dq")
+    np.testing.assert_allclose(out["roman"]["data"], ref["slope"][act], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out["roman"]["var_poisson"], ref["err_poisson"][act] ** 2, rtol=3e-5, atol=1e-12)
+    assert out["processinfo"]["exclude_first"] is True and "endslice" in out["processinfo"]
+    assert_same_bits(np.asarray(out["processinfo"]["weights"], dtype=np.float32), ref["K"], "weights")
+    with pytest.raises(KeyError):
+        gen_cal_image.calibrateimage({"IN": config["IN"], "OUT": config["OUT"], "CALDIR": {"gain": caldir["gain"]}},
+                                     verbose=False)
+    with pytest.raises(NotImplementedError):
+        gen_cal_image.calibrateimage(dict(config, SKYORDER=2), verbose=False)

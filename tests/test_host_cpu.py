@@ -1,0 +1,203 @@
+"""CPU-only tests of the host side: C-ABI binding, plan scalars, file formats, sharding over gloo."""
+
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+from conftest import REPO, assert_same_bits, load_golden
+
+from romanimpreprocess_amd import _native, calio, plan as planmod, synth
+from romanimpreprocess_amd.dqflags import group, pixel
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "romanhip.h")).read()
+    declared = set(re.findall(r"\b(rip_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"rip_ctx", "rip_status", "rip_dtype", "rip_location"}
+    lib = _native.load_library()  # binds every entry of SYMBOLS or raises
+    assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.rip_version() == 100
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """sizeof/offsetof of the ABI structs as gcc sees them == the ctypes mirrors."""
+    src = tmp_path / "abi.c"
+    fields = {
+        "rip_caldir_desc": ["ny", "dark_data", "refout_slope", "gain", "lin_coefs", "ipc4d", "flat", "biascorr"],
+        "rip_plan_desc": ["ngrp", "tbar", "nreads", "K", "nvariants", "variant_coef", "sthresh_a", "ithresh_b"],
+        "rip_ramp_desc": ["location", "data", "data_dtype", "amp33", "area_factor", "channel_lines"],
+        "rip_outputs": ["location", "slope", "pixeldq", "groupdq", "cube"],
+    }
+    body = "".join(f'printf("{s} %zu\\n", sizeof({s}));\n' + "".join(
+        f'printf("{s}.{f} %zu\\n", offsetof({s}, {f}));\n' for f in fl) for s, fl in fields.items())
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "romanhip.h"\nint main(void){\n' + body + "return 0;}\n")
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    mirror = {"rip_caldir_desc": _native.CaldirDesc, "rip_plan_desc": _native.PlanDesc,
+              "rip_ramp_desc": _native.RampDesc, "rip_outputs": _native.Outputs}
+    for s, fl in fields.items():
+        assert int(got[s]) == C.sizeof(mirror[s]), s
+        for f in fl:
+            assert int(got[f"{s}.{f}"]) == getattr(mirror[s], f).offset, f"{s}.{f}"
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no HIP device|rip_ctx_create"):
+        _native.Context(0)
+
+
+def test_meta_and_weights_match_reference_goldens():
+    g = load_golden("weights")
+    for tag, rp in (("g6", synth.READ_PATTERN_6), ("g8", synth.READ_PATTERN_8), ("g16", synth.READ_PATTERN_16)):
+        meta = planmod.exposure_meta(rp, synth.FRAME_TIME)
+        assert_same_bits(meta["tbar"], g[f"{tag}_tbar"], "tbar")
+        assert_same_bits(meta["tau"], g[f"{tag}_tau"], "tau")
+        assert_same_bits(meta["N"], g[f"{tag}_N"], "N")
+        for ef in (True, False):
+            for utag, u in (("udef", planmod.ramp_opt_u(None)), ("ubig", 0.05)):
+                assert_same_bits(planmod.construct_weights(u, meta, ef), g[f"{tag}_{'ex' if ef else 'in'}_{utag}"], "K")
+
+
+def test_plan_desc_scalars_match_the_oracle():
+    from oracle import rampfit
+    for rp, ef in ((synth.READ_PATTERN_8, True), (synth.READ_PATTERN_6, False), (synth.READ_PATTERN_16, True)):
+        meta = planmod.exposure_meta(rp, synth.FRAME_TIME)
+        K = planmod.construct_weights(planmod.ramp_opt_u(None), meta, ef)
+        d = planmod.plan_desc(meta, K, ef, True, {"SthreshA": 5.0})
+        start = 1 if ef else 0
+        G = len(rp)
+        ends = [G] + list(range(G - 1, 2 + start, -1))
+        assert d.nvariants == len(ends) and d.sthresh_a == 5.0 and d.sthresh_b == 4.5
+        om = rampfit.ma_table_meta(rp, synth.FRAME_TIME)
+        om["K"] = K
+        for v, g in enumerate(ends):
+            k = K[:g] if v == 0 else rampfit.two_point_weights(om, g, start)
+            assert d.variant_g[v] == g
+            assert np.float32(d.variant_coef[v]) == np.float32(rampfit.poisson_coef(k, om, g, start))
+            assert np.float32(d.variant_rfac[v]) == np.float32(rampfit.read_factor(k, om, g))
+    with pytest.raises(ValueError, match="too many groups"):
+        rp = [[i] for i in range(70)]
+        m = planmod.exposure_meta(rp, 3.04)
+        planmod.plan_desc(m, np.zeros(70, np.float32))
+
+
+def test_asdf_and_npz_round_trip(tmp_path):
+    tree = {"roman": {"data": np.arange(24, dtype=np.float32).reshape(2, 3, 4), "dq": np.full((3, 4), 2**31, np.uint32),
+                      "anc": {"C_PINK": 0.8, "U_PINK": 0.4}, "amp33": {"valid": True, "M_PINK": 0.8,
+                                                                       "med": np.ones((3, 128), np.float32)},
+                      "meta": {"exposure": {"frame_time": 3.04, "read_pattern": [[0], [1, 2], [3]]}},
+                      "k64": np.linspace(0, 1, 5)}}
+    p = tmp_path / "x.asdf"
+    calio.write_asdf(str(p), tree)
+    back = calio.read_asdf(str(p))
+    r = back["roman"]
+    assert_same_bits(r["data"], tree["roman"]["data"], "data")
+    assert_same_bits(r["dq"], tree["roman"]["dq"], "dq")
+    assert_same_bits(r["k64"], tree["roman"]["k64"], "k64")
+    assert r["anc"] == {"C_PINK": 0.8, "U_PINK": 0.4} and r["amp33"]["valid"] is True
+    assert r["meta"]["exposure"]["read_pattern"] == [[0], [1, 2], [3]]
+    with calio.open_tree(str(p)) as f:
+        assert "amp33" in f["roman"] and f["roman"]["anc"]["C_PINK"] == 0.8
+    q = tmp_path / "x.npz"
+    calio.save_npz_tree(str(q), tree)
+    with calio.open_tree(str(q)) as f:
+        assert_same_bits(np.asarray(f["roman"]["amp33"]["med"]), tree["roman"]["amp33"]["med"], "med")
+        assert f["roman"]["anc"]["C_PINK"] == 0.8
+    with calio.open_tree({"data": 1}) as f:
+        assert f["roman"]["data"] == 1
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.asdf").write_bytes(b"not asdf")
+        calio.read_asdf(str(tmp_path / "bad.asdf"))
+
+
+def test_flag_saturation_semantics():
+    from romanimpreprocess_amd.L1_to_L2.gen_cal_image import flag_saturation
+    G, n = 6, 9
+    data = np.zeros((G, n, n), np.float32)
+    data[3:, 4, 4] = 100.0       # saturates from group 3 on
+    data[0, 1, 1] = 100.0        # group 0 is never checked (skip_firstn = 1)
+    thr = np.full((n, n), 50.0, np.float32)
+    thr[7, 7] = np.nan
+    data[2:, 7, 7] = 1e6         # NaN threshold: not checked
+    ramp = {"data": data, "groupdq": np.zeros((G, n, n), np.uint8), "pixeldq": np.zeros((n, n), np.uint32)}
+    flag_saturation(ramp, thr, backup=1, skip_firstn=1)
+    sat = (ramp["groupdq"] & np.uint8(group.SATURATED)) != 0
+    assert not sat[:2].any() and not sat[:, 7, 7].any() and not sat[:, 1, 1].any()
+    assert sat[2:, 3:6, 3:6].all()           # backup by one group, grown by one pixel, sticky
+    assert not sat[2:, 0, 0].any()
+    assert (ramp["pixeldq"][3:6, 3:6] & np.uint32(pixel.SATURATED)).all() and ramp["pixeldq"][0, 0] == 0
+
+
+def test_synthetic_inputs_shapes_and_tiling():
+    cal, ramp = synth.make_tiled_inputs(160, 256, read_pattern=synth.READ_PATTERN_6, p_order=3, seed=3, strip_rows=32)
+    assert ramp["data"].shape == (6, 160, 256) and ramp["data"].dtype == np.uint16
+    assert cal["ipc4d"]["data"].shape == (3, 3, 152, 248) and cal["biascorr"]["data"].shape == (6, 152, 248)
+    assert cal["linearitylegendre"]["data"].shape == (4, 160, 256) and ramp["amp33"].shape == (6, 160, 128)
+    assert (cal["mask"]["dq"][:4] & np.uint32(pixel.REFERENCE_PIXEL)).all()
+    assert not (cal["mask"]["dq"][4:-4, 4:-4] & np.uint32(pixel.REFERENCE_PIXEL)).any()
+    assert (ramp["groupdq"][0] & 1).all()
+
+
+_GLOO_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {repo!r})
+    import numpy as np, torch, torch.distributed as dist
+    from romanimpreprocess_amd import sharding
+    from romanimpreprocess_amd.harness import many_realizations as mr
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = sharding.scatter_items(list(range(100, 172)) if rank == 0 else [])
+    assert mine == list(range(100, 172))[rank::world], mine
+    # moment planes: every rank accumulates its seeds, one all-reduce gives the full statistics
+    rng = np.random.default_rng(0)
+    slopes = rng.normal(1.0, 0.1, size=(8, 5, 7)).astype(np.float32)
+    dq = (rng.uniform(size=(8, 5, 7)) < 0.2).astype(np.uint32) * 4
+    m = {{k: np.zeros((5, 7)) for k in ("N", "S1", "S2", "E1")}}
+    for j in range(rank, 8, world):
+        mr.accumulate(m, slopes[j], np.full((5, 7), 0.1, np.float32), dq[j])
+    planes = [torch.from_numpy(m[k]) for k in ("N", "S1", "S2", "E1")]
+    sharding.allreduce_sum_(planes)
+    ref = {{k: np.zeros((5, 7)) for k in ("N", "S1", "S2", "E1")}}
+    for j in range(8):
+        mr.accumulate(ref, slopes[j], np.full((5, 7), 0.1, np.float32), dq[j])
+    for k, t in zip(("N", "S1", "S2", "E1"), planes):
+        np.testing.assert_allclose(t.numpy(), ref[k], rtol=1e-12)
+    assert sharding.max_over_ranks(1.0 + rank) == float(world)
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_sharding_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER.format(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
+
+
+def test_many_realizations_finalize_sentinel():
+    from romanimpreprocess_amd.harness import many_realizations as mr
+    m = {k: np.zeros((2, 2)) for k in ("N", "S1", "S2", "E1")}
+    mr.accumulate(m, np.array([[1.0, 2.0], [3.0, 4.0]], np.float32), np.ones((2, 2), np.float32),
+                  np.array([[0, 4], [0, 0]], np.uint32))
+    mr.accumulate(m, np.array([[3.0, 2.0], [5.0, 4.0]], np.float32), np.ones((2, 2), np.float32),
+                  np.array([[0, 2], [0, 0]], np.uint32))
+    out = mr.finalize(m, np.zeros((2, 2)))
+    assert out[1, 0, 0] == 2 and out[2, 0, 0] == 2.0 and out[3, 0, 0] == 1.0
+    assert out[1, 0, 1] == 0 and (out[2:, 0, 1] == -1000.0).all()
