@@ -48,8 +48,20 @@ def alg_bytes(G, ny, nx, nb, nplanes, gain_size=4, ipc_size=4, data_size=2):
     return inputs + outputs, per_kernel
 
 
-def cpu_baseline(cal, ramp, rows=128):
-    """numpy oracle (bit-identical to the reference by tests/golden) on a `rows`-row strip of the same ramp."""
+def cpu_baseline(cal, ramp, target_s=15.0):
+    """numpy oracle (bit-identical to the reference by tests/golden) on a strip of the same ramp sized for about
+    `target_s` seconds of single-thread CPU work (a 128-row probe first, then the sized sample)."""
+    ny = ramp["data"].shape[1]
+    probe = _cpu_strip(cal, ramp, min(128, ny - 8))
+    per_row = probe[1] / probe[2]
+    rows = int(max(128, min(ny - 8, target_s / per_row)))
+    frac, dt, nrows = _cpu_strip(cal, ramp, rows)
+    return {"value": frac / dt, "unit": "ramps/s", "cores": 1, "kind": "port",
+            "sample": f"{nrows}x{ramp['data'].shape[2]}x{ramp['data'].shape[0]} strip of the same ramp "
+                      f"({frac:.4f} ramp) through the numpy oracle, {dt:.1f} s, single thread"}
+
+
+def _cpu_strip(cal, ramp, rows):
     import oracle
 
     nb = 4
@@ -72,9 +84,7 @@ def cpu_baseline(cal, ramp, rows=128):
     oracle.calibrate_arrays(sub_ramp, sub_cal)
     dt = time.perf_counter() - t0
     frac = (rows + 2 * nb) / ramp["data"].shape[1]
-    return {"value": frac / dt, "unit": "ramps/s", "cores": 1, "kind": "port",
-            "sample": f"{rows + 2 * nb}x{ramp['data'].shape[2]}x{ramp['data'].shape[0]} strip of the same ramp "
-                      f"({frac:.4f} ramp) through the numpy oracle, {dt:.1f} s, single thread"}
+    return frac, dt, rows + 2 * nb
 
 
 def main():

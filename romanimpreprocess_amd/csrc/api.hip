@@ -161,19 +161,19 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value) {
 }
 
 // diagnostic builds (-DCH_STAMP): per-phase cycle sums of the fused kernel, summed over waves; clears the buffer
-int rip_chain_stamps(rip_ctx *ctx, double out[6]) {
-    const size_t n = 4096 * 6;
+int rip_chain_stamps(rip_ctx *ctx, double out[9]) {
+    const size_t n = 4096 * 9;
     if (!ctx->chain_dbg_buf) {
         RIP_HIP(ctx, hipMalloc((void **)&ctx->chain_dbg_buf, n * 8));
         RIP_HIP(ctx, hipMemset(ctx->chain_dbg_buf, 0, n * 8));
-        for (int i = 0; i < 6; ++i) out[i] = 0;
+        for (int i = 0; i < 9; ++i) out[i] = 0;
         return RIP_OK;
     }
     RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<unsigned long long> h(n);
     RIP_HIP(ctx, hipMemcpy(h.data(), ctx->chain_dbg_buf, n * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 6; ++i) out[i] = 0;
-    for (size_t k = 0; k < n; ++k) out[k % 6] += (double)h[k];
+    for (int i = 0; i < 9; ++i) out[i] = 0;
+    for (size_t k = 0; k < n; ++k) out[k % 9] += (double)h[k];
     RIP_HIP(ctx, hipMemset(ctx->chain_dbg_buf, 0, n * 8));
     return RIP_OK;
 }

@@ -30,16 +30,19 @@ t = [torch.from_numpy(ramp["data"].view(np.int16)).to(dev), torch.from_numpy(ram
 o = [torch.empty((N, N), dtype=torch.float32, device=dev) for _ in range(3)] + [
     torch.empty((N, N), dtype=torch.int32, device=dev), torch.empty((8, N, N), dtype=torch.uint8, device=dev)]
 torch.cuda.synchronize()
-out = (C.c_double * 6)()
+out = (C.c_double * 9)()
 lib.rip_chain_stamps(cb.ctx.h, out)  # allocates
+
+
+NOGDQ = bool(int(os.environ.get("NOGDQ", "0")))
 
 
 def call():
     cb.calibrate_device(0, pid, 8, t[0].data_ptr(), True, t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
-                        o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr())
+                        o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), None if NOGDQ else o[4].data_ptr())
 
 
-names = ["P issue loads", "C O1", "barrier 1", "E O2+fit+out", "A lin", "barrier 2"]
+names = ["P issue loads", "C O1", "barrier 1", "E rest (finish+stores)", "A lin", "barrier 2", "E: O2", "E: fit+flags", "wait all loads (dbg 2048)"]
 for mask in [int(x) for x in sys.argv[1:]] or [0]:
     cb.ctx.set_option("chain_dbg", mask)
     call()
@@ -52,5 +55,5 @@ for mask in [int(x) for x in sys.argv[1:]] or [0]:
     tot = sum(out)
     nw = 2048
     print(f"dbg={mask}: total cycles per wave per launch {tot/n/nw:.0f}")
-    for i in range(6):
+    for i in range(9):
         print(f"   {names[i]:16s} {out[i]/n/nw:10.0f} cycles/wave  {100*out[i]/tot:5.1f}%  ({out[i]/n/nw/141:.0f} per step)")
