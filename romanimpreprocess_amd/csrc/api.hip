@@ -456,12 +456,36 @@ int rip_plan_create(rip_ctx *ctx, const rip_plan_desc *d, int *plan_id) {
     const size_t o_var = al(sizeof(RipPlanHeader));
     const size_t o_k = o_var + al(p->variants.size() * sizeof(RipVariant));
     const size_t o_d = o_k + al(p->kvals.size() * sizeof(float));
-    p->bytes = o_d + al(p->diffs.size() * sizeof(RipDiff));
+    const size_t o_dense = o_d + al(p->diffs.size() * sizeof(RipDiff));
+    p->bytes = o_dense + al(sizeof(RipDense));
+    {  // dense view of variant 0 (the full ramp) for the register-resident fit
+        RipDense &dn = p->dense;
+        memset(&dn, 0, sizeof dn);
+        for (int i = 0; i < G; ++i) dn.K2[i] = d->K[i];
+        const RipVariant &v0 = p->variants[0];
+        for (int k = 0; k < v0.ndiff; ++k) {
+            const RipDiff &df = p->diffs[v0.diff_ofs + k];
+            const int i = df.i, di = df.j - df.i, ps = 2 * (i / 2) + (di - 1), e = i & 1;
+            dn.valid |= 1u << (2 * ps + e);
+            dn.kidx[2 * ps + e] = k;
+            dn.pairs[ps].inv_dt[e] = df.inv_dt;
+            dn.pairs[ps].A[e] = df.A;
+            dn.pairs[ps].B[e] = df.B;
+            dn.pairs[ps].relerr[e] = df.relerr;
+        }
+        for (int ps = 0; ps < RIP_MAX_GROUPS; ++ps)
+            for (int e = 0; e < 2; ++e) {
+                const int bit = 2 * ps + e;
+                const bool used = bit < 32 && ((dn.valid >> bit) & 1u);
+                if (!used) dn.pairs[ps].A[e] = 1.0f;  // keeps the approximate variance positive for unused slots
+            }
+    }
     std::vector<char> img(p->bytes, 0);
     memcpy(img.data(), &h, sizeof h);
     memcpy(img.data() + o_var, p->variants.data(), p->variants.size() * sizeof(RipVariant));
     memcpy(img.data() + o_k, p->kvals.data(), p->kvals.size() * sizeof(float));
     if (!p->diffs.empty()) memcpy(img.data() + o_d, p->diffs.data(), p->diffs.size() * sizeof(RipDiff));
+    memcpy(img.data() + o_dense, &p->dense, sizeof(RipDense));
     hipError_t e = hipMalloc(&p->dev, p->bytes);
     if (e == hipSuccess) e = hipMemcpy(p->dev, img.data(), p->bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -472,6 +496,7 @@ int rip_plan_create(rip_ctx *ctx, const rip_plan_desc *d, int *plan_id) {
     p->d_variants = reinterpret_cast<const RipVariant *>((char *)p->dev + o_var);
     p->d_k = reinterpret_cast<const float *>((char *)p->dev + o_k);
     p->d_diffs = reinterpret_cast<const RipDiff *>((char *)p->dev + o_d);
+    p->d_dense = reinterpret_cast<const RipDense *>((char *)p->dev + o_dense);
     int id = -1;
     for (size_t i = 0; i < ctx->plans.size(); ++i)
         if (!ctx->plans[i]) {
@@ -660,6 +685,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         ca.nx = nx;
         ca.nb = c.nb;
         ca.ngrp = G;
+        ca.dense = plan->d_dense;
         ca.dbg = ctx->chain_dbg;
         ca.dbg_buf = ctx->chain_dbg_buf;
         if ((rc = rip_launch_chain(ctx, plan, ca, c.lin_nplanes, c.ipc_dtype))) return rc;

@@ -319,6 +319,7 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
             const float rgain = 1.0f / e_gain;
             const bool all = __all(vA == 0x1ffu || !act);  // wave-uniform
             float d[G];
+            f2 dpair[GP];
             if constexpr (PK) {
 #pragma unroll
                 for (int p = 0; p < GP; ++p) {
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                     }
                     d[2 * p] = val.x;
                     d[2 * p + 1] = val.y;
+                    dpair[p] = val;
                 }
             } else {
                 const float *Xf = reinterpret_cast<const float *>(X2);
@@ -354,6 +356,8 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                     }
                     d[g] = val;
                 }
+#pragma unroll
+                for (int p = 0; p < GP; ++p) dpair[p] = f2{d[2 * p], d[2 * p + 1]};
             }
             uint32_t anyq = 0;
 #pragma unroll
@@ -378,8 +382,8 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                                             guard, pdq_in, a.gdq_out ? a.gdq_out + pe : nullptr, npix, s, er, ep, pdq);
             } else {
                 uint32_t jmask = 0;
-                fit_full_regs<G>(d, h, vars[0], kvals + vars[0].k_ofs, diffs + vars[0].diff_ofs, e_gain, e_read, act,
-                                 guard, s, er, ep, jmask);
+                fit_full_pk<G>(dpair, h, vars[0], a.dense, kvals + vars[0].k_ofs, diffs + vars[0].diff_ofs, e_gain, e_read,
+                               act, guard, s, er, ep, jmask);
                 // flag propagation (fitting.py:339-353) without saturation
                 uint32_t orq = 0;
                 bool all_dnu = true;
@@ -412,9 +416,18 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                 float er2 = sqrtf(clip_lo<float>(e2 - p2, 0.0f));
                 if (a.flat) {
                     pdq |= e_ff;
-                    s = s / e_flat;
-                    er2 = er2 / e_flat;
-                    ep2 = ep2 / e_flat;
+                    if (__all(rcp_safe(e_flat) && fabsf(s) < 1e18f && fabsf(er2) < 1e18f && fabsf(ep2) < 1e18f &&
+                              (s == 0.0f || fabsf(s) > 1e-18f) && (er2 == 0.0f || er2 > 1e-18f) &&
+                              (ep2 == 0.0f || ep2 > 1e-18f))) {
+                        const float rflat = 1.0f / e_flat;
+                        s = div_rcp(s, e_flat, rflat);
+                        er2 = div_rcp(er2, e_flat, rflat);
+                        ep2 = div_rcp(ep2, e_flat, rflat);
+                    } else {
+                        s = s / e_flat;
+                        er2 = er2 / e_flat;
+                        ep2 = ep2 / e_flat;
+                    }
                 }
                 er = er2;
                 ep = ep2;

@@ -266,3 +266,117 @@ __device__ __forceinline__ void fit_full_regs(const float (&d)[G], const RipPlan
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Packed form of fit_full_regs: the ramp arrives as float2 pairs dA[p] = (d[2p], d[2p+1]) (as the IPC stage
+// produces them); the jump differences (i, i+di), (i+1, i+1+di) of one pair slot are evaluated together
+// with packed f32 arithmetic, from the dense per-plan table RipDense (compile-time offsets: every uniform
+// table load can be issued up front).  Same outputs as fit_variant() on the full ramp.
+typedef float rf2 __attribute__((ext_vector_type(2)));
+
+template <int G>
+__device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPlanHeader *__restrict__ h,
+                                            const RipVariant v, const RipDense *__restrict__ dn,
+                                            const float *__restrict__ kv, const RipDiff *__restrict__ df, float gain,
+                                            float rn, bool flag, double guard, float &s_out, float &er_out,
+                                            float &ep_out, uint32_t &jmask) {
+    constexpr int GP = G / 2;
+    const float d1 = dA[0].y;
+    const rf2 d11 = {d1, d1};
+    float s = 0.0f;
+#pragma unroll
+    for (int p = 0; p < GP; ++p) {
+        const rf2 diff = dA[p] - d11;
+        const rf2 k2 = {dn->K2[2 * p], dn->K2[2 * p + 1]};
+        const rf2 prod = k2 * diff;
+        s = s + prod.x;
+        s = s + prod.y;
+    }
+    const float gc = clip2<float>(gain, 1e-4f, 1e4f);
+    const float dv = clip_lo<float>(s / gc, 0.0f);
+    const float pv = clip_lo<float>(v.coef * dv, 0.0f);
+    s_out = s;
+    er_out = rn * v.rfac;
+    ep_out = sqrtf(pv);
+    if (!__any(flag)) return;
+
+    const float xc = clip2<float>(s, h->ia, h->ib);
+    const bool need_log = xc != h->ia;  // log(1) = 0 exactly otherwise
+    float lx = 0.0f;
+    if (__any(need_log)) lx = need_log ? __logf(xc / h->ia) : 0.0f;
+    const float slope_th = (float)(h->dsb / h->loglen);
+    const float sth32 = (float)h->sa + slope_th * lx;
+    const float band0 = 2e-6f * fabsf(sth32) + 4e-6f * fabsf(slope_th) + 1e-30f;
+    const float s2 = rn * rn;
+    const float abs_s = fabsf(s);
+    const bool force_exact = !(guard < 1e300);
+    const uint32_t valid = dn->valid;
+    uint32_t jfast = 0, unsure_mask = 0;
+    rf2 dB[GP];  // (d[2p+1], d[2p+2])
+#pragma unroll
+    for (int p = 0; p < GP; ++p) dB[p] = rf2{dA[p].y, (p + 1 < GP) ? dA[p + 1].x : 0.0f};
+#pragma unroll
+    for (int ip = 0; ip < GP; ++ip) {
+#pragma unroll
+        for (int di = 1; di <= 2; ++di) {
+            const int ps = 2 * ip + di - 1;
+            const uint32_t vbits = (valid >> (2 * ps)) & 3u;
+            if (vbits == 0) continue;  // plan-uniform
+            const rf2 hi = (di == 1) ? dB[ip] : ((ip + 1 < GP) ? dA[ip + 1] : rf2{0.0f, 0.0f});
+            const rf2 lo = dA[ip];
+            const RipDensePair r = dn->pairs[ps];
+            const rf2 num = hi - lo;
+            const rf2 q = num * rf2{r.inv_dt[0], r.inv_dt[1]};
+            const rf2 delta = q - rf2{s, s};
+            const rf2 as2 = rf2{r.A[0], r.A[1]} * s2;
+            const rf2 var = __builtin_elementwise_fma(rf2{r.B[0], r.B[1]}, rf2{dv, dv}, as2);
+            const rf2 rs = {__frsqrt_rn(var.x), __frsqrt_rn(var.y)};
+            const rf2 sm = delta * rs;
+            const rf2 asm_ = __builtin_elementwise_abs(sm);
+            const rf2 aq = __builtin_elementwise_abs(q) + abs_s;
+            const rf2 band = (asm_ * rf2{r.relerr[0], r.relerr[1]} + band0) + (aq * rs) * 4e-7f;
+            const rf2 dist = __builtin_elementwise_abs(sm - sth32);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (!((vbits >> e) & 1u)) continue;  // plan-uniform
+                const bool hit = (e ? sm.y : sm.x) > sth32;
+                const bool unsure = force_exact || !((e ? dist.y : dist.x) > (e ? band.y : band.x));
+                if (hit) jfast |= 1u << (2 * ps + e);
+                if (unsure) unsure_mask |= 1u << (2 * ps + e);
+            }
+        }
+    }
+    // differences whose approximate significance is within its error band of the threshold (or NaN): redo them in
+    // the reference's exact operation order.  Rare; one wave-uniform test covers the whole pixel.
+    if (__any(unsure_mask != 0 && flag)) {
+        const float lxe = log_f32(xc / h->ia);
+        const double sth = h->sa + h->dsb * ((double)lxe / h->loglen);
+        for (int bit = 0; bit < 4 * GP; ++bit) {
+            if (!__any((unsure_mask >> bit) & 1u)) continue;
+            if ((unsure_mask >> bit) & 1u) {
+                const RipDiff rd = df[dn->kidx[bit]];
+                // operands d[i], d[j] from the pairs (runtime indices only on this rare path)
+                float di_ = 0.0f, dj_ = 0.0f;
+#pragma unroll
+                for (int p = 0; p < GP; ++p) {
+                    di_ = (rd.i == 2 * p) ? dA[p].x : (rd.i == 2 * p + 1) ? dA[p].y : di_;
+                    dj_ = (rd.j == 2 * p) ? dA[p].x : (rd.j == 2 * p + 1) ? dA[p].y : dj_;
+                }
+                const float de = (dj_ - di_) / rd.dt - s;
+                const double varx = exact_variance<float>(h, kv, G, rd.i, rd.j, rd.dt, dv, s2);
+                const float smx = de / (float)sqrt(varx);
+                const bool hitx = (double)smx > sth;
+                jfast = hitx ? (jfast | (1u << bit)) : (jfast & ~(1u << bit));
+            }
+        }
+    }
+    // bit 2*ps+e of jfast -> JUMP_DET on group i = 2*(ps/2) + e
+    if (flag) {
+#pragma unroll
+        for (int ip = 0; ip < GP; ++ip) {
+            const uint32_t four = (jfast >> (4 * ip)) & 15u;  // (di=1: e0,e1), (di=2: e0,e1)
+            if ((four & 1u) || (four & 4u)) jmask |= 1u << (2 * ip);
+            if ((four & 2u) || (four & 8u)) jmask |= 1u << (2 * ip + 1);
+        }
+    }
+}

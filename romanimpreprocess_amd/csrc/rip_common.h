@@ -49,7 +49,19 @@ struct RipPlanHeader {
     float tbar[RIP_MAX_GROUPS], tau[RIP_MAX_GROUPS], nreads[RIP_MAX_GROUPS];  // nreads as f32(N)
 };
 
-// layout of the device plan buffer: header | variants[nvariants] | K floats | diffs
+// Dense, compile-time-indexable view of the FULL-ramp variant for the register-resident fit
+// (fit_full_regs): pair slot ps = 2*(i/2) + (di-1) holds the differences (i, i+di) and (i+1, i+1+di), i even.
+struct RipDensePair {
+    float inv_dt[2], A[2], B[2], relerr[2];  // per element e: difference (i+e, i+e+di)
+};
+struct RipDense {
+    uint32_t valid;                    // bit 2*ps + e: that difference is tested (fitting.py:225-229)
+    int32_t kidx[2 * RIP_MAX_GROUPS];  // [2*ps + e] index into the compact diff table (exact path)
+    float K2[RIP_MAX_GROUPS];          // full-ramp weights
+    RipDensePair pairs[RIP_MAX_GROUPS];
+};
+
+// layout of the device plan buffer: header | variants[nvariants] | K floats | diffs | dense
 struct RipPlan {
     RipPlanHeader h;
     std::vector<RipVariant> variants;
@@ -59,6 +71,8 @@ struct RipPlan {
     const RipVariant *d_variants = nullptr;
     const float *d_k = nullptr;
     const RipDiff *d_diffs = nullptr;
+    const RipDense *d_dense = nullptr;
+    RipDense dense;
     size_t bytes = 0;
 };
 
@@ -185,6 +199,7 @@ struct ChainArgs {
     uint32_t *pdq_out;
     uint8_t *gdq_out;  // may be null
     float *cube_out;   // may be null
+    const RipDense *dense;        // RipPlan::d_dense
     unsigned long long *dbg_buf;  // CH_STAMP builds only: per-wave phase cycle sums
     int dbg;           // timing experiments only (rip_set_option "chain_dbg"): skips phases, results invalid
     int ny, nx, nb, ngrp;
