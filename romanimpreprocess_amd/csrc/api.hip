@@ -119,6 +119,13 @@ int rip_ctx_create(int device_id, rip_ctx **out) {
         delete ctx;
         return rip_fail(nullptr, RIP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) ctx->stream2 = nullptr;
+    for (int i = 0; i < 2 && ctx->stream2; ++i)
+        if (hipEventCreateWithFlags(&ctx->ev_tab[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming) != hipSuccess) {
+            ctx->use_overlap = false;
+        }
+    if (!ctx->stream2) ctx->use_overlap = false;
     *out = ctx;
     return RIP_OK;
 }
@@ -136,10 +143,15 @@ void rip_ctx_destroy(rip_ctx *ctx) {
     for (int i = 0; i < 8; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) {
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamDestroy(ctx->stream2);
+    }
     delete ctx;
 }
 
 int rip_synchronize(rip_ctx *ctx) {
+    if (ctx->stream2) RIP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RIP_OK;
 }
@@ -151,6 +163,10 @@ void rip_set_guard_band(double rel) { rip_guard_band = rel; }
 int rip_set_option(rip_ctx *ctx, const char *name, int value) {
     if (name && strcmp(name, "fused") == 0) {
         ctx->use_fused = value != 0;
+        return RIP_OK;
+    }
+    if (name && strcmp(name, "overlap") == 0) {
+        ctx->use_overlap = value != 0 && ctx->stream2 != nullptr;
         return RIP_OK;
     }
     if (name && strcmp(name, "chain_dbg") == 0) {
@@ -186,13 +202,18 @@ int rip_profile_enable(rip_ctx *ctx, int on) {
 int rip_profile_read(rip_ctx *ctx, double out_ms[4], int *ncalls) {
     RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 4; ++i) out_ms[i] = 0.0;
-    const size_t n = ctx->prof_events.size() / 5;
-    for (size_t c = 0; c < n; ++c)
-        for (int i = 0; i < 4; ++i) {
-            float ms = 0.f;
-            RIP_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_events[c * 5 + i], ctx->prof_events[c * 5 + i + 1]));
+    if (ctx->stream2) RIP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    const size_t n = ctx->prof_events.size() / 6;  // per call: pre-pass begin/end, then 4 marks on the main stream
+    for (size_t c = 0; c < n; ++c) {
+        const hipEvent_t *e = &ctx->prof_events[c * 6];
+        float ms = 0.f;
+        RIP_HIP(ctx, hipEventElapsedTime(&ms, e[0], e[1]));
+        out_ms[0] += ms;
+        for (int i = 1; i < 4; ++i) {
+            RIP_HIP(ctx, hipEventElapsedTime(&ms, e[1 + i], e[2 + i]));
             out_ms[i] += ms;
         }
+    }
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     ctx->prof_events.clear();
     if (ncalls) *ncalls = (int)n;
@@ -616,19 +637,46 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         (void)hipEventRecord(e, ctx->stream);
         ctx->prof_events.push_back(e);
     };
-    mark();
-    // ---- reference-pixel tables
+    // ---- reference-pixel tables.  With device-resident inputs the pre-pass runs on a second stream so that it
+    // overlaps the previous ramp's main kernel; the tables are double-buffered by call parity:
+    //   stream2: wait(main kernels of call n-2 done) -> pre-pass -> ev_tab[p]
+    //   stream : wait(ev_tab[p]) -> main kernels -> ev_done[p]
+    const size_t tab_bytes = ((size_t)G * ny * 8 + (size_t)G * nch * 16 + 255) / 256 * 256;
+    char *ws3 = (do_ref || (do_fit && (stages & RIP_STAGE_FLAT) && c.has_flat && d_area))
+                    ? (char *)rip_ws(ctx, 3, 2 * tab_bytes + npix * 4 + 512)
+                    : nullptr;
+    const int par = ctx->parity;
+    const bool overlap = do_ref && !host && ctx->use_overlap;
     double *rowcorr = nullptr, *lines = nullptr;
     if (do_ref) {
         if (nx % RIP_CW) return rip_fail(ctx, RIP_EINVAL, "calibrate: nx=%d is not a multiple of 128", nx);
-        char *w = (char *)rip_ws(ctx, 3, (size_t)G * ny * 8 + (size_t)G * nch * 16 + npix * 4 + 512);
-        if (!w) return RIP_ENOMEM;
-        rowcorr = (double *)w;
+        if (!ws3) return RIP_ENOMEM;
+        if (c.has_amp33 && !d_a33) return rip_fail(ctx, RIP_EINVAL, "calibrate: the read file has amp33 but the ramp has none");
+        rowcorr = (double *)(ws3 + (size_t)par * tab_bytes);
         lines = rowcorr + (size_t)G * ny;
         RefpixArgs ra{d_data, in->data_dtype, c.dark_data, c.has_amp33 ? d_a33 : nullptr, c.amp33_med, c.refout_slope,
                       d_lines_ovr, rowcorr, lines, ny, nx, G};
-        if (c.has_amp33 && !d_a33) return rip_fail(ctx, RIP_EINVAL, "calibrate: the read file has amp33 but the ramp has none");
-        if ((rc = rip_launch_refpix_prepass(ctx, ra))) return rc;
+        hipStream_t main_stream = ctx->stream;
+        if (overlap) {
+            if (ctx->ev_done_valid[par]) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_done[par], 0));
+            ctx->stream = ctx->stream2;
+        }
+        mark();
+        rc = rip_launch_refpix_prepass(ctx, ra);
+        mark();
+        if (overlap) {
+            if (!rc) {
+                hipError_t e1 = hipEventRecord(ctx->ev_tab[par], ctx->stream2);
+                ctx->stream = main_stream;
+                RIP_HIP(ctx, e1);
+                RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tab[par], 0));
+            }
+            ctx->stream = main_stream;
+        }
+        if (rc) return rc;
+    } else {
+        mark();
+        mark();
     }
     mark();
     // flat plane the slope is divided by: f32(flat_dn / AreaFactor)  (gen_cal_image.py:622)
@@ -636,9 +684,8 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     if (do_fit && (stages & RIP_STAGE_FLAT) && c.has_flat) {
         flat_plane = c.flat_dn;
         if (d_area) {
-            float *fl = (float *)rip_ws(ctx, 3, (size_t)G * ny * 8 + (size_t)G * nch * 16 + npix * 4 + 512);
-            if (!fl) return RIP_ENOMEM;
-            fl = (float *)((char *)fl + ((size_t)G * ny * 8 + (size_t)G * nch * 16 + 255) / 256 * 256);
+            if (!ws3) return RIP_ENOMEM;
+            float *fl = (float *)(ws3 + 2 * tab_bytes);
             if ((rc = rip_launch_flat_area(ctx, c.flat_dn, d_area, fl, npix))) return rc;
             flat_plane = fl;
         }

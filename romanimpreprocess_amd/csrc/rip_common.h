@@ -109,6 +109,11 @@ struct RipCal {
 struct rip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // reference-pixel pre-pass of the NEXT ramp (device-resident inputs)
+    hipEvent_t ev_tab[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool ev_done_valid[2] = {false, false};
+    int parity = 0;
+    bool use_overlap = true;
     std::string err;
     std::vector<RipCal> cals;
     std::vector<RipPlan *> plans;
@@ -118,7 +123,7 @@ struct rip_ctx {
     unsigned long long *chain_dbg_buf = nullptr;  // 4096 waves x 6 phases (diagnostic builds)
     bool use_fused = true;  // rip_set_option("fused", 0) forces the stage-by-stage kernels
     bool prof = false;
-    std::vector<hipEvent_t> prof_events;  // 5 per rip_calibrate call
+    std::vector<hipEvent_t> prof_events;  // 6 per rip_calibrate call
     void *ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t ws_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
