@@ -165,6 +165,10 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value) {
         ctx->use_fused = value != 0;
         return RIP_OK;
     }
+    if (name && strcmp(name, "chain2") == 0) {
+        ctx->use_chain2 = value != 0;
+        return RIP_OK;
+    }
     if (name && strcmp(name, "overlap") == 0) {
         ctx->use_overlap = value != 0 && ctx->stream2 != nullptr;
         return RIP_OK;

@@ -107,6 +107,45 @@ __device__ __forceinline__ V fwd_rows(const SV *rm, const SV *r0, const SV *rp, 
     return acc;
 }
 
+// fwd_rows for NB pairs of groups at once: all 9*NB LDS reads are issued first (one exposed LDS latency per
+// batch instead of one per term), then NB independent accumulation chains run interleaved (each chain keeps the
+// reference's term order).  ctr[b] returns the centre value r0[b][t].
+template <int NB, bool ALL>
+__device__ __forceinline__ void fwd_rows_batch(const f2 *const (&rm)[NB], const f2 *const (&r0)[NB],
+                                               const f2 *const (&rp)[NB], int t, const float (&kk)[9], unsigned valid,
+                                               f2 (&f)[NB], f2 (&ctr)[NB]) {
+    f2 v[NB][9];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        v[b][5] = rm[b][t - 1];
+        v[b][1] = rm[b][t];
+        v[b][6] = rm[b][t + 1];
+        v[b][3] = r0[b][t - 1];
+        v[b][0] = r0[b][t];
+        v[b][4] = r0[b][t + 1];
+        v[b][7] = rp[b][t - 1];
+        v[b][2] = rp[b][t];
+        v[b][8] = rp[b][t + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f2 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = v[b][0] * kk[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const f2 p = v[b][k] * kk[k];
+            acc[b] = (ALL || ((valid >> k) & 1u)) ? acc[b] + p : acc[b];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        f[b] = acc[b];
+        ctr[b] = v[b][0];
+    }
+}
+
 // load through a uniform base pointer + 32-bit per-lane BYTE offset (global_load ... v_off, s[base] form: no 64-bit
 // address arithmetic per load); every array addressed this way is smaller than 4 GiB
 template <typename T>
@@ -200,6 +239,7 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
     for (int k = 0; k < 9; ++k) kA[k] = kB[k] = kC[k] = (KT)0;
     uint32_t d0 = 0, d1 = 0, d2 = 0;
 
+    const RipVariant v0 = rip_load_variant(vars, 0);
 #ifdef CH_STAMP
     unsigned long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tl_ = __builtin_amdgcn_s_memtime();
@@ -382,7 +422,7 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                                             guard, pdq_in, a.gdq_out ? a.gdq_out + pe : nullptr, npix, s, er, ep, pdq);
             } else {
                 uint32_t jmask = 0;
-                fit_full_pk<G>(dpair, h, vars[0], a.dense, kvals + vars[0].k_ofs, diffs + vars[0].diff_ofs, e_gain, e_read,
+                fit_full_pk<G>(dpair, h, v0, a.dense, kvals + v0.k_ofs, diffs + v0.diff_ofs, e_gain, e_read,
                                act, guard, s, er, ep, jmask);
                 // flag propagation (fitting.py:339-353) without saturation
                 uint32_t orq = 0;

@@ -1,6 +1,11 @@
-// Instantiations of the fused chain kernel for 4 Legendre planes (see chain_kernel.h).
-#include "chain_kernel.h"
+// Instantiations of the fused chain kernels for 4 Legendre planes (chain_kernel.h, chain2_kernel.h).
+#include "chain2_kernel.h"
 
 int rip_launch_chain_np4(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int k_dtype) {
+    // wave-specialised kernel for the common case (f32 ipc4d, 6 or 8 groups); general fused kernel otherwise
+    if (k_dtype == RIP_F32 && ctx->use_chain2) {
+        if (a.ngrp == 8) return launch_chain2<4, 8>(ctx, plan, a);
+        if (a.ngrp == 6) return launch_chain2<4, 6>(ctx, plan, a);
+    }
     return launch_chain_np<4>(ctx, plan, a, k_dtype);
 }

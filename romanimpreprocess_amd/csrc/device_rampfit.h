@@ -5,6 +5,27 @@
 #pragma once
 #include "rip_common.h"
 
+// Plan tables (header, variants, weights, difference tables) never change while a kernel runs.  Reading them
+// through the constant address space lets the compiler use scalar loads (s_load, lgkmcnt) for these wave-uniform
+// values even after the kernel has stored to global memory; as plain global pointers they become vector loads
+// followed by s_waitcnt vmcnt(0), which also waits for every prefetched pixel load in flight.
+#define RIP_K __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const RIP_K T *rip_k(const T *p) {
+    return (const RIP_K T *)p;
+}
+#define KLD(x) (*rip_k(&(x)))
+__device__ __forceinline__ RipVariant rip_load_variant(const RipVariant *vars, int i) {
+    RipVariant v;
+    v.g = KLD(vars[i].g);
+    v.ndiff = KLD(vars[i].ndiff);
+    v.diff_ofs = KLD(vars[i].diff_ofs);
+    v.k_ofs = KLD(vars[i].k_ofs);
+    v.coef = KLD(vars[i].coef);
+    v.rfac = KLD(vars[i].rfac);
+    return v;
+}
+
 __device__ __forceinline__ float log_f32(float x) {
     // np.log on an f32 array.  Evaluated in f64 and rounded: correctly rounded f32 logarithm.
     // (numpy's AVX512F/AVX2 f32 log differs from the correctly rounded value by <= 2 ulp on ~4% of
@@ -211,7 +232,7 @@ __device__ __forceinline__ void fit_full_regs(const float (&d)[G], const RipPlan
 #pragma unroll
     for (int t = 0; t < G; ++t) {
         const float diff = d[t] - d1;
-        const float prod = kv[t] * diff;
+        const float prod = KLD(kv[t]) * diff;
         s = s + prod;
     }
     const float gc = clip2<float>(gain, 1e-4f, 1e4f);
@@ -222,17 +243,17 @@ __device__ __forceinline__ void fit_full_regs(const float (&d)[G], const RipPlan
     ep_out = sqrtf(pv);
     if (!__any(flag)) return;
 
-    const float xc = clip2<float>(s, h->ia, h->ib);
-    const bool need_log = xc != h->ia;  // log(1) = 0 exactly otherwise
+    const float xc = clip2<float>(s, KLD(h->ia), KLD(h->ib));
+    const bool need_log = xc != KLD(h->ia);  // log(1) = 0 exactly otherwise
     float lx = 0.0f;
-    if (__any(need_log)) lx = need_log ? __logf(xc / h->ia) : 0.0f;
-    const float slope_th = (float)(h->dsb / h->loglen);
-    const float sth32 = (float)h->sa + slope_th * lx;
+    if (__any(need_log)) lx = need_log ? __logf(xc / KLD(h->ia)) : 0.0f;
+    const float slope_th = (float)(KLD(h->dsb) / KLD(h->loglen));
+    const float sth32 = (float)KLD(h->sa) + slope_th * lx;
     // error band of the approximate comparison (see DESIGN.md "jump significance fast path")
     const float band0 = 2e-6f * fabsf(sth32) + 4e-6f * fabsf(slope_th) + 1e-30f;
     const float s2 = rn * rn;
     const bool force_exact = !(guard < 1e300);
-    const int start = h->start;
+    const int start = KLD(h->start);
     int k = 0;
 #pragma unroll
     for (int i = 0; i < G - 1; ++i) {
@@ -242,7 +263,10 @@ __device__ __forceinline__ void fit_full_regs(const float (&d)[G], const RipPlan
             const int j = i + di;
             if (j > G - 1) continue;
             if (di == 2 && (i == G - 2 || G - 1 - start == 2)) continue;
-            const RipDiff r = df[k++];
+            RipDiff r;
+            r.i = KLD(df[k].i), r.j = KLD(df[k].j), r.dt = KLD(df[k].dt), r.A = KLD(df[k].A), r.B = KLD(df[k].B);
+            r.inv_dt = KLD(df[k].inv_dt), r.relerr = KLD(df[k].relerr);
+            ++k;
             const float num = d[j] - d[i];
             const float q = num * r.inv_dt;
             const float delta = q - s;
@@ -254,8 +278,8 @@ __device__ __forceinline__ void fit_full_regs(const float (&d)[G], const RipPlan
             const bool unsure = force_exact || !(fabsf(sm - sth32) > band);
             if (__any(unsure && flag)) {
                 if (unsure) {
-                    const float lxe = log_f32(xc / h->ia);
-                    const double sth = h->sa + h->dsb * ((double)lxe / h->loglen);
+                    const float lxe = log_f32(xc / KLD(h->ia));
+                    const double sth = KLD(h->sa) + KLD(h->dsb) * ((double)lxe / KLD(h->loglen));
                     const float de = num / r.dt - s;
                     const double var = exact_variance<float>(h, kv, G, r.i, r.j, r.dt, dv, s2);
                     const float sme = de / (float)sqrt(var);
@@ -287,7 +311,7 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
 #pragma unroll
     for (int p = 0; p < GP; ++p) {
         const rf2 diff = dA[p] - d11;
-        const rf2 k2 = {dn->K2[2 * p], dn->K2[2 * p + 1]};
+        const rf2 k2 = {KLD(dn->K2[2 * p]), KLD(dn->K2[2 * p + 1])};
         const rf2 prod = k2 * diff;
         s = s + prod.x;
         s = s + prod.y;
@@ -300,17 +324,17 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
     ep_out = sqrtf(pv);
     if (!__any(flag)) return;
 
-    const float xc = clip2<float>(s, h->ia, h->ib);
-    const bool need_log = xc != h->ia;  // log(1) = 0 exactly otherwise
+    const float xc = clip2<float>(s, KLD(h->ia), KLD(h->ib));
+    const bool need_log = xc != KLD(h->ia);  // log(1) = 0 exactly otherwise
     float lx = 0.0f;
-    if (__any(need_log)) lx = need_log ? __logf(xc / h->ia) : 0.0f;
-    const float slope_th = (float)(h->dsb / h->loglen);
-    const float sth32 = (float)h->sa + slope_th * lx;
+    if (__any(need_log)) lx = need_log ? __logf(xc / KLD(h->ia)) : 0.0f;
+    const float slope_th = (float)(KLD(h->dsb) / KLD(h->loglen));
+    const float sth32 = (float)KLD(h->sa) + slope_th * lx;
     const float band0 = 2e-6f * fabsf(sth32) + 4e-6f * fabsf(slope_th) + 1e-30f;
     const float s2 = rn * rn;
     const float abs_s = fabsf(s);
     const bool force_exact = !(guard < 1e300);
-    const uint32_t valid = dn->valid;
+    const uint32_t valid = KLD(dn->valid);
     uint32_t jfast = 0, unsure_mask = 0;
     rf2 dB[GP];  // (d[2p+1], d[2p+2])
 #pragma unroll
@@ -324,7 +348,14 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
             if (vbits == 0) continue;  // plan-uniform
             const rf2 hi = (di == 1) ? dB[ip] : ((ip + 1 < GP) ? dA[ip + 1] : rf2{0.0f, 0.0f});
             const rf2 lo = dA[ip];
-            const RipDensePair r = dn->pairs[ps];
+            RipDensePair r;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                r.inv_dt[e] = KLD(dn->pairs[ps].inv_dt[e]);
+                r.A[e] = KLD(dn->pairs[ps].A[e]);
+                r.B[e] = KLD(dn->pairs[ps].B[e]);
+                r.relerr[e] = KLD(dn->pairs[ps].relerr[e]);
+            }
             const rf2 num = hi - lo;
             const rf2 q = num * rf2{r.inv_dt[0], r.inv_dt[1]};
             const rf2 delta = q - rf2{s, s};
@@ -349,12 +380,12 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
     // differences whose approximate significance is within its error band of the threshold (or NaN): redo them in
     // the reference's exact operation order.  Rare; one wave-uniform test covers the whole pixel.
     if (__any(unsure_mask != 0 && flag)) {
-        const float lxe = log_f32(xc / h->ia);
-        const double sth = h->sa + h->dsb * ((double)lxe / h->loglen);
+        const float lxe = log_f32(xc / KLD(h->ia));
+        const double sth = KLD(h->sa) + KLD(h->dsb) * ((double)lxe / KLD(h->loglen));
         for (int bit = 0; bit < 4 * GP; ++bit) {
             if (!__any((unsure_mask >> bit) & 1u)) continue;
             if ((unsure_mask >> bit) & 1u) {
-                const RipDiff rd = df[dn->kidx[bit]];
+                const RipDiff rd = df[KLD(dn->kidx[bit])];
                 // operands d[i], d[j] from the pairs (runtime indices only on this rare path)
                 float di_ = 0.0f, dj_ = 0.0f;
 #pragma unroll
@@ -379,4 +410,60 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
             if ((four & 2u) || (four & 8u)) jmask |= 1u << (2 * ip + 1);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Saturation-truncated refits (fitting.py:326-337) with the ramp in registers: compile-time recursion over the
+// truncation length GV = G-1 ... 3.  A layer is evaluated only when some lane of the wave first saturates at
+// group GV (wave-uniform test); results and jump flags replace the running ones for those lanes, in the
+// reference's order (descending GV).
+template <int G, int GV>
+__device__ __forceinline__ void trunc_layers(const float (&d)[G], const uint32_t (&qe)[G],
+                                             const RipPlanHeader *__restrict__ h, const RipVariant *__restrict__ vars,
+                                             const float *__restrict__ kvals, const RipDiff *__restrict__ diffs,
+                                             float gain, float rn, bool act, double guard, float &s, float &er,
+                                             float &ep, uint32_t &jmask) {
+    if constexpr (GV >= 3) {
+        if (GV >= 3 + KLD(h->start)) {
+            const bool layer = ((qe[GV] & ~qe[GV - 1]) & DQ_SATURATED) != 0;
+            if (__any(layer)) {
+                float dt[GV];
+#pragma unroll
+                for (int t = 0; t < GV; ++t) dt[t] = d[t];
+                const RipVariant v = rip_load_variant(vars, G - GV);
+                float s_, er_, ep_;
+                uint32_t jm = 0;
+                fit_full_regs<GV>(dt, h, v, kvals + v.k_ofs, diffs + v.diff_ofs, gain, rn, act, guard, s_, er_, ep_, jm);
+                if (layer) {
+                    s = s_;
+                    er = er_;
+                    ep = ep_;
+                    jmask |= jm;
+                }
+            }
+        }
+        trunc_layers<G, GV - 1>(d, qe, h, vars, kvals, diffs, gain, rn, act, guard, s, er, ep, jmask);
+    }
+}
+
+// flag propagation of fitting.py:339-353 from registers; writes the updated group flags when gdq_out != null
+template <int G>
+__device__ __forceinline__ uint32_t propagate_flags(const uint32_t (&qe)[G], uint32_t jmask, int start, uint32_t pdq_in,
+                                                    uint8_t *gdq_out, unsigned gstride) {
+    uint32_t or_unsat = 0, any_sat = 0;
+    bool all_dnu = true;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const uint32_t rq = qe[g] | (((jmask >> g) & 1u) ? DQ_JUMP_DET : 0u);
+        if (gdq_out) gdq_out[(size_t)g * gstride] = (uint8_t)rq;
+        if ((rq & DQ_SATURATED) == 0) or_unsat |= rq;
+        any_sat |= rq & DQ_SATURATED;
+        all_dnu = all_dnu && ((rq & DQ_DO_NOT_USE) != 0);
+    }
+    uint32_t pdq2 = or_unsat & ~DQ_DO_NOT_USE;
+    if (all_dnu) pdq2 |= DQ_DO_NOT_USE;
+    const uint32_t q_early = start ? qe[(G > 2) ? 2 : G - 1] : qe[1];  // rdq[1 + start]
+    if (q_early & DQ_SATURATED) pdq2 |= DQ_DO_NOT_USE;
+    pdq2 |= any_sat;
+    return (pdq_in & DQ_REFERENCE_PIXEL) ? pdq_in : (pdq_in | pdq2);
 }

@@ -114,6 +114,7 @@ struct rip_ctx {
     bool ev_done_valid[2] = {false, false};
     int parity = 0;
     bool use_overlap = true;
+    bool use_chain2 = true;  // wave-specialised fused kernel where it applies
     std::string err;
     std::vector<RipCal> cals;
     std::vector<RipPlan *> plans;

@@ -12,6 +12,7 @@ rp = synth.READ_PATTERN_8
 N = 4096
 cal, ramp = synth.make_tiled_inputs(N, N, read_pattern=rp, p_order=8, seed=1, strip_rows=64)
 cb = pipeline.Calibrator(device=0)
+cb.ctx.set_option("chain2", int(os.environ.get("CHAIN2", "1")))
 cb.load_caldir(0, cal)
 pid, meta = cb.plan_for(rp, ramp["frame_time"])
 dev = torch.device("cuda", 0)

@@ -42,6 +42,10 @@ def call():
                         o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), None if NOGDQ else o[4].data_ptr())
 
 
+CHAIN2 = bool(int(os.environ.get("CHAIN2", "1")))
+cb.ctx.set_option("chain2", int(CHAIN2))
+names2 = ["ingest A lin", "ingest barrier 1", "ingest C + loads", "ingest barrier 2", "fit O2", "fit barrier 1",
+          "fit F", "fit barrier 2", "-"]
 names = ["P issue loads", "C O1", "barrier 1", "E rest (finish+stores)", "A lin", "barrier 2", "E: O2", "E: fit+flags", "wait all loads (dbg 2048)"]
 for mask in [int(x) for x in sys.argv[1:]] or [0]:
     cb.ctx.set_option("chain_dbg", mask)
@@ -54,6 +58,8 @@ for mask in [int(x) for x in sys.argv[1:]] or [0]:
     lib.rip_chain_stamps(cb.ctx.h, out)
     tot = sum(out)
     nw = 2048
+    if CHAIN2:
+        names = names2
     print(f"dbg={mask}: total cycles per wave per launch {tot/n/nw:.0f}")
     for i in range(9):
         print(f"   {names[i]:16s} {out[i]/n/nw:10.0f} cycles/wave  {100*out[i]/tot:5.1f}%  ({out[i]/n/nw/141:.0f} per step)")
