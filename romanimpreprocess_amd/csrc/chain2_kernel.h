@@ -6,21 +6,47 @@
 // 512 threads covers the same 256 columns with TWO ROLES of four waves each:
 //     ingest waves (tid < 256)   P: raw loads of row r+4            A: refpix/bias/linearity of row r+3 -> x ring
 //                                C: first IPC iterate of row r+2    (reads x rows r+1..r+3)          -> O1 ring
+//                                T: flag propagation, finish (dark rate, error split, flat), stores of row r-1
 //     fit waves    (tid >= 256)  O2: second iterate of row r / gain (reads O1 rows r-1..r+1, x row r)
-//                                F: ramp fit, flags, finish, stores of pixel (r, c)
+//                                F: ramp fit with jump detection and saturated refits of row r      -> T ring
 // so each role needs <= 128 VGPRs and a CU holds 2 workgroups = 16 waves = 4 waves/SIMD.  Per step:
-//     S1: ingest A(r+3)            | fit O2(r)            -- barrier --
-//     S2: ingest C(r+2), P(r+4)    | fit F(r), loads of row r+1
-// The x ring is 4 rows deep (rows r..r+3 are live during a step), the O1 ring 3 rows (C writes row r+2 into the
-// slot of row r-1, which O2(r) finished reading before the barrier).  What the fit waves need from the ingest of
-// the same pixel three steps earlier (linearity dq, the 8 groupdq bytes, gain) travels through small LDS rings.
+//     S1: ingest A(r+3)                     | fit O2(r)                 -- barrier --
+//     S2: ingest P(r+4), C(r+2), T(r-1)     | fit F(r), loads of row r+1 -- barrier --
+// (the split keeps both roles busy for about the same time in both halves; see profiles/).  The x ring is 4 rows
+// deep (rows r..r+3 are live during a step), the O1 ring 3 rows (C writes row r+2 into the slot of row r-1, which
+// O2(r) finished reading before the barrier), the T ring (slope, two errors, jump mask) 2 rows.  The linearity dq
+// and the 8 groupdq bytes of a pixel travel from its ingest to its fit and its tail through 4-row rings.
 // Saturated pixels are refitted from registers (trunc_layers), so no per-pixel ramp staging in LDS.
 #pragma once
 #include "chain_kernel.h"
 
+#ifndef C2_COLS
 #define C2_COLS 256
-#define C2_THREADS 512
+#endif
+#define C2_THREADS (2 * C2_COLS)
+#ifdef CH_STAMP
+#define C2_DRAIN()                                \
+    if (a.dbg & 2048) {                           \
+        __builtin_amdgcn_s_waitcnt(0);            \
+    }
+#else
+#define C2_DRAIN()
+#endif
+#ifdef C2_NOBARRIER  // timing experiment only (results are wrong)
+#define C2_SYNC()
+#else
+#define C2_SYNC() __syncthreads()
+#endif
 #define C2_OUTW (C2_COLS - 4)
+
+// Returns x, opaque to the optimiser: used on loop-invariant per-lane offsets right before a global access so that
+// the zero-extension stays next to the address add and instruction selection can use the
+// `global_load v, v_off32, s[base:base+1]` form (with the offset hoisted out of the loop it falls back to a 64-bit
+// vector add per access).  Emits no instruction.
+__device__ __forceinline__ unsigned c2_opaque(unsigned x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 
 template <int NP, int G>
 __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
@@ -34,8 +60,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
     f2 *O12 = X2 + GP * 4 * C2_COLS;                                // [GP][3][C2_COLS]  first Neumann iterate
     uint32_t *DQ = reinterpret_cast<uint32_t *>(O12 + GP * 3 * C2_COLS);  // [4][C2_COLS] linearity dq of the row
     uint2 *QS = reinterpret_cast<uint2 *>(DQ + 4 * C2_COLS);       // [4][C2_COLS] groupdq bytes of the pixel
-    float *GS = reinterpret_cast<float *>(QS + 4 * C2_COLS);        // [4][C2_COLS] gain
-    double *LN = reinterpret_cast<double *>(GS + 4 * C2_COLS);      // [3][G][2] channel lines of this strip
+    float4 *TR = reinterpret_cast<float4 *>(QS + 4 * C2_COLS);      // [2][C2_COLS] slope, err_read, err_poisson, jump mask
+    double *LN = reinterpret_cast<double *>(TR + 2 * C2_COLS);      // [3][G][2] channel lines of this strip
 
     const int tid = threadIdx.x;
     const bool fit_role = tid >= C2_COLS;
@@ -80,21 +106,58 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
     }
     __syncthreads();
 
-    // coefficient loader: raw loads at clamped source positions + validity mask for destination (y, c)
-    auto load_k = [&](int y, bool want, float (&kk)[9]) -> unsigned {
-        const bool dest_ok = want && (y >= ay0 && y < ay1 && c >= ax0 && c < ax1);
-        unsigned valid = 0;
+    // Addressing: every global access is (wave-uniform 64-bit base: array + plane + row, scalar ALU) + (per-lane
+    // 32-bit column offset, loop-invariant VGPR), i.e. the saddr form of global_load/store with no vector
+    // address arithmetic per access.
+    const unsigned cc4 = (unsigned)cc * 4u, cc2 = (unsigned)cc * 2u, cc1 = (unsigned)cc;
+    unsigned cx4[3];  // byte offset of the clamped source column c - dx, index dx + 1
+    unsigned colmask = 0;  // bit k: source column of term k is in the active box (and so is c)
+    {
+        bool okx[3];
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) {
+            const int sx = c - (dxi - 1);
+            okx[dxi] = sx >= ax0 && sx < ax1;
+            cx4[dxi] = (unsigned)min(max(sx, 0), nx - 1) * 4u;
+        }
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int dy = (k == 1 || k == 5 || k == 6) ? 1 : (k == 2 || k == 7 || k == 8) ? -1 : 0;
             const int dx = (k == 3 || k == 5 || k == 7) ? 1 : (k == 4 || k == 6 || k == 8) ? -1 : 0;
-            const int sy = y - dy, sx = c - dx;
-            const bool ok = dest_ok && sy >= ay0 && sy < ay1 && sx >= ax0 && sx < ax1;
-            const int syc = min(max(sy, 0), ny - 1), sxc = min(max(sx, 0), nx - 1);
-            kk[k] = ldg<float>(kern, (unsigned)(3 * (1 + dy) + (1 + dx)) * pl4 + (unsigned)(syc * nx + sxc) * 4u);
-            valid |= ok ? (1u << k) : 0u;
+            if (okx[dx + 1]) colmask |= 1u << k;
         }
-        return valid;
+        if (!col_act) colmask = 0;
+    }
+    const unsigned lane_mask = fit_role ? ((col >= 2 && col < C2_COLS - 2) ? colmask : 0u)
+                                        : ((col >= 1 && col < C2_COLS - 1) ? colmask : 0u);
+    const unsigned row4 = (unsigned)nx * 4u;  // row pitch of an f32/u32 plane; offsets within a plane fit 32 bits
+
+    // coefficient loader: raw loads at clamped source positions + validity mask for destination (y, c);
+    // `want` is wave-uniform.  Planes are walked in memory order (plane = 3*(1+dy) + (1+dx)).
+    auto load_k = [&](int y, bool want, float (&kk)[9]) -> unsigned {
+        size_t rowoff[3];
+        const unsigned ox[3] = {c2_opaque(cx4[0]), c2_opaque(cx4[1]), c2_opaque(cx4[2])};
+        bool rok[3];
+#pragma unroll
+        for (int dyi = 0; dyi < 3; ++dyi) {
+            const int sy = y - (dyi - 1);
+            rok[dyi] = sy >= ay0 && sy < ay1;
+            rowoff[dyi] = (size_t)((unsigned)min(max(sy, 0), ny - 1) * row4);
+        }
+        unsigned rowbits = 0;
+        const char *kb = reinterpret_cast<const char *>(kern);
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const int dy = p / 3 - 1, dx = p % 3 - 1;
+            // term index of (dy, dx) in the reference's order: 0 centre, 1 (1,0), 2 (-1,0), 3 (0,1), 4 (0,-1), 5 (1,1),
+            // 6 (1,-1), 7 (-1,1), 8 (-1,-1)
+            const int k = (dy == 0) ? (dx == 0 ? 0 : dx == 1 ? 3 : 4) : (dy == 1) ? (dx == 0 ? 1 : dx == 1 ? 5 : 6)
+                                                                                  : (dx == 0 ? 2 : dx == 1 ? 7 : 8);
+            kk[k] = *reinterpret_cast<const float *>(kb + rowoff[dy + 1] + ox[dx + 1]);
+            if (rok[dy + 1]) rowbits |= 1u << k;
+            kb += pl4;
+        }
+        const unsigned um = (want && y >= ay0 && y < ay1) ? rowbits : 0u;
+        return lane_mask & um;
     };
 
 #ifdef CH_STAMP
@@ -104,44 +167,115 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
     if (!fit_role) {
         // =========================================================================== ingest waves
         auto fetch_row = [&](int y, RowRegs<NP, G> &rr) {
-            const int yl = min(max(y, 0), ny - 1);
-            const unsigned p = (unsigned)(yl * nx + cc);
-            // running byte offsets (one v_add per load, one SGPR stride) instead of per-plane constants: keeps the
-            // scalar register file free of ~40 loop-invariant offsets
-            unsigned o4 = p * 4u;
+            const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
+            const unsigned o4 = c2_opaque(cc4), o2 = c2_opaque(cc2), o1 = c2_opaque(cc1);
+            const char *pb = reinterpret_cast<const char *>(planes) + (size_t)(yl * row4);  // running plane base (scalar)
 #pragma unroll
             for (int L = 0; L < NP; ++L) {
-                rr.cf[L] = ldg<float>(planes, o4);
-                o4 += pl4;
+                rr.cf[L] = *reinterpret_cast<const float *>(pb + o4);
+                pb += pl4;
             }
-            rr.smin = ldg<float>(planes, o4);
-            o4 += pl4;
-            rr.smax = ldg<float>(planes, o4);
-            o4 += pl4;
-            rr.sref = ldg<float>(planes, o4);
-            o4 += pl4;
-            rr.dq = ldg<uint32_t>(planes, o4);
-            o4 += pl4;
-            rr.gain = ldg<float>(planes, o4);
-            unsigned g4 = p * 4u, g2 = p * 2u, g1 = p;
+            rr.smin = *reinterpret_cast<const float *>(pb + o4);
+            pb += pl4;
+            rr.smax = *reinterpret_cast<const float *>(pb + o4);
+            pb += pl4;
+            rr.sref = *reinterpret_cast<const float *>(pb + o4);
+            pb += pl4;
+            rr.dq = *reinterpret_cast<const uint32_t *>(pb + o4);
+            pb += pl4;
+            rr.gain = *reinterpret_cast<const float *>(pb + o4);
+            const char *sb = reinterpret_cast<const char *>(d16) + (size_t)(yl * (row4 >> 1));
+            const char *qb = reinterpret_cast<const char *>(gdq) + (size_t)(yl * (row4 >> 2));
+            const char *db = reinterpret_cast<const char *>(dark) + (size_t)(yl * row4);
+            const char *bb = reinterpret_cast<const char *>(bias) + (size_t)(yl * row4);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                rr.S[g] = ldg<uint16_t>(d16, g2);
-                rr.q[g] = ldg<uint8_t>(gdq, g1);
-                rr.dk[g] = ldg<float>(dark, g4);
-                rr.bs[g] = ldg<float>(bias, g4);
-                g4 += pl4;
-                g2 += pl4 >> 1;
-                g1 += npix;
+                rr.S[g] = *reinterpret_cast<const uint16_t *>(sb + o2);
+                rr.q[g] = *reinterpret_cast<const uint8_t *>(qb + o1);
+                rr.dk[g] = *reinterpret_cast<const float *>(db + o4);
+                rr.bs[g] = *reinterpret_cast<const float *>(bb + o4);
+                sb += pl4 >> 1;
+                qb += npix;
+                db += pl4;
+                bb += pl4;
             }
         };
+        // The same loads in pieces, issued between blocks of arithmetic (scheduling fences keep them there): a burst of
+        // 46 loads per wave from all waves at once saturates the CU's address unit while the vector ALUs idle.
+        auto fetch_groups = [&](int y, int g0, int g1, RowRegs<NP, G> &rr) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
+            const unsigned o4 = c2_opaque(cc4), o2 = c2_opaque(cc2), o1 = c2_opaque(cc1);
+            const char *sb = reinterpret_cast<const char *>(d16) + (size_t)(yl * (row4 >> 1)) + (size_t)g0 * (pl4 >> 1);
+            const char *qb = reinterpret_cast<const char *>(gdq) + (size_t)(yl * (row4 >> 2)) + (size_t)g0 * npix;
+            const char *db = reinterpret_cast<const char *>(dark) + (size_t)(yl * row4) + (size_t)g0 * pl4;
+            const char *bb = reinterpret_cast<const char *>(bias) + (size_t)(yl * row4) + (size_t)g0 * pl4;
+#pragma unroll
+            for (int g = g0; g < g1; ++g) {
+                rr.S[g] = *reinterpret_cast<const uint16_t *>(sb + o2);
+                rr.q[g] = *reinterpret_cast<const uint8_t *>(qb + o1);
+                rr.dk[g] = *reinterpret_cast<const float *>(db + o4);
+                rr.bs[g] = *reinterpret_cast<const float *>(bb + o4);
+                sb += pl4 >> 1;
+                qb += npix;
+                db += pl4;
+                bb += pl4;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // planes i0..i1-1 of [cf[0..NP-1], Smin, Smax, Sref, dq, gain]
+        auto fetch_coefs = [&](int y, int i0, int i1, RowRegs<NP, G> &rr) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
+            const unsigned o4 = c2_opaque(cc4);
+            const char *pb = reinterpret_cast<const char *>(planes) + (size_t)(yl * row4) + (size_t)i0 * pl4;
+#pragma unroll
+            for (int i = i0; i < i1; ++i) {
+                if (i < NP)
+                    rr.cf[i] = *reinterpret_cast<const float *>(pb + o4);
+                else if (i == NP)
+                    rr.smin = *reinterpret_cast<const float *>(pb + o4);
+                else if (i == NP + 1)
+                    rr.smax = *reinterpret_cast<const float *>(pb + o4);
+                else if (i == NP + 2)
+                    rr.sref = *reinterpret_cast<const float *>(pb + o4);
+                else if (i == NP + 3)
+                    rr.dq = *reinterpret_cast<const uint32_t *>(pb + o4);
+                else
+                    rr.gain = *reinterpret_cast<const float *>(pb + o4);
+                pb += pl4;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        constexpr int NCO = NP + 5;                 // coefficient-type planes per pixel
+        constexpr int CO_STEP = (NCO + GP - 1) / GP;  // issued per pair of C
         RowRegs<NP, G> rr;
         fetch_row(R0 - 2, rr);
-        for (int r = R0 - 5; r < R1; ++r) {
-            const int yi = r + 3, yc = r + 2;
+        const int start = KLD(h->start);
+        for (int r = R0 - 5; r <= R1; ++r) {
+            const int yi = r + 3, yc = r + 2, yt = r - 1;
             const bool do_a = (yi >= R0 - 2) && (yi <= R1 + 1);
             const bool do_c = (yc >= R0 - 1) && (yc <= R1);
-            // ---- S1: coefficient loads for C, then A (linearity of row yi from rr)
+            const bool emit = (yt >= R0) && (yt < R1) && col >= 2 && col < C2_COLS - 2 && col_ok;
+            // ---- S1: loads of the tail (row yt: calibration planes, and the pixel's dq words before A reuses their
+            //          ring slot), coefficient loads for C, then A (linearity of row yi from rr)
+            const unsigned ytc = (unsigned)min(max(yt, 0), ny - 1);
+            const size_t t_row4 = (size_t)(ytc * row4);             // byte offset of the tail row in an f32 plane (uniform)
+            const size_t pe_row = (size_t)(ytc * (unsigned)nx);     // element offset of the tail row
+            const char *tb = reinterpret_cast<const char *>(planes) + t_row4;
+            const unsigned t4 = c2_opaque(cc4);
+            const float e_dark = *reinterpret_cast<const float *>(tb + (size_t)(NP + 6) * pl4 + t4);
+            const uint32_t e_ff = *reinterpret_cast<const uint32_t *>(tb + (size_t)(NP + 8) * pl4 + t4);
+            const uint32_t e_pdq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(a.pdq) + t_row4 + t4);
+            // flat == null: read the gain plane instead (value unused), keeps the loads in one straight-line block
+            const char *fb = a.flat ? reinterpret_cast<const char *>(a.flat) : reinterpret_cast<const char *>(planes);
+            const float e_flat_raw = *reinterpret_cast<const float *>(fb + t_row4 + t4);
+            const float e_flat = a.flat ? e_flat_raw : 1.0f;
+            const char *ddb = a.dark_dq ? reinterpret_cast<const char *>(a.dark_dq) : reinterpret_cast<const char *>(planes);
+            const uint32_t e_ddq_raw = *reinterpret_cast<const uint32_t *>(ddb + t_row4 + t4);
+            const uint32_t e_ddq = a.dark_dq ? e_ddq_raw : 0u;
+            const uint2 t_q = QS[(yt & 3) * C2_COLS + col];
+            const uint32_t t_dq = DQ[(yt & 3) * C2_COLS + col];
             // per-row reference-pixel correction of the G groups: wave-uniform, scalar loads (constant address space)
             double rc[G];
             {
@@ -151,156 +285,214 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             }
             float kC[9];
             const unsigned vC = load_k(yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
-            if (do_a) {
-                const int slot = yi & 3;
-                f2 *xs = X2 + slot * C2_COLS + col;
-                const bool row_in = yi >= 0 && yi < ny;
-                if (!(row_in && col_ok)) {
+            CH_T(0)
+            C2_DRAIN()
+            CH_T(1)
+            const bool a_full = do_a && yi >= 0 && yi < ny;  // wave-uniform
+            // The loads of the next row are issued UNCONDITIONALLY between the blocks below (the wait-count pass is
+            // path-insensitive: a load that exists on one side of a branch only forces vmcnt(0) at later uses).
+            // All lanes compute (lanes beyond the frame edge work on the clamped column and store zeros).
+            const int slot = yi & 3;
+            f2 *xs = X2 + slot * C2_COLS + col;
+            const bool act = col_act && yi >= ay0 && yi < ay1;
+            uint32_t dq = rr.dq;
+            bool slow = false;
+            f2 zz[GP], SS[GP];
+            uint32_t w0 = 0, w1 = 0;  // the pixel's groupdq bytes, packed
+            if (a_full) {
+                const float smin = rr.smin;
+                const float span = rr.smax - smin;
+                const bool fastdiv = __all(rcp_safe(span));
+                const float rspan = 1.0f / span;
+                const double yd = (double)yi;
+                bool any_ex = false;
 #pragma unroll
-                    for (int p = 0; p < GP; ++p) xs[p * 4 * C2_COLS] = f2{0.0f, 0.0f};
-                    DQ[slot * C2_COLS + col] = 0u;
-                    QS[slot * C2_COLS + col] = uint2{0u, 0u};
-                    GS[slot * C2_COLS + col] = 1.0f;
-                } else {
-                    const bool act = col_act && yi >= ay0 && yi < ay1;
-                    const float smin = rr.smin;
-                    const float span = rr.smax - smin;
-                    const bool fastdiv = __all(rcp_safe(span));
-                    const float rspan = 1.0f / span;
-                    uint32_t dq = rr.dq;
-                    const double yd = (double)yi;
-                    bool any_ex = false;
-                    f2 zz[GP], SS[GP];
+                for (int p = 0; p < GP; ++p) {
+                    float Sv[2];
 #pragma unroll
-                    for (int p = 0; p < GP; ++p) {
-                        float Sv[2];
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const int g = 2 * p + e;
-                            float S = (float)rr.S[g];
-                            const float dk = rr.dk[g];
-                            float v = S - dk;
-                            v = (float)((double)v - rc[g]);
-                            const double *ln = LN + (chr * G + g) * 2;
-                            const double iel = ln[0] * yd + ln[1];
-                            v = (float)((double)v - iel);
-                            S = v + dk;
-                            if (act) S = S - rr.bs[g];
-                            Sv[e] = S;
-                        }
-                        const f2 S2 = {Sv[0], Sv[1]};
-                        f2 t = S2 - f2{smin, smin};
-                        t = t * 2.0f;
-                        f2 quo;
-                        if (fastdiv)
-                            quo = div_rcp2(t, span, rspan);
-                        else
-                            quo = f2{t.x / span, t.y / span};
-                        f2 z = quo + (-1.0f);
-                        if (p == 0 && a.do_not_flag_first) z.x = clip2<float>(z.x, -1.0f, 1.0f);
-                        zz[p] = z;
-                        SS[p] = S2;
-                        any_ex = any_ex || (fabsf(z.x) > 1.0f) || (fabsf(z.y) > 1.0f);
-                    }
-                    const bool slow = __any(any_ex);
-#pragma unroll
-                    for (int p = 0; p < GP; ++p) {
-                        const f2 z = zz[p];
-                        f2 phi = {rr.cf[0], rr.cf[0]};
-                        bool ex[2] = {false, false};
-                        if (!slow) {
-                            f2 pp = {1.0f, 1.0f}, pc = z;
-#pragma unroll
-                            for (int L = 1; L < NP; ++L) {
-                                const f2 term = pc * rr.cf[L];
-                                phi = phi + term;
-                                const f2 u = z * c1[L];
-                                const f2 pn = u * pc - pp * c2[L];
-                                pp = pc;
-                                pc = pn;
-                            }
-                        } else {
-                            float ph[2];
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const float ze = e ? z.y : z.x;
-                                const float az = fabsf(ze);
-                                ex[e] = az > 1.0f;
-                                const float exc = az - 1.0f;
-                                const bool neg = ze < 0.0f;
-                                float phs = rr.cf[0], pp = 1.0f, pc = ze;
-#pragma unroll
-                                for (int L = 1; L < NP; ++L) {
-                                    float ee = 1.0f + chf[L] * exc;
-                                    ee = (neg && (L & 1)) ? -ee : ee;
-                                    const float sel = ex[e] ? ee : pc;
-                                    const float term = rr.cf[L] * sel;
-                                    phs = phs + term;
-                                    const float u = c1[L] * ze;
-                                    const float pn = u * pc - c2[L] * pp;
-                                    pp = pc;
-                                    pc = pn;
-                                }
-                                ph[e] = phs;
-                            }
-                            phi = f2{ph[0], ph[1]};
-                        }
-                        const f2 fb = SS[p] - f2{rr.sref, rr.sref};
-                        float vout[2];
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const int g = 2 * p + e;
-                            vout[e] = ((dq & bad) == 0) ? (e ? phi.y : phi.x) : (e ? fb.y : fb.x);
-                            const bool first = (g == 0) && a.do_not_flag_first;
-                            if (!first && ex[e] && (rr.q[g] & DQ_SATURATED) == 0) dq |= DQ_NO_LIN_CORR;
-                        }
-                        f2 xv = {vout[0], vout[1]};
-                        if (act) xv = xv * rr.gain;
-                        xs[p * 4 * C2_COLS] = xv;
-                    }
-                    DQ[slot * C2_COLS + col] = dq;
-                    uint32_t w0 = 0, w1 = 0;
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
+                    for (int e = 0; e < 2; ++e) {
+                        const int g = 2 * p + e;
+                        float S = (float)rr.S[g];
+                        const float dk = rr.dk[g];
+                        float v = S - dk;
+                        v = (float)((double)v - rc[g]);
+                        const double *ln = LN + (chr * G + g) * 2;
+                        const double iel = ln[0] * yd + ln[1];
+                        v = (float)((double)v - iel);
+                        S = v + dk;
+                        if (act) S = S - rr.bs[g];
+                        Sv[e] = S;
                         if (g < 4)
                             w0 |= (rr.q[g] & 0xffu) << (8 * g);
                         else
                             w1 |= (rr.q[g] & 0xffu) << (8 * (g - 4));
                     }
-                    QS[slot * C2_COLS + col] = uint2{w0, w1};
-                    GS[slot * C2_COLS + col] = rr.gain;
+                    const f2 S2 = {Sv[0], Sv[1]};
+                    f2 t = S2 - f2{smin, smin};
+                    t = t * 2.0f;
+                    f2 quo;
+                    if (fastdiv)
+                        quo = div_rcp2(t, span, rspan);
+                    else
+                        quo = f2{t.x / span, t.y / span};
+                    f2 z = quo + (-1.0f);
+                    if (p == 0 && a.do_not_flag_first) z.x = clip2<float>(z.x, -1.0f, 1.0f);
+                    zz[p] = z;
+                    SS[p] = S2;
+                    any_ex = any_ex || (fabsf(z.x) > 1.0f) || (fabsf(z.y) > 1.0f);
+                }
+                slow = __any(any_ex);
+            } else {
+#pragma unroll
+                for (int p = 0; p < GP; ++p) zz[p] = SS[p] = f2{0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int p = 0; p < GP; ++p) {
+                // raw values of groups 2p, 2p+1 of the next row (this row's are consumed)
+                fetch_groups(r + 4, 2 * p, 2 * p + 2, rr);
+                if (a_full) {
+                    const f2 z = zz[p];
+                    f2 phi = {rr.cf[0], rr.cf[0]};
+                    bool ex[2] = {false, false};
+                    if (!slow) {
+                        f2 pp = {1.0f, 1.0f}, pc = z;
+#pragma unroll
+                        for (int L = 1; L < NP; ++L) {
+                            const f2 term = pc * rr.cf[L];
+                            phi = phi + term;
+                            const f2 u = z * c1[L];
+                            const f2 pn = u * pc - pp * c2[L];
+                            pp = pc;
+                            pc = pn;
+                        }
+                    } else {
+                        float ph[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float ze = e ? z.y : z.x;
+                            const float az = fabsf(ze);
+                            ex[e] = az > 1.0f;
+                            const float exc = az - 1.0f;
+                            const bool neg = ze < 0.0f;
+                            float phs = rr.cf[0], pp = 1.0f, pc = ze;
+#pragma unroll
+                            for (int L = 1; L < NP; ++L) {
+                                float ee = 1.0f + chf[L] * exc;
+                                ee = (neg && (L & 1)) ? -ee : ee;
+                                const float sel = ex[e] ? ee : pc;
+                                const float term = rr.cf[L] * sel;
+                                phs = phs + term;
+                                const float u = c1[L] * ze;
+                                const float pn = u * pc - c2[L] * pp;
+                                pp = pc;
+                                pc = pn;
+                            }
+                            ph[e] = phs;
+                        }
+                        phi = f2{ph[0], ph[1]};
+                    }
+                    const f2 fb = SS[p] - f2{rr.sref, rr.sref};
+                    float vout[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int g = 2 * p + e;
+                        vout[e] = ((dq & bad) == 0) ? (e ? phi.y : phi.x) : (e ? fb.y : fb.x);
+                        const bool first = (g == 0) && a.do_not_flag_first;
+                        const uint32_t qg = ((g < 4 ? w0 : w1) >> (8 * (g & 3)));
+                        if (!first && ex[e] && (qg & DQ_SATURATED) == 0) dq |= DQ_NO_LIN_CORR;
+                    }
+                    f2 xv = {vout[0], vout[1]};
+                    if (act) xv = xv * rr.gain;
+                    xs[p * 4 * C2_COLS] = col_ok ? xv : f2{0.0f, 0.0f};
+                } else if (do_a) {
+                    xs[p * 4 * C2_COLS] = f2{0.0f, 0.0f};
                 }
             }
-            CH_T(0)
-            __syncthreads();
-            CH_T(1)
-            // ---- S2: issue the raw loads of row r+4 (consumed in S1 of the next step), then C of row yc
-            fetch_row(r + 4, rr);
-            if (do_c && vC) {
-                const bool all = __all(vC == 0x1ffu);
-                const int sm = (yc - 1) & 3, s0 = yc & 3, sp = (yc + 1) & 3;
-                const int so = (yc + 3000) % 3;
-                constexpr int NB = 1;  // register budget of the ingest role (the row prefetch is live here)
-#pragma unroll
-                for (int p0 = 0; p0 < GP; p0 += NB) {
-                    const f2 *xm[NB], *x0[NB], *xp[NB];
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        const f2 *xb = X2 + (p0 + b) * 4 * C2_COLS;
-                        xm[b] = xb + sm * C2_COLS, x0[b] = xb + s0 * C2_COLS, xp[b] = xb + sp * C2_COLS;
-                    }
-                    f2 f[NB], xc[NB];
-                    if (all)
-                        fwd_rows_batch<NB, true>(xm, x0, xp, col, kC, vC, f, xc);
-                    else
-                        fwd_rows_batch<NB, false>(xm, x0, xp, col, kC, vC, f, xc);
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) O12[((p0 + b) * 3 + so) * C2_COLS + col] = (xc[b] + xc[b]) - f[b];
-                }
+            if (do_a) {
+                const bool keep = a_full && col_ok;
+                DQ[slot * C2_COLS + col] = keep ? dq : 0u;
+                QS[slot * C2_COLS + col] = keep ? uint2{w0, w1} : uint2{0u, 0u};
             }
             CH_T(2)
-            __syncthreads();
+            C2_SYNC();
             CH_T(3)
+            // ---- S2: issue the raw loads of row r+4 (consumed in S1 of the next step), then C of row yc
+            CH_T(4)
+            {
+                // every lane evaluates (lanes without valid terms produce values nobody reads); the coefficient planes of
+                // the next row are requested between the pairs, unconditionally (see above)
+                const bool all = __all(vC == 0x1ffu || vC == 0u);
+                const int sm = (yc - 1) & 3, s0 = yc & 3, sp = (yc + 1) & 3;
+                const int so = (yc + 3000) % 3;
+#pragma unroll
+                for (int p0 = 0; p0 < GP; ++p0) {
+                    fetch_coefs(r + 4, p0 * CO_STEP, (p0 * CO_STEP + CO_STEP < NCO) ? p0 * CO_STEP + CO_STEP : NCO, rr);
+                    if (do_c) {
+                        const f2 *xb = X2 + p0 * 4 * C2_COLS;
+                        const f2 *xm[1] = {xb + sm * C2_COLS}, *x0[1] = {xb + s0 * C2_COLS}, *xp[1] = {xb + sp * C2_COLS};
+                        f2 f[1], xc[1];
+                        if (all)
+                            fwd_rows_batch<1, true>(xm, x0, xp, col, kC, vC, f, xc);
+                        else
+                            fwd_rows_batch<1, false>(xm, x0, xp, col, kC, vC, f, xc);
+                        O12[(p0 * 3 + so) * C2_COLS + col] = (xc[0] + xc[0]) - f[0];
+                    }
+                }
+                if (GP * CO_STEP < NCO) fetch_coefs(r + 4, GP * CO_STEP, NCO, rr);
+            }
+            CH_T(5)
+            // ---- T: flag propagation (fitting.py:339-353), finish and stores of pixel (yt, c) from the fit waves' results
+            if (emit) {
+                const float4 tr = TR[(yt & 1) * C2_COLS + col];
+                float s = tr.x, er = tr.y, ep = tr.z;
+                const uint32_t jmask = __float_as_uint(tr.w);
+                const bool act = col_act && yt >= ay0 && yt < ay1;
+                uint32_t qe[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) qe[g] = ((g < 4 ? t_q.x : t_q.y) >> (8 * (g & 3))) & 0xffu;
+                uint32_t pdq =
+                    propagate_flags<G>(qe, jmask, start, e_pdq | t_dq, a.gdq_out ? a.gdq_out + pe_row : nullptr, npix, c2_opaque(cc1));
+                if (a.finish) {
+                    float err = hypot_f32(er, ep);
+                    float vp = ep * ep;
+                    if (!act) {
+                        s = 0.0f;
+                        err = 0.0f;
+                        vp = 0.0f;
+                    }
+                    if (act && a.dark_rate) s = s - e_dark;
+                    if (act) pdq |= e_ddq;
+                    float ep2 = sqrtf(vp);
+                    const float e2 = err * err;
+                    const float p2 = ep2 * ep2;
+                    float er2 = sqrtf(clip_lo<float>(e2 - p2, 0.0f));
+                    if (a.flat) {
+                        pdq |= e_ff;
+                        if (__all(rcp_safe(e_flat) && fabsf(s) < 1e18f && fabsf(er2) < 1e18f && fabsf(ep2) < 1e18f &&
+                                  (s == 0.0f || fabsf(s) > 1e-18f) && (er2 == 0.0f || er2 > 1e-18f) &&
+                                  (ep2 == 0.0f || ep2 > 1e-18f))) {
+                            const float rflat = 1.0f / e_flat;
+                            s = div_rcp(s, e_flat, rflat);
+                            er2 = div_rcp(er2, e_flat, rflat);
+                            ep2 = div_rcp(ep2, e_flat, rflat);
+                        } else {
+                            s = s / e_flat;
+                            er2 = er2 / e_flat;
+                            ep2 = ep2 / e_flat;
+                        }
+                    }
+                    er = er2;
+                    ep = ep2;
+                }
+                const unsigned w4 = c2_opaque(cc4);
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(a.slope) + t_row4 + w4) = s;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(a.err_read) + t_row4 + w4) = er;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(a.err_poisson) + t_row4 + w4) = ep;
+                *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.pdq_out) + t_row4 + w4) = pdq;
+            }
+            CH_T(6)
+            C2_SYNC();
+            CH_T(7)
         }
     } else {
         // =========================================================================== fit waves
@@ -308,28 +500,26 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
         unsigned vF = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) kF[k] = 0.0f;
-        const int start = KLD(h->start);
         const RipVariant v0 = rip_load_variant(vars, 0);
-        for (int r = R0 - 5; r < R1; ++r) {
-            const bool do_e = r >= R0;
-            const bool emit = do_e && col >= 2 && col < C2_COLS - 2 && col_ok;
-            const unsigned pe = (unsigned)(min(max(r, 0), ny - 1) * nx + cc);
-            // ---- S1: loads the finish needs (latency hidden by O2), then the second IPC iterate of row r
-            const float e_read = ldg<float>(planes, (unsigned)(NP + 5) * pl4 + pe * 4u);
-            const float e_dark = ldg<float>(planes, (unsigned)(NP + 6) * pl4 + pe * 4u);
-            const uint32_t e_ff = ldg<uint32_t>(planes, (unsigned)(NP + 8) * pl4 + pe * 4u);
-            const uint32_t e_pdq = ldg<uint32_t>(a.pdq, pe * 4u);
-            const float e_flat = a.flat ? ldg<float>(a.flat, pe * 4u) : 1.0f;
+    const RipFitConst fc0 = rip_fit_const(h);
+        float gain_next = 1.0f;
+        for (int r = R0 - 5; r <= R1; ++r) {
+            const bool emit = (r >= R0) && (r < R1) && col >= 2 && col < C2_COLS - 2 && col_ok;
+            const unsigned rc_ = (unsigned)min(max(r, 0), ny - 1);
+            const unsigned pe = rc_ * (unsigned)nx + cc1;
+            // ---- S1: read noise of the pixel (used by the fit), then the second IPC iterate of row r
+            const float e_read = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(planes) +
+                                                                  (size_t)(NP + 5) * pl4 + (size_t)(rc_ * row4) + c2_opaque(cc4));
+            const float e_gain = gain_next;
             float d[G];
             f2 dpair[GP];
             uint32_t qe[G];
-            float e_gain = 1.0f;
-            uint32_t lin_dq = 0;
             const bool act = emit && col_act && r >= ay0 && r < ay1;
+            CH_T(0)
+            C2_DRAIN()
+            CH_T(1)
             if (emit) {
                 const int sx = r & 3;
-                e_gain = GS[sx * C2_COLS + col];
-                lin_dq = DQ[sx * C2_COLS + col];
                 const uint2 qw = QS[sx * C2_COLS + col];
 #pragma unroll
                 for (int g = 0; g < G; ++g) qe[g] = ((g < 4 ? qw.x : qw.y) >> (8 * (g & 3))) & 0xffu;
@@ -372,12 +562,18 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                     }
                 }
             }
-            CH_T(4)
-            __syncthreads();
-            CH_T(5)
-            // ---- S2: coefficients of the next row's O2, then fit + finish + stores of pixel (r, c)
+            CH_T(2)
+            C2_SYNC();
+            CH_T(3)
+            // ---- S2: coefficients and gain of the next row's O2, then the fit of pixel (r, c) -> T ring
             float kN[9];
-            const unsigned vN = load_k(r + 1, (r + 1 >= R0) && col >= 2 && col < C2_COLS - 2, kN);
+            const bool next_on = (r + 1 >= R0) && (r + 1 < R1) && col >= 2 && col < C2_COLS - 2;
+            const unsigned vN = load_k(r + 1, next_on, kN);
+            gain_next = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(planes) + (size_t)(NP + 4) * pl4 +
+                                                         (size_t)((unsigned)min(max(r + 1, 0), ny - 1) * row4) + c2_opaque(cc4));
+            CH_T(4)
+            C2_DRAIN()
+            CH_T(5)
             if (emit) {
                 if (a.cube_out) {
 #pragma unroll
@@ -389,50 +585,14 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 float s, er, ep;
                 uint32_t jmask = 0;
                 const bool unsat = (qe[G - 1] & DQ_SATURATED) == 0;
-                fit_full_pk<G>(dpair, h, v0, a.dense, kvals + v0.k_ofs, diffs + v0.diff_ofs, e_gain, e_read,
+                fit_full_pk<G>(dpair, h, fc0, v0, a.dense, kvals + v0.k_ofs, diffs + v0.diff_ofs, e_gain, e_read,
                                unsat && act, guard, s, er, ep, jmask);
                 if (__any((anyq & DQ_SATURATED) != 0))
                     trunc_layers<G, G - 1>(d, qe, h, vars, kvals, diffs, e_gain, e_read, act, guard, s, er, ep, jmask);
-                uint32_t pdq = propagate_flags<G>(qe, jmask, start, e_pdq | lin_dq, a.gdq_out ? a.gdq_out + pe : nullptr, npix);
-                if (a.finish) {
-                    float err = hypot_f32(er, ep);
-                    float vp = ep * ep;
-                    if (!act) {
-                        s = 0.0f;
-                        err = 0.0f;
-                        vp = 0.0f;
-                    }
-                    if (act && a.dark_rate) s = s - e_dark;
-                    if (act && a.dark_dq) pdq |= a.dark_dq[pe];
-                    float ep2 = sqrtf(vp);
-                    const float e2 = err * err;
-                    const float p2 = ep2 * ep2;
-                    float er2 = sqrtf(clip_lo<float>(e2 - p2, 0.0f));
-                    if (a.flat) {
-                        pdq |= e_ff;
-                        if (__all(rcp_safe(e_flat) && fabsf(s) < 1e18f && fabsf(er2) < 1e18f && fabsf(ep2) < 1e18f &&
-                                  (s == 0.0f || fabsf(s) > 1e-18f) && (er2 == 0.0f || er2 > 1e-18f) &&
-                                  (ep2 == 0.0f || ep2 > 1e-18f))) {
-                            const float rflat = 1.0f / e_flat;
-                            s = div_rcp(s, e_flat, rflat);
-                            er2 = div_rcp(er2, e_flat, rflat);
-                            ep2 = div_rcp(ep2, e_flat, rflat);
-                        } else {
-                            s = s / e_flat;
-                            er2 = er2 / e_flat;
-                            ep2 = ep2 / e_flat;
-                        }
-                    }
-                    er = er2;
-                    ep = ep2;
-                }
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(a.slope) + pe * 4u) = s;
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(a.err_read) + pe * 4u) = er;
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(a.err_poisson) + pe * 4u) = ep;
-                *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.pdq_out) + pe * 4u) = pdq;
+                TR[(r & 1) * C2_COLS + col] = float4{s, er, ep, __uint_as_float(jmask)};
             }
             CH_T(6)
-            __syncthreads();
+            C2_SYNC();
             CH_T(7)
             vF = vN;
 #pragma unroll
@@ -448,7 +608,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
 }
 
 static inline size_t chain2_lds_bytes(int G) {
-    return (size_t)(G / 2) * C2_COLS * 8 * (4 + 3) + (size_t)C2_COLS * 4 * (4 + 8 + 4) + (size_t)3 * G * 2 * 8;
+    return (size_t)(G / 2) * C2_COLS * 8 * (4 + 3) + (size_t)C2_COLS * 4 * (4 + 8) + (size_t)C2_COLS * 2 * 16 +
+           (size_t)3 * G * 2 * 8;
 }
 
 template <int NP, int G>
@@ -463,7 +624,8 @@ static int launch_chain2(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) 
     }
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
-    if (per_cu > 2) per_cu = 2;  // 2 x 8 waves = 4 waves/SIMD at <= 128 VGPRs
+    const int max_wg = 16 / (C2_THREADS / 64);  // 16 waves per CU = 4 waves/SIMD at <= 128 VGPRs
+    if (per_cu > max_wg) per_cu = max_wg;
     const int nstrips = (a.nx + C2_OUTW - 1) / C2_OUTW;
     int nranges = (int)(((long)ncu * per_cu) / nstrips);
     if (nranges > (a.ny + 7) / 8) nranges = (a.ny + 7) / 8;

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
     uint32_t d0 = 0, d1 = 0, d2 = 0;
 
     const RipVariant v0 = rip_load_variant(vars, 0);
+    const RipFitConst fc0 = rip_fit_const(h);
 #ifdef CH_STAMP
     unsigned long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tl_ = __builtin_amdgcn_s_memtime();
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(CH_BT) void chain_kernel(ChainArgs a, const RipPlan
                                             guard, pdq_in, a.gdq_out ? a.gdq_out + pe : nullptr, npix, s, er, ep, pdq);
             } else {
                 uint32_t jmask = 0;
-                fit_full_pk<G>(dpair, h, v0, a.dense, kvals + v0.k_ofs, diffs + v0.diff_ofs, e_gain, e_read,
+                fit_full_pk<G>(dpair, h, fc0, v0, a.dense, kvals + v0.k_ofs, diffs + v0.diff_ofs, e_gain, e_read,
                                act, guard, s, er, ep, jmask);
                 // flag propagation (fitting.py:339-353) without saturation
                 uint32_t orq = 0;

@@ -298,21 +298,55 @@ __device__ __forceinline__ void fit_full_regs(const float (&d)[G], const RipPlan
 // table load can be issued up front).  Same outputs as fit_variant() on the full ramp.
 typedef float rf2 __attribute__((ext_vector_type(2)));
 
+// plan constants of the jump threshold, computed once per kernel (wave-uniform)
+struct RipFitConst {
+    float ia, ib;       // f32(IthreshA), f32(IthreshB)
+    float sa32;         // f32(SthreshA)
+    float slope_th;     // f32((SthreshB - SthreshA) / log(IthreshB / IthreshA))
+};
+__device__ __forceinline__ RipFitConst rip_fit_const(const RipPlanHeader *h) {
+    RipFitConst c;
+    c.ia = KLD(h->ia);
+    c.ib = KLD(h->ib);
+    c.sa32 = (float)KLD(h->sa);
+    c.slope_th = (float)(KLD(h->dsb) / KLD(h->loglen));
+    return c;
+}
+
+__device__ __forceinline__ void rip_load_pair(RipDensePair &r, const RipDense *dn, int ps) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        r.inv_dt[e] = KLD(dn->pairs[ps].inv_dt[e]);
+        r.A[e] = KLD(dn->pairs[ps].A[e]);
+        r.B[e] = KLD(dn->pairs[ps].B[e]);
+        r.relerr[e] = KLD(dn->pairs[ps].relerr[e]);
+    }
+}
+
 template <int G>
 __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPlanHeader *__restrict__ h,
-                                            const RipVariant v, const RipDense *__restrict__ dn,
+                                            const RipFitConst fc, const RipVariant v, const RipDense *__restrict__ dn,
                                             const float *__restrict__ kv, const RipDiff *__restrict__ df, float gain,
                                             float rn, bool flag, double guard, float &s_out, float &er_out,
                                             float &ep_out, uint32_t &jmask) {
     constexpr int GP = G / 2;
+    constexpr int NS = 2 * GP;  // pair slots
+    // scalar loads of the weights and of the first difference slot are issued before the slope arithmetic; slot
+    // ps+1 is requested while slot ps is evaluated (scalar loads return out of order: every wait is lgkmcnt(0))
+    float k2[G];
+#pragma unroll
+    for (int t = 0; t < G; ++t) k2[t] = KLD(dn->K2[t]);
+    const uint32_t valid = KLD(dn->valid);
+    RipDensePair tab[2];
+    rip_load_pair(tab[0], dn, 0);
     const float d1 = dA[0].y;
     const rf2 d11 = {d1, d1};
     float s = 0.0f;
 #pragma unroll
     for (int p = 0; p < GP; ++p) {
         const rf2 diff = dA[p] - d11;
-        const rf2 k2 = {KLD(dn->K2[2 * p]), KLD(dn->K2[2 * p + 1])};
-        const rf2 prod = k2 * diff;
+        const rf2 kk = {k2[2 * p], k2[2 * p + 1]};
+        const rf2 prod = kk * diff;
         s = s + prod.x;
         s = s + prod.y;
     }
@@ -324,63 +358,53 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
     ep_out = sqrtf(pv);
     if (!__any(flag)) return;
 
-    const float xc = clip2<float>(s, KLD(h->ia), KLD(h->ib));
-    const bool need_log = xc != KLD(h->ia);  // log(1) = 0 exactly otherwise
+    const float xc = clip2<float>(s, fc.ia, fc.ib);
+    const bool need_log = xc != fc.ia;  // log(1) = 0 exactly otherwise
     float lx = 0.0f;
-    if (__any(need_log)) lx = need_log ? __logf(xc / KLD(h->ia)) : 0.0f;
-    const float slope_th = (float)(KLD(h->dsb) / KLD(h->loglen));
-    const float sth32 = (float)KLD(h->sa) + slope_th * lx;
+    if (__any(need_log)) lx = need_log ? __logf(xc / fc.ia) : 0.0f;
+    const float slope_th = fc.slope_th;
+    const float sth32 = fc.sa32 + slope_th * lx;
     const float band0 = 2e-6f * fabsf(sth32) + 4e-6f * fabsf(slope_th) + 1e-30f;
     const float s2 = rn * rn;
     const float abs_s = fabsf(s);
     const bool force_exact = !(guard < 1e300);
-    const uint32_t valid = KLD(dn->valid);
     uint32_t jfast = 0, unsure_mask = 0;
     rf2 dB[GP];  // (d[2p+1], d[2p+2])
 #pragma unroll
     for (int p = 0; p < GP; ++p) dB[p] = rf2{dA[p].y, (p + 1 < GP) ? dA[p + 1].x : 0.0f};
 #pragma unroll
-    for (int ip = 0; ip < GP; ++ip) {
+    for (int ps = 0; ps < NS; ++ps) {
+        if (ps + 1 < NS) rip_load_pair(tab[(ps + 1) & 1], dn, ps + 1);
+        const int ip = ps / 2, di = (ps & 1) + 1;
+        const uint32_t vbits = (valid >> (2 * ps)) & 3u;
+        if (vbits == 0) continue;  // plan-uniform
+        const rf2 hi = (di == 1) ? dB[ip] : ((ip + 1 < GP) ? dA[ip + 1] : rf2{0.0f, 0.0f});
+        const rf2 lo = dA[ip];
+        const RipDensePair &r = tab[ps & 1];
+        const rf2 num = hi - lo;
+        const rf2 q = num * rf2{r.inv_dt[0], r.inv_dt[1]};
+        const rf2 delta = q - rf2{s, s};
+        const rf2 as2 = rf2{r.A[0], r.A[1]} * s2;
+        const rf2 var = __builtin_elementwise_fma(rf2{r.B[0], r.B[1]}, rf2{dv, dv}, as2);
+        const rf2 rs = {__frsqrt_rn(var.x), __frsqrt_rn(var.y)};
+        const rf2 sm = delta * rs;
+        const rf2 asm_ = __builtin_elementwise_abs(sm);
+        const rf2 aq = __builtin_elementwise_abs(q) + abs_s;
+        const rf2 band = (asm_ * rf2{r.relerr[0], r.relerr[1]} + band0) + (aq * rs) * 4e-7f;
+        const rf2 dist = __builtin_elementwise_abs(sm - sth32);
 #pragma unroll
-        for (int di = 1; di <= 2; ++di) {
-            const int ps = 2 * ip + di - 1;
-            const uint32_t vbits = (valid >> (2 * ps)) & 3u;
-            if (vbits == 0) continue;  // plan-uniform
-            const rf2 hi = (di == 1) ? dB[ip] : ((ip + 1 < GP) ? dA[ip + 1] : rf2{0.0f, 0.0f});
-            const rf2 lo = dA[ip];
-            RipDensePair r;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                r.inv_dt[e] = KLD(dn->pairs[ps].inv_dt[e]);
-                r.A[e] = KLD(dn->pairs[ps].A[e]);
-                r.B[e] = KLD(dn->pairs[ps].B[e]);
-                r.relerr[e] = KLD(dn->pairs[ps].relerr[e]);
-            }
-            const rf2 num = hi - lo;
-            const rf2 q = num * rf2{r.inv_dt[0], r.inv_dt[1]};
-            const rf2 delta = q - rf2{s, s};
-            const rf2 as2 = rf2{r.A[0], r.A[1]} * s2;
-            const rf2 var = __builtin_elementwise_fma(rf2{r.B[0], r.B[1]}, rf2{dv, dv}, as2);
-            const rf2 rs = {__frsqrt_rn(var.x), __frsqrt_rn(var.y)};
-            const rf2 sm = delta * rs;
-            const rf2 asm_ = __builtin_elementwise_abs(sm);
-            const rf2 aq = __builtin_elementwise_abs(q) + abs_s;
-            const rf2 band = (asm_ * rf2{r.relerr[0], r.relerr[1]} + band0) + (aq * rs) * 4e-7f;
-            const rf2 dist = __builtin_elementwise_abs(sm - sth32);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                if (!((vbits >> e) & 1u)) continue;  // plan-uniform
-                const bool hit = (e ? sm.y : sm.x) > sth32;
-                const bool unsure = force_exact || !((e ? dist.y : dist.x) > (e ? band.y : band.x));
-                if (hit) jfast |= 1u << (2 * ps + e);
-                if (unsure) unsure_mask |= 1u << (2 * ps + e);
-            }
+        for (int e = 0; e < 2; ++e) {
+            if (!((vbits >> e) & 1u)) continue;  // plan-uniform
+            const bool hit = (e ? sm.y : sm.x) > sth32;
+            const bool unsure = force_exact || !((e ? dist.y : dist.x) > (e ? band.y : band.x));
+            if (hit) jfast |= 1u << (2 * ps + e);
+            if (unsure) unsure_mask |= 1u << (2 * ps + e);
         }
     }
     // differences whose approximate significance is within its error band of the threshold (or NaN): redo them in
     // the reference's exact operation order.  Rare; one wave-uniform test covers the whole pixel.
     if (__any(unsure_mask != 0 && flag)) {
-        const float lxe = log_f32(xc / KLD(h->ia));
+        const float lxe = log_f32(xc / fc.ia);
         const double sth = KLD(h->sa) + KLD(h->dsb) * ((double)lxe / KLD(h->loglen));
         for (int bit = 0; bit < 4 * GP; ++bit) {
             if (!__any((unsure_mask >> bit) & 1u)) continue;
@@ -449,13 +473,13 @@ __device__ __forceinline__ void trunc_layers(const float (&d)[G], const uint32_t
 // flag propagation of fitting.py:339-353 from registers; writes the updated group flags when gdq_out != null
 template <int G>
 __device__ __forceinline__ uint32_t propagate_flags(const uint32_t (&qe)[G], uint32_t jmask, int start, uint32_t pdq_in,
-                                                    uint8_t *gdq_out, unsigned gstride) {
+                                                    uint8_t *gdq_out, unsigned gstride, unsigned lane_off = 0) {
     uint32_t or_unsat = 0, any_sat = 0;
     bool all_dnu = true;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const uint32_t rq = qe[g] | (((jmask >> g) & 1u) ? DQ_JUMP_DET : 0u);
-        if (gdq_out) gdq_out[(size_t)g * gstride] = (uint8_t)rq;
+        if (gdq_out) *(gdq_out + (size_t)g * gstride + lane_off) = (uint8_t)rq;  // uniform base + per-lane offset
         if ((rq & DQ_SATURATED) == 0) or_unsat |= rq;
         any_sat |= rq & DQ_SATURATED;
         all_dnu = all_dnu && ((rq & DQ_DO_NOT_USE) != 0);

@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 import torch
 
+from romanimpreprocess_amd import _native
+if os.environ.get("ALTLIB"):
+    _native.LIB_PATH = os.path.join(os.path.dirname(_native.__file__), os.environ["ALTLIB"])
 from romanimpreprocess_amd import pipeline, synth
 
 rp = synth.READ_PATTERN_8

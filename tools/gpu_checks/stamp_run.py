@@ -20,6 +20,8 @@ cb = pipeline.Calibrator(device=0)
 lib = cb.ctx.lib
 lib.rip_chain_stamps.restype = C.c_int
 lib.rip_chain_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+lib.rip_chain_stamps2.restype = C.c_int
+lib.rip_chain_stamps2.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 cb.load_caldir(0, cal)
 pid, meta = cb.plan_for(rp, ramp["frame_time"])
 dev = torch.device("cuda", 0)
@@ -46,6 +48,27 @@ CHAIN2 = bool(int(os.environ.get("CHAIN2", "1")))
 cb.ctx.set_option("chain2", int(CHAIN2))
 names2 = ["ingest A lin", "ingest barrier 1", "ingest C + loads", "ingest barrier 2", "fit O2", "fit barrier 1",
           "fit F", "fit barrier 2", "-"]
+names18 = ["ingest S1 issue loads", "ingest drain (dbg 2048)", "ingest A lin", "ingest barrier 1", "ingest fetch row r+4",
+           "ingest C", "ingest T tail", "ingest barrier 2", "-",
+           "fit S1 issue loads", "fit drain (dbg 2048)", "fit O2", "fit barrier 1", "fit S2 issue loads",
+           "fit drain (dbg 2048)", "fit F", "fit barrier 2", "-"]
+if CHAIN2:
+    out18 = (C.c_double * 18)()
+    for mask in [int(x) for x in sys.argv[1:]] or [0]:
+        cb.ctx.set_option("chain_dbg", mask)
+        call()
+        cb.synchronize()
+        lib.rip_chain_stamps2(cb.ctx.h, out18)
+        n = 3
+        for _ in range(n):
+            call()
+        lib.rip_chain_stamps2(cb.ctx.h, out18)
+        for role in (0, 1):
+            tot = sum(out18[9 * role:9 * role + 9])
+            print(f"dbg={mask} role {role}: total ticks per wave per launch {tot/n/2048:.0f}")
+            for i in range(9 * role, 9 * role + 8):
+                print(f"   {names18[i]:26s} {out18[i]/n/2048/141:8.0f} per step  {100*out18[i]/tot:5.1f}%")
+    sys.exit(0)
 names = ["P issue loads", "C O1", "barrier 1", "E rest (finish+stores)", "A lin", "barrier 2", "E: O2", "E: fit+flags", "wait all loads (dbg 2048)"]
 for mask in [int(x) for x in sys.argv[1:]] or [0]:
     cb.ctx.set_option("chain_dbg", mask)
