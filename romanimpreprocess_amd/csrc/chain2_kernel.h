@@ -64,6 +64,11 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
     double *LN = reinterpret_cast<double *>(TR + 2 * C2_COLS);      // [3][G][2] channel lines of this strip
 
     const int tid = threadIdx.x;
+#ifdef C2_DBG
+    const int dbg = a.dbg;  // timing experiments only (tools/gpu_checks/phase_timing.py): bits switch phases off
+#else
+    constexpr int dbg = 0;
+#endif
     const bool fit_role = tid >= C2_COLS;
     const int col = tid & (C2_COLS - 1);
     const int ny = a.ny, nx = a.nx, nb = a.nb;
@@ -134,6 +139,11 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
     // coefficient loader: raw loads at clamped source positions + validity mask for destination (y, c);
     // `want` is wave-uniform.  Planes are walked in memory order (plane = 3*(1+dy) + (1+dx)).
     auto load_k = [&](int y, bool want, float (&kk)[9]) -> unsigned {
+        if (dbg & 128) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) kk[k] = (k == 0) ? 1.0f : 0.001f;
+            return want ? lane_mask : 0u;
+        }
         size_t rowoff[3];
         const unsigned ox[3] = {c2_opaque(cx4[0]), c2_opaque(cx4[1]), c2_opaque(cx4[2])};
         bool rok[3];
@@ -203,6 +213,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
         // The same loads in pieces, issued between blocks of arithmetic (scheduling fences keep them there): a burst of
         // 46 loads per wave from all waves at once saturates the CU's address unit while the vector ALUs idle.
         auto fetch_groups = [&](int y, int g0, int g1, RowRegs<NP, G> &rr) {
+            if (dbg & 64) return;
             __builtin_amdgcn_sched_barrier(0);
             const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
             const unsigned o4 = c2_opaque(cc4), o2 = c2_opaque(cc2), o1 = c2_opaque(cc1);
@@ -225,6 +236,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
         };
         // planes i0..i1-1 of [cf[0..NP-1], Smin, Smax, Sref, dq, gain]
         auto fetch_coefs = [&](int y, int i0, int i1, RowRegs<NP, G> &rr) {
+            if (dbg & 64) return;
             __builtin_amdgcn_sched_barrier(0);
             const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
             const unsigned o4 = c2_opaque(cc4);
@@ -257,8 +269,170 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             const bool do_a = (yi >= R0 - 2) && (yi <= R1 + 1);
             const bool do_c = (yc >= R0 - 1) && (yc <= R1);
             const bool emit = (yt >= R0) && (yt < R1) && col >= 2 && col < C2_COLS - 2 && col_ok;
-            // ---- S1: loads of the tail (row yt: calibration planes, and the pixel's dq words before A reuses their
-            //          ring slot), coefficient loads for C, then A (linearity of row yi from rr)
+            // ---- S1: A (linearity of row yi from rr), then the loads S2 consumes
+            // per-row reference-pixel correction of the G groups: wave-uniform, scalar loads (constant address space)
+            double rc[G];
+            {
+                const int yl = min(max(yi, 0), ny - 1);
+#pragma unroll
+                for (int g = 0; g < G; ++g) rc[g] = KLD(a.rowcorr[g * ny + yl]);
+            }
+            const bool a_full = do_a && yi >= 0 && yi < ny;  // wave-uniform
+            // A: two pairs of groups at a time -- reference-pixel/bias arithmetic and z of both pairs, then their two
+            // Legendre recurrences interleaved (independent chains), then the raw loads of the same groups of the next
+            // row.  The loads are issued UNCONDITIONALLY between the blocks (the wait-count pass is path-insensitive: a
+            // load that exists on one side of a branch only forces vmcnt(0) at later uses).  All lanes compute (lanes
+            // beyond the frame edge work on the clamped column and store zeros).
+            const int slot = yi & 3;
+            f2 *xs = X2 + slot * C2_COLS + col;
+            const bool act = col_act && yi >= ay0 && yi < ay1;
+            uint32_t dq = rr.dq;
+            uint32_t w0 = 0, w1 = 0;  // the pixel's groupdq bytes, packed
+            const float smin = rr.smin;
+            const float span = rr.smax - smin;
+            const bool fastdiv = __all(rcp_safe(span));
+            const float rspan = 1.0f / span;
+            const double yd = (double)yi;
+            constexpr int PB = (GP % 2 == 0) ? 2 : 1;  // pairs per block
+#pragma unroll
+            for (int pb = 0; pb < GP; pb += PB) {
+                f2 zz[PB], SS[PB];
+                bool any_ex = false;
+                if (a_full && !(dbg & 32)) {
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) {
+                        const int p = pb + b;
+                        float Sv[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int g = 2 * p + e;
+                            float S = (float)rr.S[g];
+                            const float dk = rr.dk[g];
+                            float v = S - dk;
+                            v = (float)((double)v - rc[g]);
+                            const double *ln = LN + (chr * G + g) * 2;
+                            const double iel = ln[0] * yd + ln[1];
+                            v = (float)((double)v - iel);
+                            S = v + dk;
+                            if (act) S = S - rr.bs[g];
+                            Sv[e] = S;
+                            if (g < 4)
+                                w0 |= (rr.q[g] & 0xffu) << (8 * g);
+                            else
+                                w1 |= (rr.q[g] & 0xffu) << (8 * (g - 4));
+                        }
+                        const f2 S2 = {Sv[0], Sv[1]};
+                        f2 t = S2 - f2{smin, smin};
+                        t = t * 2.0f;
+                        f2 quo;
+                        if (fastdiv)
+                            quo = div_rcp2(t, span, rspan);
+                        else
+                            quo = f2{t.x / span, t.y / span};
+                        f2 z = quo + (-1.0f);
+                        if (p == 0 && a.do_not_flag_first) z.x = clip2<float>(z.x, -1.0f, 1.0f);
+                        zz[b] = z;
+                        SS[b] = S2;
+                        any_ex = any_ex || (fabsf(z.x) > 1.0f) || (fabsf(z.y) > 1.0f);
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) zz[b] = SS[b] = f2{0.0f, 0.0f};
+                }
+                // raw values of these groups of the next row (this row's are consumed)
+                fetch_groups(r + 4, 2 * pb, 2 * (pb + PB), rr);
+                if (a_full && (dbg & 16)) {
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) xs[(pb + b) * 4 * C2_COLS] = zz[b] + f2{1000.0f, 1100.0f};
+                } else if (a_full) {
+                    const bool slow = __any(any_ex);
+                    f2 phi[PB];
+                    bool ex[PB][2];
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) ex[b][0] = ex[b][1] = false;
+                    if (!slow) {
+                        f2 pp[PB], pc[PB];
+#pragma unroll
+                        for (int b = 0; b < PB; ++b) {
+                            phi[b] = f2{rr.cf[0], rr.cf[0]};
+                            pp[b] = f2{1.0f, 1.0f};
+                            pc[b] = zz[b];
+                        }
+#pragma unroll
+                        for (int L = 1; L < NP; ++L) {
+#pragma unroll
+                            for (int b = 0; b < PB; ++b) {
+                                const f2 term = pc[b] * rr.cf[L];
+                                phi[b] = phi[b] + term;
+                                const f2 u = zz[b] * c1[L];
+                                const f2 pn = u * pc[b] - pp[b] * c2[L];
+                                pp[b] = pc[b];
+                                pc[b] = pn;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < PB; ++b) {
+                            float ph[2];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const float ze = e ? zz[b].y : zz[b].x;
+                                const float az = fabsf(ze);
+                                ex[b][e] = az > 1.0f;
+                                const float exc = az - 1.0f;
+                                const bool neg = ze < 0.0f;
+                                float phs = rr.cf[0], pp = 1.0f, pc = ze;
+#pragma unroll
+                                for (int L = 1; L < NP; ++L) {
+                                    float ee = 1.0f + chf[L] * exc;
+                                    ee = (neg && (L & 1)) ? -ee : ee;
+                                    const float sel = ex[b][e] ? ee : pc;
+                                    const float term = rr.cf[L] * sel;
+                                    phs = phs + term;
+                                    const float u = c1[L] * ze;
+                                    const float pn = u * pc - c2[L] * pp;
+                                    pp = pc;
+                                    pc = pn;
+                                }
+                                ph[e] = phs;
+                            }
+                            phi[b] = f2{ph[0], ph[1]};
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) {
+                        const int p = pb + b;
+                        const f2 fb = SS[b] - f2{rr.sref, rr.sref};
+                        float vout[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int g = 2 * p + e;
+                            vout[e] = ((dq & bad) == 0) ? (e ? phi[b].y : phi[b].x) : (e ? fb.y : fb.x);
+                            const bool first = (g == 0) && a.do_not_flag_first;
+                            const uint32_t qg = ((g < 4 ? w0 : w1) >> (8 * (g & 3)));
+                            if (!first && ex[b][e] && (qg & DQ_SATURATED) == 0) dq |= DQ_NO_LIN_CORR;
+                        }
+                        f2 xv = {vout[0], vout[1]};
+                        if (act) xv = xv * rr.gain;
+                        xs[p * 4 * C2_COLS] = col_ok ? xv : f2{0.0f, 0.0f};
+                    }
+                } else if (do_a) {
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) xs[(pb + b) * 4 * C2_COLS] = f2{0.0f, 0.0f};
+                }
+            }
+            // the tail's dq words of pixel (yt, c), read before A reuses their ring slot
+            const uint2 t_q = QS[(yt & 3) * C2_COLS + col];
+            const uint32_t t_dq = DQ[(yt & 3) * C2_COLS + col];
+            if (do_a) {
+                const bool keep = a_full && col_ok;
+                DQ[slot * C2_COLS + col] = keep ? dq : 0u;
+                QS[slot * C2_COLS + col] = keep ? uint2{w0, w1} : uint2{0u, 0u};
+            }
+            // loads consumed after the barrier: IPC coefficients of row yc (for C) and the calibration planes of the
+            // tail row yt; issued here so that their registers are not live during A
+            float kC[9];
+            const unsigned vC = load_k(yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
             const unsigned ytc = (unsigned)min(max(yt, 0), ny - 1);
             const size_t t_row4 = (size_t)(ytc * row4);             // byte offset of the tail row in an f32 plane (uniform)
             const size_t pe_row = (size_t)(ytc * (unsigned)nx);     // element offset of the tail row
@@ -274,145 +448,6 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             const char *ddb = a.dark_dq ? reinterpret_cast<const char *>(a.dark_dq) : reinterpret_cast<const char *>(planes);
             const uint32_t e_ddq_raw = *reinterpret_cast<const uint32_t *>(ddb + t_row4 + t4);
             const uint32_t e_ddq = a.dark_dq ? e_ddq_raw : 0u;
-            const uint2 t_q = QS[(yt & 3) * C2_COLS + col];
-            const uint32_t t_dq = DQ[(yt & 3) * C2_COLS + col];
-            // per-row reference-pixel correction of the G groups: wave-uniform, scalar loads (constant address space)
-            double rc[G];
-            {
-                const int yl = min(max(yi, 0), ny - 1);
-#pragma unroll
-                for (int g = 0; g < G; ++g) rc[g] = KLD(a.rowcorr[g * ny + yl]);
-            }
-            float kC[9];
-            const unsigned vC = load_k(yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
-            CH_T(0)
-            C2_DRAIN()
-            CH_T(1)
-            const bool a_full = do_a && yi >= 0 && yi < ny;  // wave-uniform
-            // The loads of the next row are issued UNCONDITIONALLY between the blocks below (the wait-count pass is
-            // path-insensitive: a load that exists on one side of a branch only forces vmcnt(0) at later uses).
-            // All lanes compute (lanes beyond the frame edge work on the clamped column and store zeros).
-            const int slot = yi & 3;
-            f2 *xs = X2 + slot * C2_COLS + col;
-            const bool act = col_act && yi >= ay0 && yi < ay1;
-            uint32_t dq = rr.dq;
-            bool slow = false;
-            f2 zz[GP], SS[GP];
-            uint32_t w0 = 0, w1 = 0;  // the pixel's groupdq bytes, packed
-            if (a_full) {
-                const float smin = rr.smin;
-                const float span = rr.smax - smin;
-                const bool fastdiv = __all(rcp_safe(span));
-                const float rspan = 1.0f / span;
-                const double yd = (double)yi;
-                bool any_ex = false;
-#pragma unroll
-                for (int p = 0; p < GP; ++p) {
-                    float Sv[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int g = 2 * p + e;
-                        float S = (float)rr.S[g];
-                        const float dk = rr.dk[g];
-                        float v = S - dk;
-                        v = (float)((double)v - rc[g]);
-                        const double *ln = LN + (chr * G + g) * 2;
-                        const double iel = ln[0] * yd + ln[1];
-                        v = (float)((double)v - iel);
-                        S = v + dk;
-                        if (act) S = S - rr.bs[g];
-                        Sv[e] = S;
-                        if (g < 4)
-                            w0 |= (rr.q[g] & 0xffu) << (8 * g);
-                        else
-                            w1 |= (rr.q[g] & 0xffu) << (8 * (g - 4));
-                    }
-                    const f2 S2 = {Sv[0], Sv[1]};
-                    f2 t = S2 - f2{smin, smin};
-                    t = t * 2.0f;
-                    f2 quo;
-                    if (fastdiv)
-                        quo = div_rcp2(t, span, rspan);
-                    else
-                        quo = f2{t.x / span, t.y / span};
-                    f2 z = quo + (-1.0f);
-                    if (p == 0 && a.do_not_flag_first) z.x = clip2<float>(z.x, -1.0f, 1.0f);
-                    zz[p] = z;
-                    SS[p] = S2;
-                    any_ex = any_ex || (fabsf(z.x) > 1.0f) || (fabsf(z.y) > 1.0f);
-                }
-                slow = __any(any_ex);
-            } else {
-#pragma unroll
-                for (int p = 0; p < GP; ++p) zz[p] = SS[p] = f2{0.0f, 0.0f};
-            }
-#pragma unroll
-            for (int p = 0; p < GP; ++p) {
-                // raw values of groups 2p, 2p+1 of the next row (this row's are consumed)
-                fetch_groups(r + 4, 2 * p, 2 * p + 2, rr);
-                if (a_full) {
-                    const f2 z = zz[p];
-                    f2 phi = {rr.cf[0], rr.cf[0]};
-                    bool ex[2] = {false, false};
-                    if (!slow) {
-                        f2 pp = {1.0f, 1.0f}, pc = z;
-#pragma unroll
-                        for (int L = 1; L < NP; ++L) {
-                            const f2 term = pc * rr.cf[L];
-                            phi = phi + term;
-                            const f2 u = z * c1[L];
-                            const f2 pn = u * pc - pp * c2[L];
-                            pp = pc;
-                            pc = pn;
-                        }
-                    } else {
-                        float ph[2];
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const float ze = e ? z.y : z.x;
-                            const float az = fabsf(ze);
-                            ex[e] = az > 1.0f;
-                            const float exc = az - 1.0f;
-                            const bool neg = ze < 0.0f;
-                            float phs = rr.cf[0], pp = 1.0f, pc = ze;
-#pragma unroll
-                            for (int L = 1; L < NP; ++L) {
-                                float ee = 1.0f + chf[L] * exc;
-                                ee = (neg && (L & 1)) ? -ee : ee;
-                                const float sel = ex[e] ? ee : pc;
-                                const float term = rr.cf[L] * sel;
-                                phs = phs + term;
-                                const float u = c1[L] * ze;
-                                const float pn = u * pc - c2[L] * pp;
-                                pp = pc;
-                                pc = pn;
-                            }
-                            ph[e] = phs;
-                        }
-                        phi = f2{ph[0], ph[1]};
-                    }
-                    const f2 fb = SS[p] - f2{rr.sref, rr.sref};
-                    float vout[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int g = 2 * p + e;
-                        vout[e] = ((dq & bad) == 0) ? (e ? phi.y : phi.x) : (e ? fb.y : fb.x);
-                        const bool first = (g == 0) && a.do_not_flag_first;
-                        const uint32_t qg = ((g < 4 ? w0 : w1) >> (8 * (g & 3)));
-                        if (!first && ex[e] && (qg & DQ_SATURATED) == 0) dq |= DQ_NO_LIN_CORR;
-                    }
-                    f2 xv = {vout[0], vout[1]};
-                    if (act) xv = xv * rr.gain;
-                    xs[p * 4 * C2_COLS] = col_ok ? xv : f2{0.0f, 0.0f};
-                } else if (do_a) {
-                    xs[p * 4 * C2_COLS] = f2{0.0f, 0.0f};
-                }
-            }
-            if (do_a) {
-                const bool keep = a_full && col_ok;
-                DQ[slot * C2_COLS + col] = keep ? dq : 0u;
-                QS[slot * C2_COLS + col] = keep ? uint2{w0, w1} : uint2{0u, 0u};
-            }
             CH_T(2)
             C2_SYNC();
             CH_T(3)
@@ -427,7 +462,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
 #pragma unroll
                 for (int p0 = 0; p0 < GP; ++p0) {
                     fetch_coefs(r + 4, p0 * CO_STEP, (p0 * CO_STEP + CO_STEP < NCO) ? p0 * CO_STEP + CO_STEP : NCO, rr);
-                    if (do_c) {
+                    if (do_c && !(dbg & 1)) {
                         const f2 *xb = X2 + p0 * 4 * C2_COLS;
                         const f2 *xm[1] = {xb + sm * C2_COLS}, *x0[1] = {xb + s0 * C2_COLS}, *xp[1] = {xb + sp * C2_COLS};
                         f2 f[1], xc[1];
@@ -442,7 +477,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             }
             CH_T(5)
             // ---- T: flag propagation (fitting.py:339-353), finish and stores of pixel (yt, c) from the fit waves' results
-            if (emit) {
+            if (emit && !(dbg & 8)) {
                 const float4 tr = TR[(yt & 1) * C2_COLS + col];
                 float s = tr.x, er = tr.y, ep = tr.z;
                 const uint32_t jmask = __float_as_uint(tr.w);
@@ -533,7 +568,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                     f2 xc[NB], val[NB];
 #pragma unroll
                     for (int b = 0; b < NB; ++b) val[b] = xc[b] = X2[((p0 + b) * 4 + sx) * C2_COLS + col];
-                    if (act) {
+                    if (act && !(dbg & 2)) {
                         const f2 *om[NB], *o0[NB], *op[NB];
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
@@ -585,10 +620,14 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 float s, er, ep;
                 uint32_t jmask = 0;
                 const bool unsat = (qe[G - 1] & DQ_SATURATED) == 0;
-                fit_full_pk<G>(dpair, h, fc0, v0, a.dense, kvals + v0.k_ofs, diffs + v0.diff_ofs, e_gain, e_read,
-                               unsat && act, guard, s, er, ep, jmask);
-                if (__any((anyq & DQ_SATURATED) != 0))
-                    trunc_layers<G, G - 1>(d, qe, h, vars, kvals, diffs, e_gain, e_read, act, guard, s, er, ep, jmask);
+                if (dbg & 4) {
+                    s = d[0], er = e_read, ep = e_gain;
+                } else {
+                    fit_full_pk<G>(dpair, h, fc0, v0, a.dense, kvals + v0.k_ofs, diffs + v0.diff_ofs, e_gain, e_read,
+                                   unsat && act, guard, s, er, ep, jmask);
+                    if (__any((anyq & DQ_SATURATED) != 0))
+                        trunc_layers<G, G - 1>(d, qe, h, vars, kvals, diffs, e_gain, e_read, act, guard, s, er, ep, jmask);
+                }
                 TR[(r & 1) * C2_COLS + col] = float4{s, er, ep, __uint_as_float(jmask)};
             }
             CH_T(6)
