@@ -48,6 +48,23 @@ __device__ __forceinline__ unsigned c2_opaque(unsigned x) {
     return x;
 }
 
+// The kernel arguments re-read from the kernarg segment (scalar loads from the constant address space) through a
+// pointer made opaque once per phase: the ~25 pointers and sizes of ChainArgs then live in scalar registers only
+// from their first to their last use inside a phase, instead of all being loop invariants that the register
+// allocator spills to VGPR lanes (v_readlane/v_writelane are vector-ALU instructions with scalar hazards).
+struct C2KernArgs {  // the kernel's argument list as it lies in the kernarg segment
+    ChainArgs a;
+    const RipPlanHeader *h;
+    const RipVariant *vars;
+    const float *kvals;
+    const RipDiff *diffs;
+    double guard;
+};
+__device__ __forceinline__ const RIP_K C2KernArgs *c2_args(const RIP_K C2KernArgs *p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 template <int NP, int G>
 __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
                                                                const RipVariant *__restrict__ vars,
@@ -63,6 +80,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
     float4 *TR = reinterpret_cast<float4 *>(QS + 4 * C2_COLS);      // [2][C2_COLS] slope, err_read, err_poisson, jump mask
     double *LN = reinterpret_cast<double *>(TR + 2 * C2_COLS);      // [3][G][2] channel lines of this strip
 
+    // ChainArgs is the first kernel argument: it sits at offset 0 of the kernarg segment
+    const RIP_K C2KernArgs *kargs = (const RIP_K C2KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const int tid = threadIdx.x;
 #ifdef C2_DBG
     const int dbg = a.dbg;  // timing experiments only (tools/gpu_checks/phase_timing.py): bits switch phases off
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
 
     // coefficient loader: raw loads at clamped source positions + validity mask for destination (y, c);
     // `want` is wave-uniform.  Planes are walked in memory order (plane = 3*(1+dy) + (1+dx)).
-    auto load_k = [&](int y, bool want, float (&kk)[9]) -> unsigned {
+    auto load_k = [&](const void *kern_base, int y, bool want, float (&kk)[9]) -> unsigned {
         if (dbg & 128) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) kk[k] = (k == 0) ? 1.0f : 0.001f;
@@ -154,7 +173,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             rowoff[dyi] = (size_t)((unsigned)min(max(sy, 0), ny - 1) * row4);
         }
         unsigned rowbits = 0;
-        const char *kb = reinterpret_cast<const char *>(kern);
+        const char *kb = reinterpret_cast<const char *>(kern_base);
 #pragma unroll
         for (int p = 0; p < 9; ++p) {
             const int dy = p / 3 - 1, dx = p % 3 - 1;
@@ -212,15 +231,15 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
         };
         // The same loads in pieces, issued between blocks of arithmetic (scheduling fences keep them there): a burst of
         // 46 loads per wave from all waves at once saturates the CU's address unit while the vector ALUs idle.
-        auto fetch_groups = [&](int y, int g0, int g1, RowRegs<NP, G> &rr) {
+        auto fetch_groups = [&](const RIP_K ChainArgs *ka, int y, int g0, int g1, RowRegs<NP, G> &rr) {
             if (dbg & 64) return;
             __builtin_amdgcn_sched_barrier(0);
             const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
             const unsigned o4 = c2_opaque(cc4), o2 = c2_opaque(cc2), o1 = c2_opaque(cc1);
-            const char *sb = reinterpret_cast<const char *>(d16) + (size_t)(yl * (row4 >> 1)) + (size_t)g0 * (pl4 >> 1);
-            const char *qb = reinterpret_cast<const char *>(gdq) + (size_t)(yl * (row4 >> 2)) + (size_t)g0 * npix;
-            const char *db = reinterpret_cast<const char *>(dark) + (size_t)(yl * row4) + (size_t)g0 * pl4;
-            const char *bb = reinterpret_cast<const char *>(bias) + (size_t)(yl * row4) + (size_t)g0 * pl4;
+            const char *sb = reinterpret_cast<const char *>(ka->data) + (size_t)(yl * (row4 >> 1)) + (size_t)g0 * (pl4 >> 1);
+            const char *qb = reinterpret_cast<const char *>(ka->gdq) + (size_t)(yl * (row4 >> 2)) + (size_t)g0 * npix;
+            const char *db = reinterpret_cast<const char *>(ka->dark_data) + (size_t)(yl * row4) + (size_t)g0 * pl4;
+            const char *bb = reinterpret_cast<const char *>(ka->bias) + (size_t)(yl * row4) + (size_t)g0 * pl4;
 #pragma unroll
             for (int g = g0; g < g1; ++g) {
                 rr.S[g] = *reinterpret_cast<const uint16_t *>(sb + o2);
@@ -235,12 +254,12 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             __builtin_amdgcn_sched_barrier(0);
         };
         // planes i0..i1-1 of [cf[0..NP-1], Smin, Smax, Sref, dq, gain]
-        auto fetch_coefs = [&](int y, int i0, int i1, RowRegs<NP, G> &rr) {
+        auto fetch_coefs = [&](const RIP_K ChainArgs *ka, int y, int i0, int i1, RowRegs<NP, G> &rr) {
             if (dbg & 64) return;
             __builtin_amdgcn_sched_barrier(0);
             const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
             const unsigned o4 = c2_opaque(cc4);
-            const char *pb = reinterpret_cast<const char *>(planes) + (size_t)(yl * row4) + (size_t)i0 * pl4;
+            const char *pb = reinterpret_cast<const char *>(ka->planes) + (size_t)(yl * row4) + (size_t)i0 * pl4;
 #pragma unroll
             for (int i = i0; i < i1; ++i) {
                 if (i < NP)
@@ -265,6 +284,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
         fetch_row(R0 - 2, rr);
         const int start = KLD(h->start);
         for (int r = R0 - 5; r <= R1; ++r) {
+            const RIP_K ChainArgs *ka = &c2_args(kargs)->a;  // S1 copy of the argument block
             const int yi = r + 3, yc = r + 2, yt = r - 1;
             const bool do_a = (yi >= R0 - 2) && (yi <= R1 + 1);
             const bool do_c = (yc >= R0 - 1) && (yc <= R1);
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             {
                 const int yl = min(max(yi, 0), ny - 1);
 #pragma unroll
-                for (int g = 0; g < G; ++g) rc[g] = KLD(a.rowcorr[g * ny + yl]);
+                for (int g = 0; g < G; ++g) rc[g] = KLD(ka->rowcorr[g * ny + yl]);
             }
             const bool a_full = do_a && yi >= 0 && yi < ny;  // wave-uniform
             // A: two pairs of groups at a time -- reference-pixel/bias arithmetic and z of both pairs, then their two
@@ -340,7 +360,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                     for (int b = 0; b < PB; ++b) zz[b] = SS[b] = f2{0.0f, 0.0f};
                 }
                 // raw values of these groups of the next row (this row's are consumed)
-                fetch_groups(r + 4, 2 * pb, 2 * (pb + PB), rr);
+                fetch_groups(ka, r + 4, 2 * pb, 2 * (pb + PB), rr);
                 if (a_full && (dbg & 16)) {
 #pragma unroll
                     for (int b = 0; b < PB; ++b) xs[(pb + b) * 4 * C2_COLS] = zz[b] + f2{1000.0f, 1100.0f};
@@ -432,25 +452,26 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             // loads consumed after the barrier: IPC coefficients of row yc (for C) and the calibration planes of the
             // tail row yt; issued here so that their registers are not live during A
             float kC[9];
-            const unsigned vC = load_k(yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
+            const unsigned vC = load_k(ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
             const unsigned ytc = (unsigned)min(max(yt, 0), ny - 1);
             const size_t t_row4 = (size_t)(ytc * row4);             // byte offset of the tail row in an f32 plane (uniform)
             const size_t pe_row = (size_t)(ytc * (unsigned)nx);     // element offset of the tail row
-            const char *tb = reinterpret_cast<const char *>(planes) + t_row4;
+            const char *tb = reinterpret_cast<const char *>(ka->planes) + t_row4;
             const unsigned t4 = c2_opaque(cc4);
             const float e_dark = *reinterpret_cast<const float *>(tb + (size_t)(NP + 6) * pl4 + t4);
             const uint32_t e_ff = *reinterpret_cast<const uint32_t *>(tb + (size_t)(NP + 8) * pl4 + t4);
-            const uint32_t e_pdq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(a.pdq) + t_row4 + t4);
+            const uint32_t e_pdq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ka->pdq) + t_row4 + t4);
             // flat == null: read the gain plane instead (value unused), keeps the loads in one straight-line block
-            const char *fb = a.flat ? reinterpret_cast<const char *>(a.flat) : reinterpret_cast<const char *>(planes);
+            const char *fb = ka->flat ? reinterpret_cast<const char *>(ka->flat) : reinterpret_cast<const char *>(ka->planes);
             const float e_flat_raw = *reinterpret_cast<const float *>(fb + t_row4 + t4);
-            const float e_flat = a.flat ? e_flat_raw : 1.0f;
-            const char *ddb = a.dark_dq ? reinterpret_cast<const char *>(a.dark_dq) : reinterpret_cast<const char *>(planes);
+            const float e_flat = ka->flat ? e_flat_raw : 1.0f;
+            const char *ddb = ka->dark_dq ? reinterpret_cast<const char *>(ka->dark_dq) : reinterpret_cast<const char *>(ka->planes);
             const uint32_t e_ddq_raw = *reinterpret_cast<const uint32_t *>(ddb + t_row4 + t4);
-            const uint32_t e_ddq = a.dark_dq ? e_ddq_raw : 0u;
+            const uint32_t e_ddq = ka->dark_dq ? e_ddq_raw : 0u;
             CH_T(2)
             C2_SYNC();
             CH_T(3)
+            const RIP_K ChainArgs *kb2 = &c2_args(kargs)->a;  // S2 copy
             // ---- S2: issue the raw loads of row r+4 (consumed in S1 of the next step), then C of row yc
             CH_T(4)
             {
@@ -461,7 +482,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 const int so = (yc + 3000) % 3;
 #pragma unroll
                 for (int p0 = 0; p0 < GP; ++p0) {
-                    fetch_coefs(r + 4, p0 * CO_STEP, (p0 * CO_STEP + CO_STEP < NCO) ? p0 * CO_STEP + CO_STEP : NCO, rr);
+                    fetch_coefs(kb2, r + 4, p0 * CO_STEP, (p0 * CO_STEP + CO_STEP < NCO) ? p0 * CO_STEP + CO_STEP : NCO, rr);
                     if (do_c && !(dbg & 1)) {
                         const f2 *xb = X2 + p0 * 4 * C2_COLS;
                         const f2 *xm[1] = {xb + sm * C2_COLS}, *x0[1] = {xb + s0 * C2_COLS}, *xp[1] = {xb + sp * C2_COLS};
@@ -473,7 +494,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                         O12[(p0 * 3 + so) * C2_COLS + col] = (xc[0] + xc[0]) - f[0];
                     }
                 }
-                if (GP * CO_STEP < NCO) fetch_coefs(r + 4, GP * CO_STEP, NCO, rr);
+                if (GP * CO_STEP < NCO) fetch_coefs(kb2, r + 4, GP * CO_STEP, NCO, rr);
             }
             CH_T(5)
             // ---- T: flag propagation (fitting.py:339-353), finish and stores of pixel (yt, c) from the fit waves' results
@@ -486,8 +507,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
 #pragma unroll
                 for (int g = 0; g < G; ++g) qe[g] = ((g < 4 ? t_q.x : t_q.y) >> (8 * (g & 3))) & 0xffu;
                 uint32_t pdq =
-                    propagate_flags<G>(qe, jmask, start, e_pdq | t_dq, a.gdq_out ? a.gdq_out + pe_row : nullptr, npix, c2_opaque(cc1));
-                if (a.finish) {
+                    propagate_flags<G>(qe, jmask, start, e_pdq | t_dq, kb2->gdq_out ? kb2->gdq_out + pe_row : nullptr, npix, c2_opaque(cc1));
+                if (kb2->finish) {
                     float err = hypot_f32(er, ep);
                     float vp = ep * ep;
                     if (!act) {
@@ -495,13 +516,13 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                         err = 0.0f;
                         vp = 0.0f;
                     }
-                    if (act && a.dark_rate) s = s - e_dark;
+                    if (act && kb2->dark_rate) s = s - e_dark;
                     if (act) pdq |= e_ddq;
                     float ep2 = sqrtf(vp);
                     const float e2 = err * err;
                     const float p2 = ep2 * ep2;
                     float er2 = sqrtf(clip_lo<float>(e2 - p2, 0.0f));
-                    if (a.flat) {
+                    if (kb2->flat) {
                         pdq |= e_ff;
                         if (__all(rcp_safe(e_flat) && fabsf(s) < 1e18f && fabsf(er2) < 1e18f && fabsf(ep2) < 1e18f &&
                                   (s == 0.0f || fabsf(s) > 1e-18f) && (er2 == 0.0f || er2 > 1e-18f) &&
@@ -520,10 +541,10 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                     ep = ep2;
                 }
                 const unsigned w4 = c2_opaque(cc4);
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(a.slope) + t_row4 + w4) = s;
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(a.err_read) + t_row4 + w4) = er;
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(a.err_poisson) + t_row4 + w4) = ep;
-                *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.pdq_out) + t_row4 + w4) = pdq;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(kb2->slope) + t_row4 + w4) = s;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(kb2->err_read) + t_row4 + w4) = er;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(kb2->err_poisson) + t_row4 + w4) = ep;
+                *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kb2->pdq_out) + t_row4 + w4) = pdq;
             }
             CH_T(6)
             C2_SYNC();
@@ -540,10 +561,11 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
         float gain_next = 1.0f;
         for (int r = R0 - 5; r <= R1; ++r) {
             const bool emit = (r >= R0) && (r < R1) && col >= 2 && col < C2_COLS - 2 && col_ok;
+            const RIP_K C2KernArgs *kf = c2_args(kargs);  // S1 copy of the argument block
             const unsigned rc_ = (unsigned)min(max(r, 0), ny - 1);
             const unsigned pe = rc_ * (unsigned)nx + cc1;
             // ---- S1: read noise of the pixel (used by the fit), then the second IPC iterate of row r
-            const float e_read = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(planes) +
+            const float e_read = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(kf->a.planes) +
                                                                   (size_t)(NP + 5) * pl4 + (size_t)(rc_ * row4) + c2_opaque(cc4));
             const float e_gain = gain_next;
             float d[G];
@@ -600,19 +622,20 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             CH_T(2)
             C2_SYNC();
             CH_T(3)
+            const RIP_K C2KernArgs *kg = c2_args(kargs);  // S2 copy
             // ---- S2: coefficients and gain of the next row's O2, then the fit of pixel (r, c) -> T ring
             float kN[9];
             const bool next_on = (r + 1 >= R0) && (r + 1 < R1) && col >= 2 && col < C2_COLS - 2;
-            const unsigned vN = load_k(r + 1, next_on, kN);
-            gain_next = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(planes) + (size_t)(NP + 4) * pl4 +
+            const unsigned vN = load_k(kg->a.kern, r + 1, next_on, kN);
+            gain_next = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(kg->a.planes) + (size_t)(NP + 4) * pl4 +
                                                          (size_t)((unsigned)min(max(r + 1, 0), ny - 1) * row4) + c2_opaque(cc4));
             CH_T(4)
             C2_DRAIN()
             CH_T(5)
             if (emit) {
-                if (a.cube_out) {
+                if (kg->a.cube_out) {
 #pragma unroll
-                    for (int g = 0; g < G; ++g) a.cube_out[(unsigned)g * npix + pe] = d[g];
+                    for (int g = 0; g < G; ++g) kg->a.cube_out[(unsigned)g * npix + pe] = d[g];
                 }
                 uint32_t anyq = 0;
 #pragma unroll
@@ -623,10 +646,11 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 if (dbg & 4) {
                     s = d[0], er = e_read, ep = e_gain;
                 } else {
-                    fit_full_pk<G>(dpair, h, fc0, v0, a.dense, kvals + v0.k_ofs, diffs + v0.diff_ofs, e_gain, e_read,
-                                   unsat && act, guard, s, er, ep, jmask);
+                    fit_full_pk<G>(dpair, kg->h, fc0, v0, kg->a.dense, kg->kvals + v0.k_ofs, kg->diffs + v0.diff_ofs, e_gain,
+                                   e_read, unsat && act, kg->guard, s, er, ep, jmask);
                     if (__any((anyq & DQ_SATURATED) != 0))
-                        trunc_layers<G, G - 1>(d, qe, h, vars, kvals, diffs, e_gain, e_read, act, guard, s, er, ep, jmask);
+                        trunc_layers<G, G - 1>(d, qe, kg->h, kg->vars, kg->kvals, kg->diffs, e_gain, e_read, act, kg->guard, s, er, ep,
+                                               jmask);
                 }
                 TR[(r & 1) * C2_COLS + col] = float4{s, er, ep, __uint_as_float(jmask)};
             }
