@@ -311,7 +311,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             const float smin = rr.smin;
             const float span = rr.smax - smin;
             const bool fastdiv = __all(rcp_safe(span));
-            const float rspan = 1.0f / span;
+            const float rspan = rip_rcp_mid(span);  // used only when every lane passes rcp_safe (2^-59.8 .. 2^59.8)
             const double yd = (double)yi;
             constexpr int PB = (GP % 2 == 0) ? 2 : 1;  // pairs per block
 #pragma unroll
@@ -503,11 +503,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 float s = tr.x, er = tr.y, ep = tr.z;
                 const uint32_t jmask = __float_as_uint(tr.w);
                 const bool act = col_act && yt >= ay0 && yt < ay1;
-                uint32_t qe[G];
-#pragma unroll
-                for (int g = 0; g < G; ++g) qe[g] = ((g < 4 ? t_q.x : t_q.y) >> (8 * (g & 3))) & 0xffu;
-                uint32_t pdq =
-                    propagate_flags<G>(qe, jmask, start, e_pdq | t_dq, kb2->gdq_out ? kb2->gdq_out + pe_row : nullptr, npix, c2_opaque(cc1));
+                uint8_t *gq = kb2->gdq_out ? kb2->gdq_out + pe_row : nullptr;
+                uint32_t pdq = propagate_flags_packed<G>(t_q.x, t_q.y, jmask, start, e_pdq | t_dq, gq, npix, c2_opaque(cc1));
                 if (kb2->finish) {
                     float err = hypot_f32(er, ep);
                     float vp = ep * ep;
@@ -518,16 +515,26 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                     }
                     if (act && kb2->dark_rate) s = s - e_dark;
                     if (act) pdq |= e_ddq;
-                    float ep2 = sqrtf(vp);
+                    // sqrt(ep*ep) == ep exactly when ep*ep neither overflows nor goes subnormal (fpcheck.hip C)
+                    float ep2;
+                    if (__all(vp == 0.0f || rip_mid_range(vp)))
+                        ep2 = act ? ep : 0.0f;
+                    else
+                        ep2 = sqrtf(vp);
                     const float e2 = err * err;
                     const float p2 = ep2 * ep2;
-                    float er2 = sqrtf(clip_lo<float>(e2 - p2, 0.0f));
+                    const float rdiff = clip_lo<float>(e2 - p2, 0.0f);
+                    float er2;
+                    if (__all(rdiff == 0.0f || rip_mid_range(rdiff)))  // rip_sqrt_mid(0) = 0
+                        er2 = rip_sqrt_mid(rdiff);
+                    else
+                        er2 = sqrtf(rdiff);
                     if (kb2->flat) {
                         pdq |= e_ff;
                         if (__all(rcp_safe(e_flat) && fabsf(s) < 1e18f && fabsf(er2) < 1e18f && fabsf(ep2) < 1e18f &&
                                   (s == 0.0f || fabsf(s) > 1e-18f) && (er2 == 0.0f || er2 > 1e-18f) &&
                                   (ep2 == 0.0f || ep2 > 1e-18f))) {
-                            const float rflat = 1.0f / e_flat;
+                            const float rflat = rip_rcp_mid(e_flat);
                             s = div_rcp(s, e_flat, rflat);
                             er2 = div_rcp(er2, e_flat, rflat);
                             ep2 = div_rcp(ep2, e_flat, rflat);
@@ -570,18 +577,16 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             const float e_gain = gain_next;
             float d[G];
             f2 dpair[GP];
-            uint32_t qe[G];
+            uint2 qw = {0u, 0u};  // the pixel's groupdq bytes, packed
             const bool act = emit && col_act && r >= ay0 && r < ay1;
             CH_T(0)
             C2_DRAIN()
             CH_T(1)
             if (emit) {
                 const int sx = r & 3;
-                const uint2 qw = QS[sx * C2_COLS + col];
-#pragma unroll
-                for (int g = 0; g < G; ++g) qe[g] = ((g < 4 ? qw.x : qw.y) >> (8 * (g & 3))) & 0xffu;
+                qw = QS[sx * C2_COLS + col];
                 const bool fastdiv = __all(rcp_safe(e_gain) || !act);
-                const float rgain = 1.0f / e_gain;
+                const float rgain = rip_rcp_mid(e_gain);
                 const bool all = __all(vF == 0x1ffu || !act);
                 const int om_ = (r - 1 + 3000) % 3, o0_ = (r + 3000) % 3, op_ = (r + 1 + 3000) % 3;
                 constexpr int NB = (GP % 2 == 0) ? 2 : 1;
@@ -637,20 +642,22 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
 #pragma unroll
                     for (int g = 0; g < G; ++g) kg->a.cube_out[(unsigned)g * npix + pe] = d[g];
                 }
-                uint32_t anyq = 0;
-#pragma unroll
-                for (int g = 0; g < G; ++g) anyq |= qe[g];
+                const bool anysat = ((qw.x | qw.y) & 0x02020202u) != 0u;
                 float s, er, ep;
                 uint32_t jmask = 0;
-                const bool unsat = (qe[G - 1] & DQ_SATURATED) == 0;
+                const bool unsat = ((((G - 1) < 4 ? qw.x : qw.y) >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
                 if (dbg & 4) {
                     s = d[0], er = e_read, ep = e_gain;
                 } else {
                     fit_full_pk<G>(dpair, kg->h, fc0, v0, kg->a.dense, kg->kvals + v0.k_ofs, kg->diffs + v0.diff_ofs, e_gain,
                                    e_read, unsat && act, kg->guard, s, er, ep, jmask);
-                    if (__any((anyq & DQ_SATURATED) != 0))
+                    if (__any(anysat)) {
+                        uint32_t qe[G];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) qe[g] = ((g < 4 ? qw.x : qw.y) >> (8 * (g & 3))) & 0xffu;
                         trunc_layers<G, G - 1>(d, qe, kg->h, kg->vars, kg->kvals, kg->diffs, e_gain, e_read, act, kg->guard, s, er, ep,
                                                jmask);
+                    }
                 }
                 TR[(r & 1) * C2_COLS + col] = float4{s, er, ep, __uint_as_float(jmask)};
             }

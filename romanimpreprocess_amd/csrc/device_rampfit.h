@@ -40,6 +40,34 @@ __device__ __forceinline__ float hypot_f32(float a, float b) {
     return (float)sqrt(da * da + db * db);
 }
 
+// Short forms of IEEE f32 reciprocal and square root, bit-identical to 1.0f/b and sqrtf(x) for 2^-60 <= |.| <= 2^60
+// (tools/gpu_checks/fpcheck.hip: exhaustive over all such floats, 0 mismatches).  Callers vote on the range with
+// rip_mid_range() over the wave and fall back to the compiler's full expansion otherwise.
+__device__ __forceinline__ bool rip_mid_range(float x) {  // false for NaN, Inf, 0, subnormals, |x| outside 2^-59..2^59
+    const float ax = fabsf(x);
+    return ax > 1.8e-18f && ax < 5.7e17f;
+}
+__device__ __forceinline__ float rip_rcp_mid(float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e = fmaf(-b, r0, 1.0f);
+    return fmaf(e, r0, r0);
+}
+__device__ __forceinline__ float div_rcp_(float a, float b, float rb) {  // a / b from the exact reciprocal (chain_kernel.h)
+    const float q0 = a * rb;
+    const float r0 = fmaf(-b, q0, a);
+    const float q1 = fmaf(r0, rb, q0);
+    const float r1 = fmaf(-b, q1, a);
+    return fmaf(r1, rb, q1);
+}
+__device__ __forceinline__ float rip_sqrt_mid(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = fmaf(-sd, s, x), ru = fmaf(-su, s, x);
+    float r = (rd <= 0.0f) ? sd : s;
+    r = (ru > 0.0f) ? su : r;
+    return r;
+}
+
 template <typename T>
 __device__ __forceinline__ T clip_lo(T x, T lo) {  // np.clip(x, lo, None): NaN stays NaN
     return x < lo ? lo : x;
@@ -351,11 +379,20 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
         s = s + prod.y;
     }
     const float gc = clip2<float>(gain, 1e-4f, 1e4f);
-    const float dv = clip_lo<float>(s / gc, 0.0f);
+    // s / gc and sqrt(pv): short exact forms when every lane is in their validated range (see rip_rcp_mid)
+    float dvq;
+    if (__all(rip_mid_range(s) && rip_mid_range(gc)))
+        dvq = div_rcp_(s, gc, rip_rcp_mid(gc));
+    else
+        dvq = s / gc;
+    const float dv = clip_lo<float>(dvq, 0.0f);
     const float pv = clip_lo<float>(v.coef * dv, 0.0f);
     s_out = s;
     er_out = rn * v.rfac;
-    ep_out = sqrtf(pv);
+    if (__all(pv == 0.0f || rip_mid_range(pv)))  // rip_sqrt_mid(0) = 0
+        ep_out = rip_sqrt_mid(pv);
+    else
+        ep_out = sqrtf(pv);
     if (!__any(flag)) return;
 
     const float xc = clip2<float>(s, fc.ia, fc.ib);
@@ -489,5 +526,44 @@ __device__ __forceinline__ uint32_t propagate_flags(const uint32_t (&qe)[G], uin
     const uint32_t q_early = start ? qe[(G > 2) ? 2 : G - 1] : qe[1];  // rdq[1 + start]
     if (q_early & DQ_SATURATED) pdq2 |= DQ_DO_NOT_USE;
     pdq2 |= any_sat;
+    return (pdq_in & DQ_REFERENCE_PIXEL) ? pdq_in : (pdq_in | pdq2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// propagate_flags on the pixel's group flags PACKED four to a word (w0 = groups 0-3, w1 = groups 4-7, bytes of
+// groups >= G are zero): the same results with byte-parallel logic instead of G unpack / test / select sequences.
+//   gdq_row  uniform byte pointer to element (group 0, row, column 0) of the output group flags, or null
+__device__ __forceinline__ uint32_t rip_spread_bit1(uint32_t t) {  // bytes holding 0x02 -> 0xFF, others (0x00) -> 0x00
+    t |= t >> 1;
+    t |= t << 2;
+    t |= t << 4;
+    return t;
+}
+template <int G>
+__device__ __forceinline__ uint32_t propagate_flags_packed(uint32_t w0, uint32_t w1, uint32_t jmask, int start,
+                                                           uint32_t pdq_in, uint8_t *gdq_row, unsigned gstride,
+                                                           unsigned lane_off) {
+    static_assert(G > 4 && G <= 8, "two flag words");
+    constexpr uint32_t PAD1 = (G >= 8) ? 0u : (0x01010101u << (8 * (G - 4)));  // missing groups count as DO_NOT_USE
+    // bit i of jmask -> JUMP_DET (0x04) of byte i
+    const uint32_t rq0 = w0 | ((__umul24(jmask & 0xFu, 0x00204081u) & 0x01010101u) << 2);
+    const uint32_t rq1 = w1 | ((__umul24((jmask >> 4) & 0xFu, 0x00204081u) & 0x01010101u) << 2);
+    if (gdq_row) {  // uniform
+        uint8_t *p = gdq_row;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            *(p + lane_off) = (uint8_t)((g < 4 ? rq0 : rq1) >> (8 * (g & 3)));
+            p += gstride;
+        }
+    }
+    const uint32_t s0 = rq0 & 0x02020202u, s1 = rq1 & 0x02020202u;  // SATURATED bit of every group
+    const uint32_t u0 = rq0 & ~rip_spread_bit1(s0), u1 = rq1 & ~rip_spread_bit1(s1);  // flags of the unsaturated groups
+    uint32_t red = (u0 | u1) | (s0 | s1);  // OR over groups: bit 1 = any saturated, other bits = OR of the unsaturated
+    red |= red >> 16;
+    red |= red >> 8;
+    uint32_t pdq2 = red & 0xFEu;  // without DO_NOT_USE
+    const bool all_dnu = ((rq0 & (rq1 | PAD1)) & 0x01010101u) == 0x01010101u;
+    const bool early = ((w0 >> (8 * (1 + start))) & DQ_SATURATED) != 0;  // rdq[1 + start]
+    if (all_dnu || early) pdq2 |= DQ_DO_NOT_USE;
     return (pdq_in & DQ_REFERENCE_PIXEL) ? pdq_in : (pdq_in | pdq2);
 }
