@@ -172,7 +172,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             rok[dyi] = sy >= ay0 && sy < ay1;
             rowoff[dyi] = (size_t)((unsigned)min(max(sy, 0), ny - 1) * row4);
         }
-        unsigned rowbits = 0;
+        // terms by source row: dy = -1 -> k in {2, 7, 8}, dy = 0 -> {0, 3, 4}, dy = +1 -> {1, 5, 6}
+        const unsigned rowbits = (rok[0] ? 0x184u : 0u) | (rok[1] ? 0x019u : 0u) | (rok[2] ? 0x062u : 0u);
         const char *kb = reinterpret_cast<const char *>(kern_base);
 #pragma unroll
         for (int p = 0; p < 9; ++p) {
@@ -182,7 +183,6 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             const int k = (dy == 0) ? (dx == 0 ? 0 : dx == 1 ? 3 : 4) : (dy == 1) ? (dx == 0 ? 1 : dx == 1 ? 5 : 6)
                                                                                   : (dx == 0 ? 2 : dx == 1 ? 7 : 8);
             kk[k] = *reinterpret_cast<const float *>(kb + rowoff[dy + 1] + ox[dx + 1]);
-            if (rok[dy + 1]) rowbits |= 1u << k;
             kb += pl4;
         }
         const unsigned um = (want && y >= ay0 && y < ay1) ? rowbits : 0u;
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
         RowRegs<NP, G> rr;
         fetch_row(R0 - 2, rr);
         const int start = KLD(h->start);
-        for (int r = R0 - 5; r <= R1; ++r) {
+        int so_c = (R0 - 5 + 2 + 3000) % 3;  // O1 ring slot of row yc = r + 2
+        for (int r = R0 - 5; r <= R1; ++r, so_c = (so_c == 2) ? 0 : so_c + 1) {
             const RIP_K ChainArgs *ka = &c2_args(kargs)->a;  // S1 copy of the argument block
             const int yi = r + 3, yc = r + 2, yt = r - 1;
             const bool do_a = (yi >= R0 - 2) && (yi <= R1 + 1);
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 // the next row are requested between the pairs, unconditionally (see above)
                 const bool all = __all(vC == 0x1ffu || vC == 0u);
                 const int sm = (yc - 1) & 3, s0 = yc & 3, sp = (yc + 1) & 3;
-                const int so = (yc + 3000) % 3;
+                const int so = so_c;
 #pragma unroll
                 for (int p0 = 0; p0 < GP; ++p0) {
                     fetch_coefs(kb2, r + 4, p0 * CO_STEP, (p0 * CO_STEP + CO_STEP < NCO) ? p0 * CO_STEP + CO_STEP : NCO, rr);
@@ -566,7 +567,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
         const RipVariant v0 = rip_load_variant(vars, 0);
     const RipFitConst fc0 = rip_fit_const(h);
         float gain_next = 1.0f;
-        for (int r = R0 - 5; r <= R1; ++r) {
+        int o0_r = (R0 - 5 + 3000) % 3;  // O1 ring slot of row r
+        for (int r = R0 - 5; r <= R1; ++r, o0_r = (o0_r == 2) ? 0 : o0_r + 1) {
             const bool emit = (r >= R0) && (r < R1) && col >= 2 && col < C2_COLS - 2 && col_ok;
             const RIP_K C2KernArgs *kf = c2_args(kargs);  // S1 copy of the argument block
             const unsigned rc_ = (unsigned)min(max(r, 0), ny - 1);
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 const bool fastdiv = __all(rcp_safe(e_gain) || !act);
                 const float rgain = rip_rcp_mid(e_gain);
                 const bool all = __all(vF == 0x1ffu || !act);
-                const int om_ = (r - 1 + 3000) % 3, o0_ = (r + 3000) % 3, op_ = (r + 1 + 3000) % 3;
+                const int o0_ = o0_r, om_ = (o0_r == 0) ? 2 : o0_r - 1, op_ = (o0_r == 2) ? 0 : o0_r + 1;
                 constexpr int NB = (GP % 2 == 0) ? 2 : 1;
 #pragma unroll
                 for (int p0 = 0; p0 < GP; p0 += NB) {
