@@ -501,6 +501,7 @@ int rip_plan_create(rip_ctx *ctx, const rip_plan_desc *d, int *plan_id) {
         memset(&dn, 0, sizeof dn);
         for (int i = 0; i < G; ++i) dn.K2[i] = d->K[i];
         const RipVariant &v0 = p->variants[0];
+        double amin = 1e301;
         for (int k = 0; k < v0.ndiff; ++k) {
             const RipDiff &df = p->diffs[v0.diff_ofs + k];
             const int i = df.i, di = df.j - df.i, ps = 2 * (i / 2) + (di - 1), e = i & 1;
@@ -509,8 +510,17 @@ int rip_plan_create(rip_ctx *ctx, const rip_plan_desc *d, int *plan_id) {
             dn.pairs[ps].inv_dt[e] = df.inv_dt;
             dn.pairs[ps].A[e] = df.A;
             dn.pairs[ps].B[e] = df.B;
-            dn.pairs[ps].relerr[e] = df.relerr;
+            // acceptance factors of the packed fast path (device_rampfit.h, fit_full_pk): r = relerr + 4.1e-7 covers
+            // the variance approximation and the part of the difference's rounding that scales with the significance
+            const double r = (double)df.relerr + 4.1e-7;
+            if (r < 9.9e-3) {
+                dn.pairs[ps].k1[e] = std::nextafter((float)((1.0 / (1.0 - r)) * (1.0 + 4e-7)), INFINITY);
+            } else {  // never accepted: the exact path decides
+                dn.pairs[ps].k1[e] = INFINITY;
+            }
+            amin = (df.B >= 0.0f) ? std::fmin(amin, (double)df.A) : 0.0;
         }
+        dn.amin = (v0.ndiff > 0 && amin > 0.0 && amin < 1e300) ? (float)(amin * (1.0 - 1e-6)) : 0.0f;
         for (int ps = 0; ps < RIP_MAX_GROUPS; ++ps)
             for (int e = 0; e < 2; ++e) {
                 const int bit = 2 * ps + e;

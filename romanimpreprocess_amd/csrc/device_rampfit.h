@@ -347,7 +347,7 @@ __device__ __forceinline__ void rip_load_pair(RipDensePair &r, const RipDense *d
         r.inv_dt[e] = KLD(dn->pairs[ps].inv_dt[e]);
         r.A[e] = KLD(dn->pairs[ps].A[e]);
         r.B[e] = KLD(dn->pairs[ps].B[e]);
-        r.relerr[e] = KLD(dn->pairs[ps].relerr[e]);
+        r.k1[e] = KLD(dn->pairs[ps].k1[e]);
     }
 }
 
@@ -401,10 +401,18 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
     if (__any(need_log)) lx = need_log ? __logf(xc / fc.ia) : 0.0f;
     const float slope_th = fc.slope_th;
     const float sth32 = fc.sa32 + slope_th * lx;
+    // Acceptance test of the approximate significance sm (DESIGN.md "jump significance fast path"):
+    //   |sm - sme| <= r |sm| + t,  r = relerr + 4.1e-7 (host, folded into k1 >= 1/(1-r); k2 = 2 - k1 <= 1/(1+r)),
+    //   t = 8e-7 |s| rs  (rounding of num*inv_dt and of q - s, using |q| <= |delta| + |s|);  the threshold itself is
+    //   known to +-band0.  With thp + t > 0 and thm - t > 0 (checked per pixel through rsmax >= every rs):
+    //   sm > (thp + t) k1  => sure hit,   sm < (thm - t) k2  => surely no hit,   anything else (NaN included) -> exact pass.
     const float band0 = 2e-6f * fabsf(sth32) + 4e-6f * fabsf(slope_th) + 1e-30f;
     const float s2 = rn * rn;
-    const float abs_s = fabsf(s);
-    const bool force_exact = !(guard < 1e300);
+    const float s8 = fabsf(s) * 8.1e-7f;
+    const float thp = sth32 + band0, thm = sth32 - band0;
+    const float rsmax = __frsqrt_rn(KLD(dn->amin) * s2) * 1.000001f;
+    const bool pass = fmaf(s8, rsmax, band0) <= 0.5f * sth32;  // false for NaN, for amin == 0 and for sth32 <= 0
+    const bool lane_exact = !(guard < 1e300) || !pass;
     uint32_t jfast = 0, unsure_mask = 0;
     rf2 dB[GP];  // (d[2p+1], d[2p+2])
 #pragma unroll
@@ -425,17 +433,18 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
         const rf2 var = __builtin_elementwise_fma(rf2{r.B[0], r.B[1]}, rf2{dv, dv}, as2);
         const rf2 rs = {__frsqrt_rn(var.x), __frsqrt_rn(var.y)};
         const rf2 sm = delta * rs;
-        const rf2 asm_ = __builtin_elementwise_abs(sm);
-        const rf2 aq = __builtin_elementwise_abs(q) + abs_s;
-        const rf2 band = (asm_ * rf2{r.relerr[0], r.relerr[1]} + band0) + (aq * rs) * 4e-7f;
-        const rf2 dist = __builtin_elementwise_abs(sm - sth32);
+        const rf2 t = rs * s8;
+        const rf2 k1 = {r.k1[0], r.k1[1]};
+        const rf2 hiT = (t + thp) * k1;
+        const rf2 loT = (rf2{thm, thm} - t) * (rf2{2.0f, 2.0f} - k1);  // 2 - k1 <= 1 - r <= 1/(1+r)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if (!((vbits >> e) & 1u)) continue;  // plan-uniform
-            const bool hit = (e ? sm.y : sm.x) > sth32;
-            const bool unsure = force_exact || !((e ? dist.y : dist.x) > (e ? band.y : band.x));
+            const float sme = e ? sm.y : sm.x;
+            const bool hit = sme > (e ? hiT.y : hiT.x);
+            const bool nohit = sme < (e ? loT.y : loT.x);
             if (hit) jfast |= 1u << (2 * ps + e);
-            if (unsure) unsure_mask |= 1u << (2 * ps + e);
+            if (lane_exact || !(hit || nohit)) unsure_mask |= 1u << (2 * ps + e);
         }
     }
     // differences whose approximate significance is within its error band of the threshold (or NaN): redo them in

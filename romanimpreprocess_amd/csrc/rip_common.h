@@ -52,11 +52,13 @@ struct RipPlanHeader {
 // Dense, compile-time-indexable view of the FULL-ramp variant for the register-resident fit
 // (fit_full_regs): pair slot ps = 2*(i/2) + (di-1) holds the differences (i, i+di) and (i+1, i+1+di), i even.
 struct RipDensePair {
-    float inv_dt[2], A[2], B[2], relerr[2];  // per element e: difference (i+e, i+e+di)
+    float inv_dt[2], A[2], B[2];  // per element e: difference (i+e, i+e+di)
+    float k1[2];                   // k1 >= 1/(1-r), r = relative error bound of the approximate significance (2 - k1 <= 1/(1+r))
 };
 struct RipDense {
     uint32_t valid;                    // bit 2*ps + e: that difference is tested (fitting.py:225-229)
     int32_t kidx[2 * RIP_MAX_GROUPS];  // [2*ps + e] index into the compact diff table (exact path)
+    float amin;                        // min A over the tested differences (0: some B < 0 -> exact path everywhere)
     float K2[RIP_MAX_GROUPS];          // full-ramp weights
     RipDensePair pairs[RIP_MAX_GROUPS];
 };
