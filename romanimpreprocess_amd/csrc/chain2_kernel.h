@@ -77,8 +77,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
     f2 *O12 = X2 + GP * 4 * C2_COLS;                                // [GP][3][C2_COLS]  first Neumann iterate
     uint32_t *DQ = reinterpret_cast<uint32_t *>(O12 + GP * 3 * C2_COLS);  // [4][C2_COLS] linearity dq of the row
     uint2 *QS = reinterpret_cast<uint2 *>(DQ + 4 * C2_COLS);       // [4][C2_COLS] groupdq bytes of the pixel
-    float4 *TR = reinterpret_cast<float4 *>(QS + 4 * C2_COLS);      // [2][C2_COLS] slope, err_read, err_poisson, jump mask
-    double *LN = reinterpret_cast<double *>(TR + 2 * C2_COLS);      // [3][G][2] channel lines of this strip
+    double *LN = reinterpret_cast<double *>(QS + 4 * C2_COLS);      // [3][G][2] channel lines of this strip
 
     // ChainArgs is the first kernel argument: it sits at offset 0 of the kernarg segment
     const RIP_K C2KernArgs *kargs = (const RIP_K C2KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -282,14 +281,12 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
         constexpr int CO_STEP = (NCO + GP - 1) / GP;  // issued per pair of C
         RowRegs<NP, G> rr;
         fetch_row(R0 - 2, rr);
-        const int start = KLD(h->start);
         int so_c = (R0 - 5 + 2 + 3000) % 3;  // O1 ring slot of row yc = r + 2
         for (int r = R0 - 5; r <= R1; ++r, so_c = (so_c == 2) ? 0 : so_c + 1) {
             const RIP_K ChainArgs *ka = &c2_args(kargs)->a;  // S1 copy of the argument block
-            const int yi = r + 3, yc = r + 2, yt = r - 1;
+            const int yi = r + 3, yc = r + 2;
             const bool do_a = (yi >= R0 - 2) && (yi <= R1 + 1);
             const bool do_c = (yc >= R0 - 1) && (yc <= R1);
-            const bool emit = (yt >= R0) && (yt < R1) && col >= 2 && col < C2_COLS - 2 && col_ok;
             // ---- S1: A (linearity of row yi from rr), then the loads S2 consumes
             // per-row reference-pixel correction of the G groups: wave-uniform, scalar loads (constant address space)
             double rc[G];
@@ -442,33 +439,15 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                     for (int b = 0; b < PB; ++b) xs[(pb + b) * 4 * C2_COLS] = f2{0.0f, 0.0f};
                 }
             }
-            // the tail's dq words of pixel (yt, c), read before A reuses their ring slot
-            const uint2 t_q = QS[(yt & 3) * C2_COLS + col];
-            const uint32_t t_dq = DQ[(yt & 3) * C2_COLS + col];
             if (do_a) {
                 const bool keep = a_full && col_ok;
                 DQ[slot * C2_COLS + col] = keep ? dq : 0u;
                 QS[slot * C2_COLS + col] = keep ? uint2{w0, w1} : uint2{0u, 0u};
             }
-            // loads consumed after the barrier: IPC coefficients of row yc (for C) and the calibration planes of the
-            // tail row yt; issued here so that their registers are not live during A
+            // IPC coefficients of row yc, consumed by C after the barrier; issued here so that their registers are not live
+            // during A
             float kC[9];
             const unsigned vC = load_k(ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
-            const unsigned ytc = (unsigned)min(max(yt, 0), ny - 1);
-            const size_t t_row4 = (size_t)(ytc * row4);             // byte offset of the tail row in an f32 plane (uniform)
-            const size_t pe_row = (size_t)(ytc * (unsigned)nx);     // element offset of the tail row
-            const char *tb = reinterpret_cast<const char *>(ka->planes) + t_row4;
-            const unsigned t4 = c2_opaque(cc4);
-            const float e_dark = *reinterpret_cast<const float *>(tb + (size_t)(NP + 6) * pl4 + t4);
-            const uint32_t e_ff = *reinterpret_cast<const uint32_t *>(tb + (size_t)(NP + 8) * pl4 + t4);
-            const uint32_t e_pdq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ka->pdq) + t_row4 + t4);
-            // flat == null: read the gain plane instead (value unused), keeps the loads in one straight-line block
-            const char *fb = ka->flat ? reinterpret_cast<const char *>(ka->flat) : reinterpret_cast<const char *>(ka->planes);
-            const float e_flat_raw = *reinterpret_cast<const float *>(fb + t_row4 + t4);
-            const float e_flat = ka->flat ? e_flat_raw : 1.0f;
-            const char *ddb = ka->dark_dq ? reinterpret_cast<const char *>(ka->dark_dq) : reinterpret_cast<const char *>(ka->planes);
-            const uint32_t e_ddq_raw = *reinterpret_cast<const uint32_t *>(ddb + t_row4 + t4);
-            const uint32_t e_ddq = ka->dark_dq ? e_ddq_raw : 0u;
             CH_T(2)
             C2_SYNC();
             CH_T(3)
@@ -498,62 +477,6 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 if (GP * CO_STEP < NCO) fetch_coefs(kb2, r + 4, GP * CO_STEP, NCO, rr);
             }
             CH_T(5)
-            // ---- T: flag propagation (fitting.py:339-353), finish and stores of pixel (yt, c) from the fit waves' results
-            if (emit && !(dbg & 8)) {
-                const float4 tr = TR[(yt & 1) * C2_COLS + col];
-                float s = tr.x, er = tr.y, ep = tr.z;
-                const uint32_t jmask = __float_as_uint(tr.w);
-                const bool act = col_act && yt >= ay0 && yt < ay1;
-                uint8_t *gq = kb2->gdq_out ? kb2->gdq_out + pe_row : nullptr;
-                uint32_t pdq = propagate_flags_packed<G>(t_q.x, t_q.y, jmask, start, e_pdq | t_dq, gq, npix, c2_opaque(cc1));
-                if (kb2->finish) {
-                    float err = hypot_f32(er, ep);
-                    float vp = ep * ep;
-                    if (!act) {
-                        s = 0.0f;
-                        err = 0.0f;
-                        vp = 0.0f;
-                    }
-                    if (act && kb2->dark_rate) s = s - e_dark;
-                    if (act) pdq |= e_ddq;
-                    // sqrt(ep*ep) == ep exactly when ep*ep neither overflows nor goes subnormal (fpcheck.hip C)
-                    float ep2;
-                    if (__all(vp == 0.0f || rip_mid_range(vp)))
-                        ep2 = act ? ep : 0.0f;
-                    else
-                        ep2 = sqrtf(vp);
-                    const float e2 = err * err;
-                    const float p2 = ep2 * ep2;
-                    const float rdiff = clip_lo<float>(e2 - p2, 0.0f);
-                    float er2;
-                    if (__all(rdiff == 0.0f || rip_mid_range(rdiff)))  // rip_sqrt_mid(0) = 0
-                        er2 = rip_sqrt_mid(rdiff);
-                    else
-                        er2 = sqrtf(rdiff);
-                    if (kb2->flat) {
-                        pdq |= e_ff;
-                        if (__all(rcp_safe(e_flat) && fabsf(s) < 1e18f && fabsf(er2) < 1e18f && fabsf(ep2) < 1e18f &&
-                                  (s == 0.0f || fabsf(s) > 1e-18f) && (er2 == 0.0f || er2 > 1e-18f) &&
-                                  (ep2 == 0.0f || ep2 > 1e-18f))) {
-                            const float rflat = rip_rcp_mid(e_flat);
-                            s = div_rcp(s, e_flat, rflat);
-                            er2 = div_rcp(er2, e_flat, rflat);
-                            ep2 = div_rcp(ep2, e_flat, rflat);
-                        } else {
-                            s = s / e_flat;
-                            er2 = er2 / e_flat;
-                            ep2 = ep2 / e_flat;
-                        }
-                    }
-                    er = er2;
-                    ep = ep2;
-                }
-                const unsigned w4 = c2_opaque(cc4);
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(kb2->slope) + t_row4 + w4) = s;
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(kb2->err_read) + t_row4 + w4) = er;
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(kb2->err_poisson) + t_row4 + w4) = ep;
-                *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kb2->pdq_out) + t_row4 + w4) = pdq;
-            }
             CH_T(6)
             C2_SYNC();
             CH_T(7)
@@ -565,7 +488,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
 #pragma unroll
         for (int k = 0; k < 9; ++k) kF[k] = 0.0f;
         const RipVariant v0 = rip_load_variant(vars, 0);
-    const RipFitConst fc0 = rip_fit_const(h);
+        const RipFitConst fc0 = rip_fit_const(h);
+        const int start = KLD(h->start);
         float gain_next = 1.0f;
         int o0_r = (R0 - 5 + 3000) % 3;  // O1 ring slot of row r
         for (int r = R0 - 5; r <= R1; ++r, o0_r = (o0_r == 2) ? 0 : o0_r + 1) {
@@ -577,9 +501,26 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             const float e_read = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(kf->a.planes) +
                                                                   (size_t)(NP + 5) * pl4 + (size_t)(rc_ * row4) + c2_opaque(cc4));
             const float e_gain = gain_next;
+            // calibration planes of the tail (finish) of the same pixel, consumed after the barrier
+            const size_t t_row4 = (size_t)(rc_ * row4);           // byte offset of row r in an f32 plane (uniform)
+            const size_t pe_row = (size_t)(rc_ * (unsigned)nx);   // element offset of row r
+            const char *tb = reinterpret_cast<const char *>(kf->a.planes) + t_row4;
+            const unsigned t4 = c2_opaque(cc4);
+            const float e_dark = *reinterpret_cast<const float *>(tb + (size_t)(NP + 6) * pl4 + t4);
+            const uint32_t e_ff = *reinterpret_cast<const uint32_t *>(tb + (size_t)(NP + 8) * pl4 + t4);
+            const uint32_t e_pdq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(kf->a.pdq) + t_row4 + t4);
+            // flat / dark_dq == null: read the gain plane instead (value unused), keeps the loads in one straight-line block
+            const char *fb = kf->a.flat ? reinterpret_cast<const char *>(kf->a.flat) : reinterpret_cast<const char *>(kf->a.planes);
+            const float e_flat_raw = *reinterpret_cast<const float *>(fb + t_row4 + t4);
+            const float e_flat = kf->a.flat ? e_flat_raw : 1.0f;
+            const char *ddb = kf->a.dark_dq ? reinterpret_cast<const char *>(kf->a.dark_dq) : reinterpret_cast<const char *>(kf->a.planes);
+            const uint32_t e_ddq_raw = *reinterpret_cast<const uint32_t *>(ddb + t_row4 + t4);
+            const uint32_t e_ddq = kf->a.dark_dq ? e_ddq_raw : 0u;
             float d[G];
             f2 dpair[GP];
             uint2 qw = {0u, 0u};  // the pixel's groupdq bytes, packed
+            uint32_t lin_dq = 0;  // linearity dq of the pixel
+            RipFitState fs;
             const bool act = emit && col_act && r >= ay0 && r < ay1;
             CH_T(0)
             C2_DRAIN()
@@ -587,6 +528,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             if (emit) {
                 const int sx = r & 3;
                 qw = QS[sx * C2_COLS + col];
+                lin_dq = DQ[sx * C2_COLS + col];
                 const bool fastdiv = __all(rcp_safe(e_gain) || !act);
                 const float rgain = rip_rcp_mid(e_gain);
                 const bool all = __all(vF == 0x1ffu || !act);
@@ -625,12 +567,16 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                         dpair[p0 + b] = val[b];
                     }
                 }
+                // first half of the ramp fit (registers only): slope, errors, approximate jump significances
+                const bool unsat = ((((G - 1) < 4 ? qw.x : qw.y) >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
+                if (!(dbg & 4))
+                    fit_full_pk_a<G>(dpair, fc0, v0, kf->a.dense, e_gain, e_read, unsat && act, kf->guard, fs);
             }
             CH_T(2)
             C2_SYNC();
             CH_T(3)
             const RIP_K C2KernArgs *kg = c2_args(kargs);  // S2 copy
-            // ---- S2: coefficients and gain of the next row's O2, then the fit of pixel (r, c) -> T ring
+            // ---- S2: coefficients and gain of the next row's O2, second half of the fit, tail of pixel (r, c)
             float kN[9];
             const bool next_on = (r + 1 >= R0) && (r + 1 < R1) && col >= 2 && col < C2_COLS - 2;
             const unsigned vN = load_k(kg->a.kern, r + 1, next_on, kN);
@@ -651,8 +597,10 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 if (dbg & 4) {
                     s = d[0], er = e_read, ep = e_gain;
                 } else {
-                    fit_full_pk<G>(dpair, kg->h, fc0, v0, kg->a.dense, kg->kvals + v0.k_ofs, kg->diffs + v0.diff_ofs, e_gain,
-                                   e_read, unsat && act, kg->guard, s, er, ep, jmask);
+                    // second half of the fit: exact pass where needed, jump mask; then the saturated refits
+                    fit_full_pk_b<G>(dpair, kg->h, fc0, kg->a.dense, kg->kvals + v0.k_ofs, kg->diffs + v0.diff_ofs, unsat && act,
+                                     fs, jmask);
+                    s = fs.s, er = fs.er, ep = fs.ep;
                     if (__any(anysat)) {
                         uint32_t qe[G];
 #pragma unroll
@@ -661,7 +609,58 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                                                jmask);
                     }
                 }
-                TR[(r & 1) * C2_COLS + col] = float4{s, er, ep, __uint_as_float(jmask)};
+                // ---- T: flag propagation (fitting.py:339-353), finish and stores of pixel (r, c)
+                if (!(dbg & 8)) {
+                    uint8_t *gq = kg->a.gdq_out ? kg->a.gdq_out + pe_row : nullptr;
+                    uint32_t pdq = propagate_flags_packed<G>(qw.x, qw.y, jmask, start, e_pdq | lin_dq, gq, npix, c2_opaque(cc1));
+                    if (kg->a.finish) {
+                        float err = hypot_f32(er, ep);
+                        float vp = ep * ep;
+                        if (!act) {
+                            s = 0.0f;
+                            err = 0.0f;
+                            vp = 0.0f;
+                        }
+                        if (act && kg->a.dark_rate) s = s - e_dark;
+                        if (act) pdq |= e_ddq;
+                        // sqrt(ep*ep) == ep exactly when ep*ep neither overflows nor goes subnormal (fpcheck.hip C)
+                        float ep2;
+                        if (__all(vp == 0.0f || rip_mid_range(vp)))
+                            ep2 = act ? ep : 0.0f;
+                        else
+                            ep2 = sqrtf(vp);
+                        const float e2 = err * err;
+                        const float p2 = ep2 * ep2;
+                        const float rdiff = clip_lo<float>(e2 - p2, 0.0f);
+                        float er2;
+                        if (__all(rdiff == 0.0f || rip_mid_range(rdiff)))  // rip_sqrt_mid(0) = 0
+                            er2 = rip_sqrt_mid(rdiff);
+                        else
+                            er2 = sqrtf(rdiff);
+                        if (kg->a.flat) {
+                            pdq |= e_ff;
+                            if (__all(rcp_safe(e_flat) && fabsf(s) < 1e18f && fabsf(er2) < 1e18f && fabsf(ep2) < 1e18f &&
+                                      (s == 0.0f || fabsf(s) > 1e-18f) && (er2 == 0.0f || er2 > 1e-18f) &&
+                                      (ep2 == 0.0f || ep2 > 1e-18f))) {
+                                const float rflat = rip_rcp_mid(e_flat);
+                                s = div_rcp(s, e_flat, rflat);
+                                er2 = div_rcp(er2, e_flat, rflat);
+                                ep2 = div_rcp(ep2, e_flat, rflat);
+                            } else {
+                                s = s / e_flat;
+                                er2 = er2 / e_flat;
+                                ep2 = ep2 / e_flat;
+                            }
+                        }
+                        er = er2;
+                        ep = ep2;
+                    }
+                    const unsigned w4 = c2_opaque(cc4);
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.slope) + t_row4 + w4) = s;
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_read) + t_row4 + w4) = er;
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_poisson) + t_row4 + w4) = ep;
+                    *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kg->a.pdq_out) + t_row4 + w4) = pdq;
+                }
             }
             CH_T(6)
             C2_SYNC();
@@ -680,8 +679,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
 }
 
 static inline size_t chain2_lds_bytes(int G) {
-    return (size_t)(G / 2) * C2_COLS * 8 * (4 + 3) + (size_t)C2_COLS * 4 * (4 + 8) + (size_t)C2_COLS * 2 * 16 +
-           (size_t)3 * G * 2 * 8;
+    return (size_t)(G / 2) * C2_COLS * 8 * (4 + 3) + (size_t)C2_COLS * 4 * (4 + 8) + (size_t)3 * G * 2 * 8;
 }
 
 template <int NP, int G>

@@ -351,12 +351,19 @@ __device__ __forceinline__ void rip_load_pair(RipDensePair &r, const RipDense *d
     }
 }
 
+// state of the packed full-ramp fit between its two halves (registers; the fused kernel puts a barrier between them)
+struct RipFitState {
+    float s, er, ep;           // slope, read-noise error, Poisson error of the full ramp
+    float dv, s2, xc;          // operands of the exact pass
+    uint32_t jfast, unsure;    // per difference (bit 2*ps+e): approximate decision, needs the exact pass
+    bool live;                 // wave-uniform: some lane of the wave keeps jump flags
+};
+
+// first half: slope, errors, threshold, approximate significance of every tested difference
 template <int G>
-__device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPlanHeader *__restrict__ h,
-                                            const RipFitConst fc, const RipVariant v, const RipDense *__restrict__ dn,
-                                            const float *__restrict__ kv, const RipDiff *__restrict__ df, float gain,
-                                            float rn, bool flag, double guard, float &s_out, float &er_out,
-                                            float &ep_out, uint32_t &jmask) {
+__device__ __forceinline__ void fit_full_pk_a(const rf2 (&dA)[G / 2], const RipFitConst fc, const RipVariant v,
+                                              const RipDense *__restrict__ dn, float gain, float rn, bool flag,
+                                              double guard, RipFitState &st) {
     constexpr int GP = G / 2;
     constexpr int NS = 2 * GP;  // pair slots
     // scalar loads of the weights and of the first difference slot are issued before the slope arithmetic; slot
@@ -387,15 +394,22 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
         dvq = s / gc;
     const float dv = clip_lo<float>(dvq, 0.0f);
     const float pv = clip_lo<float>(v.coef * dv, 0.0f);
-    s_out = s;
-    er_out = rn * v.rfac;
+    st.s = s;
+    st.er = rn * v.rfac;
     if (__all(pv == 0.0f || rip_mid_range(pv)))  // rip_sqrt_mid(0) = 0
-        ep_out = rip_sqrt_mid(pv);
+        st.ep = rip_sqrt_mid(pv);
     else
-        ep_out = sqrtf(pv);
-    if (!__any(flag)) return;
+        st.ep = sqrtf(pv);
+    st.dv = dv;
+    st.s2 = rn * rn;
+    st.jfast = 0;
+    st.unsure = 0;
+    st.xc = 0.0f;
+    st.live = __any(flag);
+    if (!st.live) return;
 
     const float xc = clip2<float>(s, fc.ia, fc.ib);
+    st.xc = xc;
     const bool need_log = xc != fc.ia;  // log(1) = 0 exactly otherwise
     float lx = 0.0f;
     if (__any(need_log)) lx = need_log ? __logf(xc / fc.ia) : 0.0f;
@@ -407,7 +421,7 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
     //   known to +-band0.  With thp + t > 0 and thm - t > 0 (checked per pixel through rsmax >= every rs):
     //   sm > (thp + t) k1  => sure hit,   sm < (thm - t) k2  => surely no hit,   anything else (NaN included) -> exact pass.
     const float band0 = 2e-6f * fabsf(sth32) + 4e-6f * fabsf(slope_th) + 1e-30f;
-    const float s2 = rn * rn;
+    const float s2 = st.s2;
     const float s8 = fabsf(s) * 8.1e-7f;
     const float thp = sth32 + band0, thm = sth32 - band0;
     const float rsmax = __frsqrt_rn(KLD(dn->amin) * s2) * 1.000001f;
@@ -447,6 +461,21 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
             if (lane_exact || !(hit || nohit)) unsure_mask |= 1u << (2 * ps + e);
         }
     }
+    st.jfast = jfast;
+    st.unsure = unsure_mask;
+}
+
+// second half: exact re-evaluation where the approximate significance was not decisive, jump mask
+template <int G>
+__device__ __forceinline__ void fit_full_pk_b(const rf2 (&dA)[G / 2], const RipPlanHeader *__restrict__ h,
+                                              const RipFitConst fc, const RipDense *__restrict__ dn,
+                                              const float *__restrict__ kv, const RipDiff *__restrict__ df, bool flag,
+                                              const RipFitState &st, uint32_t &jmask) {
+    constexpr int GP = G / 2;
+    if (!st.live) return;
+    const float s = st.s, dv = st.dv, s2 = st.s2, xc = st.xc;
+    uint32_t jfast = st.jfast;
+    const uint32_t unsure_mask = st.unsure;
     // differences whose approximate significance is within its error band of the threshold (or NaN): redo them in
     // the reference's exact operation order.  Rare; one wave-uniform test covers the whole pixel.
     if (__any(unsure_mask != 0 && flag)) {
@@ -480,6 +509,20 @@ __device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPla
             if ((four & 2u) || (four & 8u)) jmask |= 1u << (2 * ip + 1);
         }
     }
+}
+
+template <int G>
+__device__ __forceinline__ void fit_full_pk(const rf2 (&dA)[G / 2], const RipPlanHeader *__restrict__ h,
+                                            const RipFitConst fc, const RipVariant v, const RipDense *__restrict__ dn,
+                                            const float *__restrict__ kv, const RipDiff *__restrict__ df, float gain,
+                                            float rn, bool flag, double guard, float &s_out, float &er_out,
+                                            float &ep_out, uint32_t &jmask) {
+    RipFitState st;
+    fit_full_pk_a<G>(dA, fc, v, dn, gain, rn, flag, guard, st);
+    fit_full_pk_b<G>(dA, h, fc, dn, kv, df, flag, st, jmask);
+    s_out = st.s;
+    er_out = st.er;
+    ep_out = st.ep;
 }
 
 // ---------------------------------------------------------------------------------------------
