@@ -65,7 +65,7 @@ __device__ __forceinline__ const RIP_K C2KernArgs *c2_args(const RIP_K C2KernArg
     return p;
 }
 
-template <int NP, int G>
+template <int NP, int G, int START>
 __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
                                                                const RipVariant *__restrict__ vars,
                                                                const float *__restrict__ kvals,
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
         for (int k = 0; k < 9; ++k) kF[k] = 0.0f;
         const RipVariant v0 = rip_load_variant(vars, 0);
         const RipFitConst fc0 = rip_fit_const(h);
-        const int start = KLD(h->start);
+        constexpr int start = START;  // first group of the fit (exclude_first)
         float gain_next = 1.0f;
         int o0_r = (R0 - 5 + 3000) % 3;  // O1 ring slot of row r
         for (int r = R0 - 5; r <= R1; ++r, o0_r = (o0_r == 2) ? 0 : o0_r + 1) {
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 // first half of the ramp fit (registers only): slope, errors, approximate jump significances
                 const bool unsat = ((((G - 1) < 4 ? qw.x : qw.y) >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
                 if (!(dbg & 4))
-                    fit_full_pk_a<G>(dpair, fc0, v0, kf->a.dense, e_gain, e_read, unsat && act, kf->guard, fs);
+                    fit_full_pk_a<G, rip_full_valid<G, START>()>(dpair, fc0, v0, kf->a.dense, e_gain, e_read, unsat && act, kf->guard, fs);
             }
             CH_T(2)
             C2_SYNC();
@@ -682,8 +682,8 @@ static inline size_t chain2_lds_bytes(int G) {
     return (size_t)(G / 2) * C2_COLS * 8 * (4 + 3) + (size_t)C2_COLS * 4 * (4 + 8) + (size_t)3 * G * 2 * 8;
 }
 
-template <int NP, int G>
-static int launch_chain2(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
+template <int NP, int G, int START>
+static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
     extern double rip_guard_band;
     const size_t lds = chain2_lds_bytes(G);
     static int ncu = 0;
@@ -702,11 +702,19 @@ static int launch_chain2(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) 
     if (nranges < 1) nranges = 1;
     const long grid = (long)nranges * nstrips;
     if (lds > 48 * 1024)
-        RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chain2_kernel<NP, G>),
+        RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chain2_kernel<NP, G, START>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((chain2_kernel<NP, G>), dim3((unsigned)grid), dim3(C2_THREADS), lds, ctx->stream, a,
+    hipLaunchKernelGGL((chain2_kernel<NP, G, START>), dim3((unsigned)grid), dim3(C2_THREADS), lds, ctx->stream, a,
                        reinterpret_cast<const RipPlanHeader *>(plan->dev), plan->d_variants, plan->d_k, plan->d_diffs,
                        rip_guard_band);
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
+}
+
+// returns the launch status, or 1 when the plan is not one the specialised kernel was compiled for
+template <int NP, int G>
+static int launch_chain2(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
+    if (plan->h.start == 0 && plan->dense.valid == rip_full_valid<G, 0>()) return launch_chain2_s<NP, G, 0>(ctx, plan, a);
+    if (plan->h.start == 1 && plan->dense.valid == rip_full_valid<G, 1>()) return launch_chain2_s<NP, G, 1>(ctx, plan, a);
+    return 1;
 }

@@ -351,6 +351,17 @@ __device__ __forceinline__ void rip_load_pair(RipDensePair &r, const RipDense *d
     }
 }
 
+// the differences the full-ramp fit tests (fitting.py:225-229) as the bit mask RipDense::valid, at compile time
+template <int G, int START>
+constexpr uint32_t rip_full_valid() {
+    uint32_t m = 0;
+    for (int i = START; i < G - 1; ++i) {
+        const int dimax = (i == G - 2 || G - 1 - START == 2) ? 1 : 2;
+        for (int di = 1; di <= dimax; ++di) m |= 1u << (2 * (2 * (i / 2) + (di - 1)) + (i & 1));
+    }
+    return m;
+}
+
 // state of the packed full-ramp fit between its two halves (registers; the fused kernel puts a barrier between them)
 struct RipFitState {
     float s, er, ep;           // slope, read-noise error, Poisson error of the full ramp
@@ -360,7 +371,9 @@ struct RipFitState {
 };
 
 // first half: slope, errors, threshold, approximate significance of every tested difference
-template <int G>
+// VALID != 0: the tested differences are known at compile time (no plan-uniform branches: the eight difference
+// slots become one basic block the scheduler can interleave)
+template <int G, uint32_t VALID = 0u>
 __device__ __forceinline__ void fit_full_pk_a(const rf2 (&dA)[G / 2], const RipFitConst fc, const RipVariant v,
                                               const RipDense *__restrict__ dn, float gain, float rn, bool flag,
                                               double guard, RipFitState &st) {
@@ -371,7 +384,7 @@ __device__ __forceinline__ void fit_full_pk_a(const rf2 (&dA)[G / 2], const RipF
     float k2[G];
 #pragma unroll
     for (int t = 0; t < G; ++t) k2[t] = KLD(dn->K2[t]);
-    const uint32_t valid = KLD(dn->valid);
+    const uint32_t valid = VALID ? VALID : KLD(dn->valid);
     RipDensePair tab[2];
     rip_load_pair(tab[0], dn, 0);
     const float d1 = dA[0].y;
