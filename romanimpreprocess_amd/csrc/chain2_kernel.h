@@ -317,6 +317,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 f2 zz[PB], SS[PB];
                 bool any_ex = false;
                 if (a_full && !(dbg & 32)) {
+                    f2 tt[PB], quo[PB];
 #pragma unroll
                     for (int b = 0; b < PB; ++b) {
                         const int p = pb + b;
@@ -339,18 +340,22 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                             else
                                 w1 |= (rr.q[g] & 0xffu) << (8 * (g - 4));
                         }
-                        const f2 S2 = {Sv[0], Sv[1]};
-                        f2 t = S2 - f2{smin, smin};
-                        t = t * 2.0f;
-                        f2 quo;
-                        if (fastdiv)
-                            quo = div_rcp2(t, span, rspan);
-                        else
-                            quo = f2{t.x / span, t.y / span};
-                        f2 z = quo + (-1.0f);
-                        if (p == 0 && a.do_not_flag_first) z.x = clip2<float>(z.x, -1.0f, 1.0f);
+                        SS[b] = f2{Sv[0], Sv[1]};
+                        const f2 t = SS[b] - f2{smin, smin};
+                        tt[b] = t * 2.0f;
+                    }
+                    if (fastdiv) {  // one block: the PB reciprocal-division chains interleave
+#pragma unroll
+                        for (int b = 0; b < PB; ++b) quo[b] = div_rcp2(tt[b], span, rspan);
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < PB; ++b) quo[b] = f2{tt[b].x / span, tt[b].y / span};
+                    }
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) {
+                        f2 z = quo[b] + (-1.0f);
+                        if (pb + b == 0 && a.do_not_flag_first) z.x = clip2<float>(z.x, -1.0f, 1.0f);
                         zz[b] = z;
-                        SS[b] = S2;
                         any_ex = any_ex || (fabsf(z.x) > 1.0f) || (fabsf(z.y) > 1.0f);
                     }
                 } else {
@@ -551,13 +556,15 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                             fwd_rows_batch<NB, true>(om, o0, op, col, kF, vF, f, oc);
                         else
                             fwd_rows_batch<NB, false>(om, o0, op, col, kF, vF, f, oc);
+                        f2 o2[NB];
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) {
-                            const f2 o2 = (oc[b] + xc[b]) - f[b];
-                            if (fastdiv)
-                                val[b] = div_rcp2(o2, e_gain, rgain);
-                            else
-                                val[b] = f2{o2.x / e_gain, o2.y / e_gain};
+                        for (int b = 0; b < NB; ++b) o2[b] = (oc[b] + xc[b]) - f[b];
+                        if (fastdiv) {  // one block: the NB reciprocal-division chains interleave
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) val[b] = div_rcp2(o2[b], e_gain, rgain);
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < NB; ++b) val[b] = f2{o2[b].x / e_gain, o2[b].y / e_gain};
                         }
                     }
 #pragma unroll
