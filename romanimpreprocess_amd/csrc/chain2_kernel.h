@@ -621,46 +621,46 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                     uint8_t *gq = kg->a.gdq_out ? kg->a.gdq_out + pe_row : nullptr;
                     uint32_t pdq = propagate_flags_packed<G>(qw.x, qw.y, jmask, start, e_pdq | lin_dq, gq, npix, c2_opaque(cc1));
                     if (kg->a.finish) {
-                        float err = hypot_f32(er, ep);
-                        float vp = ep * ep;
-                        if (!act) {
-                            s = 0.0f;
-                            err = 0.0f;
-                            vp = 0.0f;
-                        }
-                        if (act && kg->a.dark_rate) s = s - e_dark;
-                        if (act) pdq |= e_ddq;
-                        // sqrt(ep*ep) == ep exactly when ep*ep neither overflows nor goes subnormal (fpcheck.hip C)
-                        float ep2;
-                        if (__all(vp == 0.0f || rip_mid_range(vp)))
-                            ep2 = act ? ep : 0.0f;
-                        else
-                            ep2 = sqrtf(vp);
-                        const float e2 = err * err;
-                        const float p2 = ep2 * ep2;
-                        const float rdiff = clip_lo<float>(e2 - p2, 0.0f);
-                        float er2;
-                        if (__all(rdiff == 0.0f || rip_mid_range(rdiff)))  // rip_sqrt_mid(0) = 0
-                            er2 = rip_sqrt_mid(rdiff);
-                        else
-                            er2 = sqrtf(rdiff);
-                        if (kg->a.flat) {
-                            pdq |= e_ff;
-                            if (__all(rcp_safe(e_flat) && fabsf(s) < 1e18f && fabsf(er2) < 1e18f && fabsf(ep2) < 1e18f &&
-                                      (s == 0.0f || fabsf(s) > 1e-18f) && (er2 == 0.0f || er2 > 1e-18f) &&
-                                      (ep2 == 0.0f || ep2 > 1e-18f))) {
-                                const float rflat = rip_rcp_mid(e_flat);
-                                s = div_rcp(s, e_flat, rflat);
-                                er2 = div_rcp(er2, e_flat, rflat);
-                                ep2 = div_rcp(ep2, e_flat, rflat);
-                            } else {
+                        // gen_cal_image.py:458-475, 213-229, 607-629.  One wave vote selects the straight-line form built
+                        // from the short exact operations (rip_rcp_mid, rip_sqrt_mid, sqrt(x*x) = x: tools/gpu_checks/
+                        // fpcheck.hip); every intermediate then lies in their validated range 2^-100 .. 2^100 or is +0.
+                        const float sd = (act && kg->a.dark_rate) ? s - e_dark : s;
+                        const bool lean = kg->a.flat && __all(act && rip_mid36(sd) && (er == 0.0f || rip_mid36(er)) &&
+                                                              (ep == 0.0f || rip_mid36(ep)) && e_flat > 0.0f && rip_mid36(e_flat));
+                        if (lean) {
+                            const float err = hypot_f32(er, ep);
+                            pdq |= e_ddq | e_ff;
+                            const float ep2 = ep;  // sqrt(ep * ep)
+                            const float e2 = err * err;
+                            const float p2 = ep2 * ep2;
+                            const float er2 = rip_sqrt_mid(clip_lo<float>(e2 - p2, 0.0f));
+                            const float rflat = rip_rcp_mid(e_flat);
+                            s = div_rcp(sd, e_flat, rflat);
+                            er = div_rcp(er2, e_flat, rflat);
+                            ep = div_rcp(ep2, e_flat, rflat);
+                        } else {
+                            float err = hypot_f32(er, ep);
+                            float vp = ep * ep;
+                            if (!act) {
+                                s = 0.0f;
+                                err = 0.0f;
+                                vp = 0.0f;
+                            }
+                            if (act && kg->a.dark_rate) s = s - e_dark;
+                            if (act) pdq |= e_ddq;
+                            float ep2 = sqrtf(vp);
+                            const float e2 = err * err;
+                            const float p2 = ep2 * ep2;
+                            float er2 = sqrtf(clip_lo<float>(e2 - p2, 0.0f));
+                            if (kg->a.flat) {
+                                pdq |= e_ff;
                                 s = s / e_flat;
                                 er2 = er2 / e_flat;
                                 ep2 = ep2 / e_flat;
                             }
+                            er = er2;
+                            ep = ep2;
                         }
-                        er = er2;
-                        ep = ep2;
                     }
                     const unsigned w4 = c2_opaque(cc4);
                     *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.slope) + t_row4 + w4) = s;

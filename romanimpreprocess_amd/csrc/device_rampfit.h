@@ -40,12 +40,16 @@ __device__ __forceinline__ float hypot_f32(float a, float b) {
     return (float)sqrt(da * da + db * db);
 }
 
-// Short forms of IEEE f32 reciprocal and square root, bit-identical to 1.0f/b and sqrtf(x) for 2^-60 <= |.| <= 2^60
+// Short forms of IEEE f32 reciprocal and square root, bit-identical to 1.0f/b and sqrtf(x) for 2^-100 <= |.| <= 2^100
 // (tools/gpu_checks/fpcheck.hip: exhaustive over all such floats, 0 mismatches).  Callers vote on the range with
 // rip_mid_range() over the wave and fall back to the compiler's full expansion otherwise.
 __device__ __forceinline__ bool rip_mid_range(float x) {  // false for NaN, Inf, 0, subnormals, |x| outside 2^-59..2^59
     const float ax = fabsf(x);
     return ax > 1.8e-18f && ax < 5.7e17f;
+}
+__device__ __forceinline__ bool rip_mid36(float x) {  // 2^-36 < |x| < 2^36: sums / products / quotients of two such stay in range
+    const float ax = fabsf(x);
+    return ax > 1.5e-11f && ax < 6.8e10f;
 }
 __device__ __forceinline__ float rip_rcp_mid(float b) {
     const float r0 = __builtin_amdgcn_rcpf(b);

@@ -76,6 +76,15 @@ int main() {
     hipMemset(d, 0, 40);
     // exponents 67..187 = 2^-60 .. 2^60  (x*x stays normal and finite for C on 2^-60..2^60: 2^-120 .. 2^120)
     hipLaunchKernelGGL(sweep, dim3((1u << 23) / 256), dim3(256), 0, 0, 67, 187, d);
+    // wider sweep of A and D only: exponents 27..227 = 2^-100 .. 2^100
+    unsigned long long *d2;
+    hipMalloc(&d2, 40);
+    hipMemset(d2, 0, 40);
+    hipLaunchKernelGGL(sweep, dim3((1u << 23) / 256), dim3(256), 0, 0, 27, 227, d2);
+    unsigned long long h2[5];
+    hipDeviceSynchronize();
+    hipMemcpy(h2, d2, 40, hipMemcpyDeviceToHost);
+    printf("wide sweep 2^-100..2^100: reciprocal mismatches %llu, lean sqrt mismatches %llu\n", h2[0], h2[3]);
     for (int mode = 0; mode < 2; ++mode)
         for (int rep = 0; rep < 16; ++rep) hipLaunchKernelGGL(pairs, dim3(4096), dim3(256), 0, 0, 4242ull + rep * 7919ull + mode, mode, d, d + 4);
     hipDeviceSynchronize();
