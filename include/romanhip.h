@@ -202,6 +202,14 @@ int rip_profile_read(rip_ctx *ctx, double out_ms[4], int *ncalls);
    configuration allows it (f32 gain; 4, 9 or 11 Legendre planes; LDS budget); 0 forces the
    stage-by-stage kernels.  Both give identical results. */
 int rip_set_option(rip_ctx *ctx, const char *name, int value);
+/* further options (all default 1, results identical either way; they exist for A/B timing and tests):
+   "chain2"  -- use the wave-specialised form of the fused kernel (chain2_kernel.h: f32 ipc4d, 6 or 8 groups) where it
+                applies, 0 = always the general fused kernel (chain_kernel.h);
+   "overlap" -- run the reference-pixel pre-pass of a ramp on a second stream so that it overlaps the previous ramp's
+                fused kernel. */
+
+/* how the last rip_calibrate ran: 0 = stage kernels, 1 = general fused kernel, 2 = wave-specialised fused kernel */
+int rip_last_chain_form(rip_ctx *ctx);
 
 /* ---- diagnostics ------------------------------------------------------------------------- */
 /* relative half-width of the band around the jump threshold inside which the significance is

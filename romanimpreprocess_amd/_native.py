@@ -89,6 +89,7 @@ SYMBOLS = {
     "rip_stage_get_flat": (_I, [_VP, _VP, _I, _I, _I, _VP, _I, _VP, _I, _I, _VP, _VP]),
     "rip_set_guard_band": (None, [C.c_double]),
     "rip_set_option": (_I, [_VP, C.c_char_p, _I]),
+    "rip_last_chain_form": (_I, [_VP]),
     "rip_profile_enable": (_I, [_VP, _I]),
     "rip_profile_read": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(_I)]),
 }
@@ -177,6 +178,10 @@ class Context:
 
     def set_option(self, name, value):
         self.check(self.lib.rip_set_option(self.h, name.encode(), int(value)))
+
+    def last_chain_form(self):
+        """0 = stage kernels, 1 = general fused kernel, 2 = wave-specialised fused kernel (last calibrate call)."""
+        return int(self.lib.rip_last_chain_form(self.h))
 
     def profile(self, on=True):
         self.check(self.lib.rip_profile_enable(self.h, int(bool(on))))

@@ -211,6 +211,8 @@ int rip_chain_stamps2(rip_ctx *ctx, double out[18]) {
     return RIP_OK;
 }
 
+int rip_last_chain_form(rip_ctx *ctx) { return ctx ? ctx->last_form : RIP_EINVAL; }
+
 int rip_profile_enable(rip_ctx *ctx, int on) {
     ctx->prof = on != 0;
     return RIP_OK;
@@ -721,6 +723,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     const uint32_t *pdq_mid = d_pdq;
     // the fused kernel covers the complete chain on a Level-1 (u16) cube; sub-chains and f32 cubes take the
     // stage-by-stage kernels
+    ctx->last_form = 0;
     const bool fused = ctx->use_fused && do_ref && do_bias && do_lin && do_ipc && do_fit && in->data_dtype == RIP_U16 &&
                        rip_chain_supported(c.lin_nplanes, G, c.ipc_dtype, c.gain_dtype);
     if (fused) {

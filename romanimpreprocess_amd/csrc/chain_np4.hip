@@ -7,7 +7,11 @@ int rip_launch_chain_np4(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, 
         int rc = 1;
         if (a.ngrp == 8) rc = launch_chain2<4, 8>(ctx, plan, a);
         if (a.ngrp == 6) rc = launch_chain2<4, 6>(ctx, plan, a);
-        if (rc != 1) return rc;
+        if (rc != 1) {
+            ctx->last_form = 2;
+            return rc;
+        }
     }
+    ctx->last_form = 1;
     return launch_chain_np<4>(ctx, plan, a, k_dtype);
 }

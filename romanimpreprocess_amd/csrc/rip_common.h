@@ -117,6 +117,7 @@ struct rip_ctx {
     int parity = 0;
     bool use_overlap = true;
     bool use_chain2 = true;  // wave-specialised fused kernel where it applies
+    int last_form = 0;       // diagnostic: how the last rip_calibrate ran (0 stage kernels, 1 general fused, 2 specialised)
     std::string err;
     std::vector<RipCal> cals;
     std::vector<RipPlan *> plans;

@@ -181,3 +181,66 @@ def test_calibrateimage_files_end_to_end(tmp_path):
                                      verbose=False)
     with pytest.raises(NotImplementedError):
         gen_cal_image.calibrateimage(dict(config, SKYORDER=2), verbose=False)
+
+
+# ---- the wave-specialised fused kernel (chain2_kernel.h): every instantiation the dispatcher can pick, and the seams
+# between its column strips / row ranges
+
+SPECIALISED = [
+    # name, (ny, nx), read pattern, p_order (NP = p + 1 planes), exclude_first
+    ("g6_np9_start1", (48, 384), synth.READ_PATTERN_6, 8, True),
+    ("g6_np4_start0", (40, 256), synth.READ_PATTERN_6, 3, False),
+    ("g8_np11_start1", (40, 256), synth.READ_PATTERN_8, 10, True),
+    ("g8_np9_start0", (56, 256), synth.READ_PATTERN_8, 8, False),
+    ("g8_np4_start1", (40, 128), synth.READ_PATTERN_8, 3, True),
+]
+
+
+@pytest.mark.parametrize("name,shape,rp,p,exclude_first", SPECIALISED)
+def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first):
+    ny, nx = shape
+    ctx = gpu_context()
+    ctx.set_option("fused", 1)
+    ctx.set_option("chain2", 1)
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=p, seed=91, bias_amplitude=2.0, bad_lin_frac=0.01)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=92, cr_frac=0.03)
+    ref = oracle.calibrate_arrays(ramp, cal, exclude_first=exclude_first)
+    cb = pipeline.Calibrator(ctx=ctx)
+    cb.load_caldir(4, cal)
+    lines = _oracle_lines(ref, len(rp), nx // 128)
+    got = cb.calibrate(4, ramp, exclude_first=exclude_first, want_cube=True, channel_lines=lines)
+    assert ctx.last_chain_form() == 2, "the wave-specialised kernel did not run"
+    assert_same_bits(got["cube"], ref["data"], "corrected cube", zero_sign_ok=True)
+    assert_same_bits(got["groupdq"], ref["groupdq"], "groupdq")
+    assert_same_bits(got["pixeldq"], ref["pixeldq"], "pixeldq")
+    for k in ("slope", "err_read", "err_poisson"):
+        assert_same_bits(got[k], ref[k], k, zero_sign_ok=True)
+    assert np.count_nonzero(got["pixeldq"] & 4) > 5
+    cb.ctx.drop_caldir(4)
+
+
+def test_fused_forms_agree_across_seams():
+    """A frame wider than several 252-column strips and taller than several row ranges: the wave-specialised kernel, the
+    general fused kernel and the stage kernels must give identical bits (halo columns, range boundaries, frame edges)."""
+    rp = synth.READ_PATTERN_8
+    ny, nx = 1160, 896
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=31, bias_amplitude=2.0, bad_lin_frac=0.005)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=32, cr_frac=0.02)
+    ctx = gpu_context()
+    cb = pipeline.Calibrator(ctx=ctx)
+    cb.load_caldir(5, cal)
+    outs = []
+    try:
+        for fused, chain2 in ((1, 1), (1, 0), (0, 0)):
+            ctx.set_option("fused", fused)
+            ctx.set_option("chain2", chain2)
+            outs.append(cb.calibrate(5, ramp, want_cube=True))
+            assert ctx.last_chain_form() == {(1, 1): 2, (1, 0): 1, (0, 0): 0}[(fused, chain2)]
+    finally:
+        ctx.set_option("fused", 1)
+        ctx.set_option("chain2", 1)
+    for other, label in ((outs[1], "general fused"), (outs[2], "stage kernels")):
+        for k in ("cube", "slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
+            assert_same_bits(outs[0][k], other[k], f"{k}: specialised vs {label}")
+    assert np.count_nonzero(outs[0]["pixeldq"] & 4) > 1000 and np.count_nonzero(outs[0]["pixeldq"] & 2) > 100
+    cb.ctx.drop_caldir(5)
