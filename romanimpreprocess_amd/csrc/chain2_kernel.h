@@ -4,19 +4,19 @@
 // chain_kernel.h is bound by instruction issue at 2 waves/SIMD (one wave carries the registers of the linearity
 // prefetch AND of the IPC/fit state, and LDS holds only two 256-column workgroups per CU).  Here a workgroup of
 // 512 threads covers the same 256 columns with TWO ROLES of four waves each:
-//     ingest waves (tid < 256)   P: raw loads of row r+4            A: refpix/bias/linearity of row r+3 -> x ring
-//                                C: first IPC iterate of row r+2    (reads x rows r+1..r+3)          -> O1 ring
-//                                T: flag propagation, finish (dark rate, error split, flat), stores of row r-1
+//     ingest waves (tid < 256)   A: refpix/bias/linearity of row r+3 -> x ring      (raw loads of row r+4 issued between
+//                                C: first IPC iterate of row r+2 -> O1 ring             its arithmetic blocks)
 //     fit waves    (tid >= 256)  O2: second iterate of row r / gain (reads O1 rows r-1..r+1, x row r)
-//                                F: ramp fit with jump detection and saturated refits of row r      -> T ring
+//                                F: ramp fit with jump detection and saturated refits of pixel (r, c)
+//                                T: flag propagation, finish (dark rate, error split, flat), stores of pixel (r, c)
 // so each role needs <= 128 VGPRs and a CU holds 2 workgroups = 16 waves = 4 waves/SIMD.  Per step:
-//     S1: ingest A(r+3)                     | fit O2(r)                 -- barrier --
-//     S2: ingest P(r+4), C(r+2), T(r-1)     | fit F(r), loads of row r+1 -- barrier --
-// (the split keeps both roles busy for about the same time in both halves; see profiles/).  The x ring is 4 rows
-// deep (rows r..r+3 are live during a step), the O1 ring 3 rows (C writes row r+2 into the slot of row r-1, which
-// O2(r) finished reading before the barrier), the T ring (slope, two errors, jump mask) 2 rows.  The linearity dq
-// and the 8 groupdq bytes of a pixel travel from its ingest to its fit and its tail through 4-row rings.
-// Saturated pixels are refitted from registers (trunc_layers), so no per-pixel ramp staging in LDS.
+//     S1: ingest A(r+3)   | fit O2(r), first half of F(r)            -- barrier --
+//     S2: ingest C(r+2)   | fit second half of F(r), T(r), loads of row r+1   -- barrier --
+// Everything after O2 is register-only in a fit thread, so the half-step barrier can fall anywhere in it: it is placed
+// where both roles take about the same time in both halves (profiles/).  The x ring is 4 rows deep (rows r..r+3 are
+// live during a step), the O1 ring 3 rows (C writes row r+2 into the slot of row r-1, which O2(r) finished reading
+// before the barrier).  The linearity dq and the 8 groupdq bytes of a pixel travel from its ingest to its fit through
+// 4-row rings.  Saturated pixels are refitted from registers (trunc_layers), so no per-pixel ramp staging in LDS.
 #pragma once
 #include "chain_kernel.h"
 
@@ -156,10 +156,10 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
 
     // coefficient loader: raw loads at clamped source positions + validity mask for destination (y, c);
     // `want` is wave-uniform.  Planes are walked in memory order (plane = 3*(1+dy) + (1+dx)).
-    auto load_k = [&](const void *kern_base, int y, bool want, float (&kk)[9]) -> unsigned {
+    auto load_k = [&](const void *kern_base, int y, bool want, f2 (&kk2)[5]) -> unsigned {
         if (dbg & 128) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) kk[k] = (k == 0) ? 1.0f : 0.001f;
+            for (int k = 0; k < 5; ++k) kk2[k] = f2{(k == 0) ? 1.0f : 0.001f, 0.001f};
             return want ? lane_mask : 0u;
         }
         size_t rowoff[3];
@@ -181,7 +181,11 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             // 6 (1,-1), 7 (-1,1), 8 (-1,-1)
             const int k = (dy == 0) ? (dx == 0 ? 0 : dx == 1 ? 3 : 4) : (dy == 1) ? (dx == 0 ? 1 : dx == 1 ? 5 : 6)
                                                                                   : (dx == 0 ? 2 : dx == 1 ? 7 : 8);
-            kk[k] = *reinterpret_cast<const float *>(kb + rowoff[dy + 1] + ox[dx + 1]);
+            const float kv_ = *reinterpret_cast<const float *>(kb + rowoff[dy + 1] + ox[dx + 1]);
+            if (k & 1)
+                kk2[k / 2].y = kv_;
+            else
+                kk2[k / 2].x = kv_;
             kb += pl4;
         }
         const unsigned um = (want && y >= ay0 && y < ay1) ? rowbits : 0u;
@@ -451,7 +455,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             }
             // IPC coefficients of row yc, consumed by C after the barrier; issued here so that their registers are not live
             // during A
-            float kC[9];
+            f2 kC[5];
+            kC[4].y = 0.0f;
             const unsigned vC = load_k(ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
             CH_T(2)
             C2_SYNC();
@@ -465,18 +470,30 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 const bool all = __all(vC == 0x1ffu || vC == 0u);
                 const int sm = (yc - 1) & 3, s0 = yc & 3, sp = (yc + 1) & 3;
                 const int so = so_c;
+                if (do_c && all && !(dbg & 1)) {
+                    // interior wave: one straight-line block (see O2)
 #pragma unroll
-                for (int p0 = 0; p0 < GP; ++p0) {
-                    fetch_coefs(kb2, r + 4, p0 * CO_STEP, (p0 * CO_STEP + CO_STEP < NCO) ? p0 * CO_STEP + CO_STEP : NCO, rr);
-                    if (do_c && !(dbg & 1)) {
+                    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(kC[i]));
+#pragma unroll
+                    for (int p0 = 0; p0 < GP; ++p0) {
+                        fetch_coefs(kb2, r + 4, p0 * CO_STEP, (p0 * CO_STEP + CO_STEP < NCO) ? p0 * CO_STEP + CO_STEP : NCO, rr);
                         const f2 *xb = X2 + p0 * 4 * C2_COLS;
                         const f2 *xm[1] = {xb + sm * C2_COLS}, *x0[1] = {xb + s0 * C2_COLS}, *xp[1] = {xb + sp * C2_COLS};
                         f2 f[1], xc[1];
-                        if (all)
-                            fwd_rows_batch<1, true>(xm, x0, xp, col, kC, vC, f, xc);
-                        else
-                            fwd_rows_batch<1, false>(xm, x0, xp, col, kC, vC, f, xc);
+                        fwd_rows_batch<1, true>(xm, x0, xp, col, kC, vC, f, xc);
                         O12[(p0 * 3 + so) * C2_COLS + col] = (xc[0] + xc[0]) - f[0];
+                    }
+                } else {
+#pragma unroll
+                    for (int p0 = 0; p0 < GP; ++p0) {
+                        fetch_coefs(kb2, r + 4, p0 * CO_STEP, (p0 * CO_STEP + CO_STEP < NCO) ? p0 * CO_STEP + CO_STEP : NCO, rr);
+                        if (do_c && !(dbg & 1)) {
+                            const f2 *xb = X2 + p0 * 4 * C2_COLS;
+                            const f2 *xm[1] = {xb + sm * C2_COLS}, *x0[1] = {xb + s0 * C2_COLS}, *xp[1] = {xb + sp * C2_COLS};
+                            f2 f[1], xc[1];
+                            fwd_rows_batch<1, false>(xm, x0, xp, col, kC, vC, f, xc);
+                            O12[(p0 * 3 + so) * C2_COLS + col] = (xc[0] + xc[0]) - f[0];
+                        }
                     }
                 }
                 if (GP * CO_STEP < NCO) fetch_coefs(kb2, r + 4, GP * CO_STEP, NCO, rr);
@@ -488,10 +505,10 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
         }
     } else {
         // =========================================================================== fit waves
-        float kF[9];
+        f2 kF[5];
         unsigned vF = 0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) kF[k] = 0.0f;
+        for (int k = 0; k < 5; ++k) kF[k] = f2{0.0f, 0.0f};
         const RipVariant v0 = rip_load_variant(vars, 0);
         const RipFitConst fc0 = rip_fit_const(h);
         constexpr int start = START;  // first group of the fit (exclude_first)
@@ -539,39 +556,67 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 const bool all = __all(vF == 0x1ffu || !act);
                 const int o0_ = o0_r, om_ = (o0_r == 0) ? 2 : o0_r - 1, op_ = (o0_r == 2) ? 0 : o0_r + 1;
                 constexpr int NB = (GP % 2 == 0) ? 2 : 1;
+                if (all && fastdiv && __all(act) && !(dbg & 2)) {
+                    // interior wave: one straight-line block (the coefficient pairs stay 64-bit registers whose halves the
+                    // packed multiplies broadcast through op_sel)
 #pragma unroll
-                for (int p0 = 0; p0 < GP; p0 += NB) {
-                    f2 xc[NB], val[NB];
+                    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(kF[i]));
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) val[b] = xc[b] = X2[((p0 + b) * 4 + sx) * C2_COLS + col];
-                    if (act && !(dbg & 2)) {
+                    for (int p0 = 0; p0 < GP; p0 += NB) {
+                        f2 xc[NB];
                         const f2 *om[NB], *o0[NB], *op[NB];
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
+                            xc[b] = X2[((p0 + b) * 4 + sx) * C2_COLS + col];
                             const f2 *ob = O12 + (p0 + b) * 3 * C2_COLS;
                             om[b] = ob + om_ * C2_COLS, o0[b] = ob + o0_ * C2_COLS, op[b] = ob + op_ * C2_COLS;
                         }
                         f2 f[NB], oc[NB];
-                        if (all)
-                            fwd_rows_batch<NB, true>(om, o0, op, col, kF, vF, f, oc);
-                        else
-                            fwd_rows_batch<NB, false>(om, o0, op, col, kF, vF, f, oc);
-                        f2 o2[NB];
+                        fwd_rows_batch<NB, true>(om, o0, op, col, kF, vF, f, oc);
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) o2[b] = (oc[b] + xc[b]) - f[b];
-                        if (fastdiv) {  // one block: the NB reciprocal-division chains interleave
-#pragma unroll
-                            for (int b = 0; b < NB; ++b) val[b] = div_rcp2(o2[b], e_gain, rgain);
-                        } else {
-#pragma unroll
-                            for (int b = 0; b < NB; ++b) val[b] = f2{o2[b].x / e_gain, o2[b].y / e_gain};
+                        for (int b = 0; b < NB; ++b) {
+                            const f2 val = div_rcp2((oc[b] + xc[b]) - f[b], e_gain, rgain);
+                            d[2 * (p0 + b)] = val.x;
+                            d[2 * (p0 + b) + 1] = val.y;
+                            dpair[p0 + b] = val;
                         }
                     }
+                } else {
+                    constexpr int NBG = 1;  // boundary waves (rare): one pair at a time keeps this path's register demand low
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        d[2 * (p0 + b)] = val[b].x;
-                        d[2 * (p0 + b) + 1] = val[b].y;
-                        dpair[p0 + b] = val[b];
+                    for (int p0 = 0; p0 < GP; p0 += NBG) {
+                        f2 xc[NBG], val[NBG];
+#pragma unroll
+                        for (int b = 0; b < NBG; ++b) val[b] = xc[b] = X2[((p0 + b) * 4 + sx) * C2_COLS + col];
+                        if (act && !(dbg & 2)) {
+                            const f2 *om[NBG], *o0[NBG], *op[NBG];
+#pragma unroll
+                            for (int b = 0; b < NBG; ++b) {
+                                const f2 *ob = O12 + (p0 + b) * 3 * C2_COLS;
+                                om[b] = ob + om_ * C2_COLS, o0[b] = ob + o0_ * C2_COLS, op[b] = ob + op_ * C2_COLS;
+                            }
+                            f2 f[NBG], oc[NBG];
+                            if (all)
+                                fwd_rows_batch<NBG, true>(om, o0, op, col, kF, vF, f, oc);
+                            else
+                                fwd_rows_batch<NBG, false>(om, o0, op, col, kF, vF, f, oc);
+                            f2 o2[NBG];
+#pragma unroll
+                            for (int b = 0; b < NBG; ++b) o2[b] = (oc[b] + xc[b]) - f[b];
+                            if (fastdiv) {
+#pragma unroll
+                                for (int b = 0; b < NBG; ++b) val[b] = div_rcp2(o2[b], e_gain, rgain);
+                            } else {
+#pragma unroll
+                                for (int b = 0; b < NBG; ++b) val[b] = f2{o2[b].x / e_gain, o2[b].y / e_gain};
+                            }
+                        }
+#pragma unroll
+                        for (int b = 0; b < NBG; ++b) {
+                            d[2 * (p0 + b)] = val[b].x;
+                            d[2 * (p0 + b) + 1] = val[b].y;
+                            dpair[p0 + b] = val[b];
+                        }
                     }
                 }
                 // first half of the ramp fit (registers only): slope, errors, approximate jump significances
@@ -584,7 +629,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             CH_T(3)
             const RIP_K C2KernArgs *kg = c2_args(kargs);  // S2 copy
             // ---- S2: coefficients and gain of the next row's O2, second half of the fit, tail of pixel (r, c)
-            float kN[9];
+            f2 kN[5];
+            kN[4].y = 0.0f;
             const bool next_on = (r + 1 >= R0) && (r + 1 < R1) && col >= 2 && col < C2_COLS - 2;
             const unsigned vN = load_k(kg->a.kern, r + 1, next_on, kN);
             gain_next = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(kg->a.planes) + (size_t)(NP + 4) * pl4 +
@@ -674,7 +720,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             CH_T(7)
             vF = vN;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) kF[k] = kN[k];
+            for (int k = 0; k < 5; ++k) kF[k] = kN[k];
         }
     }
 #ifdef CH_STAMP

@@ -110,11 +110,15 @@ __device__ __forceinline__ V fwd_rows(const SV *rm, const SV *r0, const SV *rp, 
 // fwd_rows for NB pairs of groups at once: all 9*NB LDS reads are issued first (one exposed LDS latency per
 // batch instead of one per term), then NB independent accumulation chains run interleaved (each chain keeps the
 // reference's term order).  ctr[b] returns the centre value r0[b][t].
+// The nine coefficients travel as five register pairs (k0,k1) (k2,k3) ... (k8,-): a packed multiply broadcasts
+// either half of a pair through op_sel, so no per-coefficient copy into a (k,k) pair is needed.
+#define RIP_KSPLAT(kk2, k) (((k) & 1) ? f2{(kk2)[(k) / 2].y, (kk2)[(k) / 2].y} : f2{(kk2)[(k) / 2].x, (kk2)[(k) / 2].x})
 template <int NB, bool ALL>
 __device__ __forceinline__ void fwd_rows_batch(const f2 *const (&rm)[NB], const f2 *const (&r0)[NB],
-                                               const f2 *const (&rp)[NB], int t, const float (&kk)[9], unsigned valid,
+                                               const f2 *const (&rp)[NB], int t, const f2 (&kk2)[5], unsigned valid,
                                                f2 (&f)[NB], f2 (&ctr)[NB]) {
     f2 v[NB][9];
+    __builtin_amdgcn_sched_barrier(0);  // batches do not overlap: the reads of the next batch stay behind this one's sums
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         v[b][5] = rm[b][t - 1];
@@ -130,12 +134,12 @@ __device__ __forceinline__ void fwd_rows_batch(const f2 *const (&rm)[NB], const 
     __builtin_amdgcn_sched_barrier(0);
     f2 acc[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[b] = v[b][0] * kk[0];
+    for (int b = 0; b < NB; ++b) acc[b] = v[b][0] * RIP_KSPLAT(kk2, 0);
 #pragma unroll
     for (int k = 1; k < 9; ++k) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const f2 p = v[b][k] * kk[k];
+            const f2 p = v[b][k] * RIP_KSPLAT(kk2, k);
             acc[b] = (ALL || ((valid >> k) & 1u)) ? acc[b] + p : acc[b];
         }
     }
