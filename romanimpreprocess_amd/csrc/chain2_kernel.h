@@ -48,6 +48,25 @@ __device__ __forceinline__ unsigned c2_opaque(unsigned x) {
     return x;
 }
 
+// Buffer addressing for the global loads: descriptor (base, no stride, no bound) in four scalar registers, the
+// loop-invariant column offset of the lane as the vector offset, plane + row as a 32-bit scalar offset -- one s_add per
+// load where a 64-bit base costs two.  Every array addressed this way is smaller than 4 GiB.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t c2_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float c2_ld_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ uint32_t c2_ld_u32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+__device__ __forceinline__ uint32_t c2_ld_u16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+}
+__device__ __forceinline__ uint32_t c2_ld_u8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
+}
+
 // The kernel arguments re-read from the kernarg segment (scalar loads from the constant address space) through a
 // pointer made opaque once per phase: the ~25 pointers and sizes of ChainArgs then live in scalar registers only
 // from their first to their last use inside a phase, instead of all being loop invariants that the register
@@ -162,18 +181,18 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             for (int k = 0; k < 5; ++k) kk2[k] = f2{(k == 0) ? 1.0f : 0.001f, 0.001f};
             return want ? lane_mask : 0u;
         }
-        size_t rowoff[3];
-        const unsigned ox[3] = {c2_opaque(cx4[0]), c2_opaque(cx4[1]), c2_opaque(cx4[2])};
+        unsigned rowoff[3];
         bool rok[3];
 #pragma unroll
         for (int dyi = 0; dyi < 3; ++dyi) {
             const int sy = y - (dyi - 1);
             rok[dyi] = sy >= ay0 && sy < ay1;
-            rowoff[dyi] = (size_t)((unsigned)min(max(sy, 0), ny - 1) * row4);
+            rowoff[dyi] = (unsigned)min(max(sy, 0), ny - 1) * row4;
         }
         // terms by source row: dy = -1 -> k in {2, 7, 8}, dy = 0 -> {0, 3, 4}, dy = +1 -> {1, 5, 6}
         const unsigned rowbits = (rok[0] ? 0x184u : 0u) | (rok[1] ? 0x019u : 0u) | (rok[2] ? 0x062u : 0u);
-        const char *kb = reinterpret_cast<const char *>(kern_base);
+        const __amdgpu_buffer_rsrc_t kr = c2_rsrc(kern_base);
+        unsigned pofs = 0;  // plane offset, planes walked in memory order (plane = 3*(1+dy) + (1+dx))
 #pragma unroll
         for (int p = 0; p < 9; ++p) {
             const int dy = p / 3 - 1, dx = p % 3 - 1;
@@ -181,12 +200,12 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             // 6 (1,-1), 7 (-1,1), 8 (-1,-1)
             const int k = (dy == 0) ? (dx == 0 ? 0 : dx == 1 ? 3 : 4) : (dy == 1) ? (dx == 0 ? 1 : dx == 1 ? 5 : 6)
                                                                                   : (dx == 0 ? 2 : dx == 1 ? 7 : 8);
-            const float kv_ = *reinterpret_cast<const float *>(kb + rowoff[dy + 1] + ox[dx + 1]);
+            const float kv_ = c2_ld_f32(kr, cx4[dx + 1], pofs + rowoff[dy + 1]);
             if (k & 1)
                 kk2[k / 2].y = kv_;
             else
                 kk2[k / 2].x = kv_;
-            kb += pl4;
+            pofs += pl4;
         }
         const unsigned um = (want && y >= ay0 && y < ay1) ? rowbits : 0u;
         return lane_mask & um;
@@ -198,61 +217,24 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
 #endif
     if (!fit_role) {
         // =========================================================================== ingest waves
-        auto fetch_row = [&](int y, RowRegs<NP, G> &rr) {
-            const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
-            const unsigned o4 = c2_opaque(cc4), o2 = c2_opaque(cc2), o1 = c2_opaque(cc1);
-            const char *pb = reinterpret_cast<const char *>(planes) + (size_t)(yl * row4);  // running plane base (scalar)
-#pragma unroll
-            for (int L = 0; L < NP; ++L) {
-                rr.cf[L] = *reinterpret_cast<const float *>(pb + o4);
-                pb += pl4;
-            }
-            rr.smin = *reinterpret_cast<const float *>(pb + o4);
-            pb += pl4;
-            rr.smax = *reinterpret_cast<const float *>(pb + o4);
-            pb += pl4;
-            rr.sref = *reinterpret_cast<const float *>(pb + o4);
-            pb += pl4;
-            rr.dq = *reinterpret_cast<const uint32_t *>(pb + o4);
-            pb += pl4;
-            rr.gain = *reinterpret_cast<const float *>(pb + o4);
-            const char *sb = reinterpret_cast<const char *>(d16) + (size_t)(yl * (row4 >> 1));
-            const char *qb = reinterpret_cast<const char *>(gdq) + (size_t)(yl * (row4 >> 2));
-            const char *db = reinterpret_cast<const char *>(dark) + (size_t)(yl * row4);
-            const char *bb = reinterpret_cast<const char *>(bias) + (size_t)(yl * row4);
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                rr.S[g] = *reinterpret_cast<const uint16_t *>(sb + o2);
-                rr.q[g] = *reinterpret_cast<const uint8_t *>(qb + o1);
-                rr.dk[g] = *reinterpret_cast<const float *>(db + o4);
-                rr.bs[g] = *reinterpret_cast<const float *>(bb + o4);
-                sb += pl4 >> 1;
-                qb += npix;
-                db += pl4;
-                bb += pl4;
-            }
-        };
-        // The same loads in pieces, issued between blocks of arithmetic (scheduling fences keep them there): a burst of
-        // 46 loads per wave from all waves at once saturates the CU's address unit while the vector ALUs idle.
+        // plane p of the calibration slab at row yl: scalar offset p*pl4 + yl*row4; groups likewise in their arrays
         auto fetch_groups = [&](const RIP_K ChainArgs *ka, int y, int g0, int g1, RowRegs<NP, G> &rr) {
             if (dbg & 64) return;
             __builtin_amdgcn_sched_barrier(0);
             const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
-            const unsigned o4 = c2_opaque(cc4), o2 = c2_opaque(cc2), o1 = c2_opaque(cc1);
-            const char *sb = reinterpret_cast<const char *>(ka->data) + (size_t)(yl * (row4 >> 1)) + (size_t)g0 * (pl4 >> 1);
-            const char *qb = reinterpret_cast<const char *>(ka->gdq) + (size_t)(yl * (row4 >> 2)) + (size_t)g0 * npix;
-            const char *db = reinterpret_cast<const char *>(ka->dark_data) + (size_t)(yl * row4) + (size_t)g0 * pl4;
-            const char *bb = reinterpret_cast<const char *>(ka->bias) + (size_t)(yl * row4) + (size_t)g0 * pl4;
+            const __amdgpu_buffer_rsrc_t rs = c2_rsrc(ka->data), rq = c2_rsrc(ka->gdq), rd = c2_rsrc(ka->dark_data),
+                                         rb = c2_rsrc(ka->bias);
+            unsigned o4 = yl * row4 + (unsigned)g0 * pl4, o2 = yl * (row4 >> 1) + (unsigned)g0 * (pl4 >> 1),
+                     o1 = yl * (row4 >> 2) + (unsigned)g0 * npix;
 #pragma unroll
             for (int g = g0; g < g1; ++g) {
-                rr.S[g] = *reinterpret_cast<const uint16_t *>(sb + o2);
-                rr.q[g] = *reinterpret_cast<const uint8_t *>(qb + o1);
-                rr.dk[g] = *reinterpret_cast<const float *>(db + o4);
-                rr.bs[g] = *reinterpret_cast<const float *>(bb + o4);
-                sb += pl4 >> 1;
-                qb += npix;
-                db += pl4;
-                bb += pl4;
+                rr.S[g] = c2_ld_u16(rs, cc2, o2);
+                rr.q[g] = c2_ld_u8(rq, cc1, o1);
+                rr.dk[g] = c2_ld_f32(rd, cc4, o4);
+                rr.bs[g] = c2_ld_f32(rb, cc4, o4);
+                o4 += pl4;
+                o2 += pl4 >> 1;
+                o1 += npix;
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -261,25 +243,30 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             if (dbg & 64) return;
             __builtin_amdgcn_sched_barrier(0);
             const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
-            const unsigned o4 = c2_opaque(cc4);
-            const char *pb = reinterpret_cast<const char *>(ka->planes) + (size_t)(yl * row4) + (size_t)i0 * pl4;
+            const __amdgpu_buffer_rsrc_t rp = c2_rsrc(ka->planes);
+            unsigned o4 = yl * row4 + (unsigned)i0 * pl4;
 #pragma unroll
             for (int i = i0; i < i1; ++i) {
                 if (i < NP)
-                    rr.cf[i] = *reinterpret_cast<const float *>(pb + o4);
+                    rr.cf[i] = c2_ld_f32(rp, cc4, o4);
                 else if (i == NP)
-                    rr.smin = *reinterpret_cast<const float *>(pb + o4);
+                    rr.smin = c2_ld_f32(rp, cc4, o4);
                 else if (i == NP + 1)
-                    rr.smax = *reinterpret_cast<const float *>(pb + o4);
+                    rr.smax = c2_ld_f32(rp, cc4, o4);
                 else if (i == NP + 2)
-                    rr.sref = *reinterpret_cast<const float *>(pb + o4);
+                    rr.sref = c2_ld_f32(rp, cc4, o4);
                 else if (i == NP + 3)
-                    rr.dq = *reinterpret_cast<const uint32_t *>(pb + o4);
+                    rr.dq = c2_ld_u32(rp, cc4, o4);
                 else
-                    rr.gain = *reinterpret_cast<const float *>(pb + o4);
-                pb += pl4;
+                    rr.gain = c2_ld_f32(rp, cc4, o4);
+                o4 += pl4;
             }
             __builtin_amdgcn_sched_barrier(0);
+        };
+        auto fetch_row = [&](int y, RowRegs<NP, G> &rr) {  // prologue: the whole first row at once
+            const RIP_K ChainArgs *ka = &kargs->a;
+            fetch_coefs(ka, y, 0, NP + 5, rr);
+            fetch_groups(ka, y, 0, G, rr);
         };
         constexpr int NCO = NP + 5;                 // coefficient-type planes per pixel
         constexpr int CO_STEP = (NCO + GP - 1) / GP;  // issued per pair of C
@@ -520,23 +507,21 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             const unsigned rc_ = (unsigned)min(max(r, 0), ny - 1);
             const unsigned pe = rc_ * (unsigned)nx + cc1;
             // ---- S1: read noise of the pixel (used by the fit), then the second IPC iterate of row r
-            const float e_read = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(kf->a.planes) +
-                                                                  (size_t)(NP + 5) * pl4 + (size_t)(rc_ * row4) + c2_opaque(cc4));
+            const __amdgpu_buffer_rsrc_t rpl = c2_rsrc(kf->a.planes);
+            const unsigned t_row = rc_ * row4;  // byte offset of row r in an f32 plane (uniform)
+            const float e_read = c2_ld_f32(rpl, cc4, (unsigned)(NP + 5) * pl4 + t_row);
             const float e_gain = gain_next;
             // calibration planes of the tail (finish) of the same pixel, consumed after the barrier
-            const size_t t_row4 = (size_t)(rc_ * row4);           // byte offset of row r in an f32 plane (uniform)
+            const size_t t_row4 = (size_t)t_row;
             const size_t pe_row = (size_t)(rc_ * (unsigned)nx);   // element offset of row r
-            const char *tb = reinterpret_cast<const char *>(kf->a.planes) + t_row4;
-            const unsigned t4 = c2_opaque(cc4);
-            const float e_dark = *reinterpret_cast<const float *>(tb + (size_t)(NP + 6) * pl4 + t4);
-            const uint32_t e_ff = *reinterpret_cast<const uint32_t *>(tb + (size_t)(NP + 8) * pl4 + t4);
-            const uint32_t e_pdq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(kf->a.pdq) + t_row4 + t4);
-            // flat / dark_dq == null: read the gain plane instead (value unused), keeps the loads in one straight-line block
-            const char *fb = kf->a.flat ? reinterpret_cast<const char *>(kf->a.flat) : reinterpret_cast<const char *>(kf->a.planes);
-            const float e_flat_raw = *reinterpret_cast<const float *>(fb + t_row4 + t4);
+            const float e_dark = c2_ld_f32(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_row);
+            const uint32_t e_ff = c2_ld_u32(rpl, cc4, (unsigned)(NP + 8) * pl4 + t_row);
+            const uint32_t e_pdq = c2_ld_u32(c2_rsrc(kf->a.pdq), cc4, t_row);
+            // flat / dark_dq == null: read the first slab plane instead (value unused), keeps the loads in one block
+            const float e_flat_raw = c2_ld_f32(c2_rsrc(kf->a.flat ? (const void *)kf->a.flat : (const void *)kf->a.planes), cc4, t_row);
             const float e_flat = kf->a.flat ? e_flat_raw : 1.0f;
-            const char *ddb = kf->a.dark_dq ? reinterpret_cast<const char *>(kf->a.dark_dq) : reinterpret_cast<const char *>(kf->a.planes);
-            const uint32_t e_ddq_raw = *reinterpret_cast<const uint32_t *>(ddb + t_row4 + t4);
+            const uint32_t e_ddq_raw =
+                c2_ld_u32(c2_rsrc(kf->a.dark_dq ? (const void *)kf->a.dark_dq : (const void *)kf->a.planes), cc4, t_row);
             const uint32_t e_ddq = kf->a.dark_dq ? e_ddq_raw : 0u;
             float d[G];
             f2 dpair[GP];
@@ -633,8 +618,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             kN[4].y = 0.0f;
             const bool next_on = (r + 1 >= R0) && (r + 1 < R1) && col >= 2 && col < C2_COLS - 2;
             const unsigned vN = load_k(kg->a.kern, r + 1, next_on, kN);
-            gain_next = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(kg->a.planes) + (size_t)(NP + 4) * pl4 +
-                                                         (size_t)((unsigned)min(max(r + 1, 0), ny - 1) * row4) + c2_opaque(cc4));
+            gain_next = c2_ld_f32(c2_rsrc(kg->a.planes), cc4, (unsigned)(NP + 4) * pl4 + (unsigned)min(max(r + 1, 0), ny - 1) * row4);
             CH_T(4)
             C2_DRAIN()
             CH_T(5)
