@@ -85,18 +85,19 @@ __device__ __forceinline__ const RIP_K C2KernArgs *c2_args(const RIP_K C2KernArg
 }
 
 template <int NP, int G, int START>
-__global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
+__global__ __launch_bounds__(C2_THREADS, (G > 8 ? 2 : 4)) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
                                                                const RipVariant *__restrict__ vars,
                                                                const float *__restrict__ kvals,
                                                                const RipDiff *__restrict__ diffs, double guard) {
-    static_assert(G % 2 == 0 && G <= 8, "pairs of groups, at most 8 (groupdq bytes travel as one 64-bit word)");
+    static_assert(G % 2 == 0 && G > 4 && G <= 16, "pairs of groups; the groupdq bytes travel packed four to a word");
+    constexpr int QW = (G + 3) / 4;  // words of packed group flags per pixel
     constexpr int GP = G / 2;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     f2 *X2 = reinterpret_cast<f2 *>(lds_raw);                       // [GP][4][C2_COLS]  x = gain*phi, pair-interleaved
     f2 *O12 = X2 + GP * 4 * C2_COLS;                                // [GP][3][C2_COLS]  first Neumann iterate
     uint32_t *DQ = reinterpret_cast<uint32_t *>(O12 + GP * 3 * C2_COLS);  // [4][C2_COLS] linearity dq of the row
-    uint2 *QS = reinterpret_cast<uint2 *>(DQ + 4 * C2_COLS);       // [4][C2_COLS] groupdq bytes of the pixel
-    double *LN = reinterpret_cast<double *>(QS + 4 * C2_COLS);      // [3][G][2] channel lines of this strip
+    uint32_t *QS = DQ + 4 * C2_COLS;                                // [4][QW][C2_COLS] groupdq bytes of the pixel, packed
+    double *LN = reinterpret_cast<double *>(QS + 4 * QW * C2_COLS);  // [3][G][2] channel lines of this strip
 
     // ChainArgs is the first kernel argument: it sits at offset 0 of the kernarg segment
     const RIP_K C2KernArgs *kargs = (const RIP_K C2KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -296,7 +297,9 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             f2 *xs = X2 + slot * C2_COLS + col;
             const bool act = col_act && yi >= ay0 && yi < ay1;
             uint32_t dq = rr.dq;
-            uint32_t w0 = 0, w1 = 0;  // the pixel's groupdq bytes, packed
+            uint32_t w[QW];  // the pixel's groupdq bytes, packed
+#pragma unroll
+            for (int i = 0; i < QW; ++i) w[i] = 0;
             const float smin = rr.smin;
             const float span = rr.smax - smin;
             const bool fastdiv = __all(rcp_safe(span));
@@ -326,10 +329,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                             S = v + dk;
                             if (act) S = S - rr.bs[g];
                             Sv[e] = S;
-                            if (g < 4)
-                                w0 |= (rr.q[g] & 0xffu) << (8 * g);
-                            else
-                                w1 |= (rr.q[g] & 0xffu) << (8 * (g - 4));
+                            w[g / 4] |= (rr.q[g] & 0xffu) << (8 * (g & 3));
                         }
                         SS[b] = f2{Sv[0], Sv[1]};
                         const f2 t = SS[b] - f2{smin, smin};
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                             const int g = 2 * p + e;
                             vout[e] = ((dq & bad) == 0) ? (e ? phi[b].y : phi[b].x) : (e ? fb.y : fb.x);
                             const bool first = (g == 0) && a.do_not_flag_first;
-                            const uint32_t qg = ((g < 4 ? w0 : w1) >> (8 * (g & 3)));
+                            const uint32_t qg = w[g / 4] >> (8 * (g & 3));
                             if (!first && ex[b][e] && (qg & DQ_SATURATED) == 0) dq |= DQ_NO_LIN_CORR;
                         }
                         f2 xv = {vout[0], vout[1]};
@@ -438,7 +438,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             if (do_a) {
                 const bool keep = a_full && col_ok;
                 DQ[slot * C2_COLS + col] = keep ? dq : 0u;
-                QS[slot * C2_COLS + col] = keep ? uint2{w0, w1} : uint2{0u, 0u};
+#pragma unroll
+                for (int i = 0; i < QW; ++i) QS[(slot * QW + i) * C2_COLS + col] = keep ? w[i] : 0u;
             }
             // IPC coefficients of row yc, consumed by C after the barrier; issued here so that their registers are not live
             // during A
@@ -525,7 +526,9 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             const uint32_t e_ddq = kf->a.dark_dq ? e_ddq_raw : 0u;
             float d[G];
             f2 dpair[GP];
-            uint2 qw = {0u, 0u};  // the pixel's groupdq bytes, packed
+            uint32_t qw[QW];  // the pixel's groupdq bytes, packed
+#pragma unroll
+            for (int i = 0; i < QW; ++i) qw[i] = 0;
             uint32_t lin_dq = 0;  // linearity dq of the pixel
             RipFitState fs;
             const bool act = emit && col_act && r >= ay0 && r < ay1;
@@ -534,7 +537,8 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
             CH_T(1)
             if (emit) {
                 const int sx = r & 3;
-                qw = QS[sx * C2_COLS + col];
+#pragma unroll
+                for (int i = 0; i < QW; ++i) qw[i] = QS[(sx * QW + i) * C2_COLS + col];
                 lin_dq = DQ[sx * C2_COLS + col];
                 const bool fastdiv = __all(rcp_safe(e_gain) || !act);
                 const float rgain = rip_rcp_mid(e_gain);
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                     }
                 }
                 // first half of the ramp fit (registers only): slope, errors, approximate jump significances
-                const bool unsat = ((((G - 1) < 4 ? qw.x : qw.y) >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
+                const bool unsat = ((qw[(G - 1) / 4] >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
                 if (!(dbg & 4))
                     fit_full_pk_a<G, rip_full_valid<G, START>()>(dpair, fc0, v0, kf->a.dense, e_gain, e_read, unsat && act, kf->guard, fs);
             }
@@ -627,10 +631,13 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
 #pragma unroll
                     for (int g = 0; g < G; ++g) kg->a.cube_out[(unsigned)g * npix + pe] = d[g];
                 }
-                const bool anysat = ((qw.x | qw.y) & 0x02020202u) != 0u;
+                uint32_t qor = 0;
+#pragma unroll
+                for (int i = 0; i < QW; ++i) qor |= qw[i];
+                const bool anysat = (qor & 0x02020202u) != 0u;
                 float s, er, ep;
                 uint32_t jmask = 0;
-                const bool unsat = ((((G - 1) < 4 ? qw.x : qw.y) >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
+                const bool unsat = ((qw[(G - 1) / 4] >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
                 if (dbg & 4) {
                     s = d[0], er = e_read, ep = e_gain;
                 } else {
@@ -641,7 +648,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                     if (__any(anysat)) {
                         uint32_t qe[G];
 #pragma unroll
-                        for (int g = 0; g < G; ++g) qe[g] = ((g < 4 ? qw.x : qw.y) >> (8 * (g & 3))) & 0xffu;
+                        for (int g = 0; g < G; ++g) qe[g] = (qw[g / 4] >> (8 * (g & 3))) & 0xffu;
                         trunc_layers<G, G - 1>(d, qe, kg->h, kg->vars, kg->kvals, kg->diffs, e_gain, e_read, act, kg->guard, s, er, ep,
                                                jmask);
                     }
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
                 // ---- T: flag propagation (fitting.py:339-353), finish and stores of pixel (r, c)
                 if (!(dbg & 8)) {
                     uint8_t *gq = kg->a.gdq_out ? kg->a.gdq_out + pe_row : nullptr;
-                    uint32_t pdq = propagate_flags_packed<G>(qw.x, qw.y, jmask, start, e_pdq | lin_dq, gq, npix, c2_opaque(cc1));
+                    uint32_t pdq = propagate_flags_packed<G>(qw, jmask, start, e_pdq | lin_dq, gq, npix, c2_opaque(cc1));
                     if (kg->a.finish) {
                         // gen_cal_image.py:458-475, 213-229, 607-629.  One wave vote selects the straight-line form built
                         // from the short exact operations (rip_rcp_mid, rip_sqrt_mid, sqrt(x*x) = x: tools/gpu_checks/
@@ -716,7 +723,7 @@ __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(ChainArgs a, cons
 }
 
 static inline size_t chain2_lds_bytes(int G) {
-    return (size_t)(G / 2) * C2_COLS * 8 * (4 + 3) + (size_t)C2_COLS * 4 * (4 + 8) + (size_t)3 * G * 2 * 8;
+    return (size_t)(G / 2) * C2_COLS * 8 * (4 + 3) + (size_t)C2_COLS * 4 * 4 * (1 + (G + 3) / 4) + (size_t)3 * G * 2 * 8;
 }
 
 template <int NP, int G, int START>
@@ -731,7 +738,7 @@ static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
     }
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
-    const int max_wg = 16 / (C2_THREADS / 64);  // 16 waves per CU = 4 waves/SIMD at <= 128 VGPRs
+    const int max_wg = (G > 8 ? 8 : 16) / (C2_THREADS / 64);  // 4 waves/SIMD at <= 128 VGPRs (2 at 256 for G = 16)
     if (per_cu > max_wg) per_cu = max_wg;
     const int nstrips = (a.nx + C2_OUTW - 1) / C2_OUTW;
     int nranges = (int)(((long)ncu * per_cu) / nstrips);

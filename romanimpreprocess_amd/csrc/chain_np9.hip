@@ -2,11 +2,12 @@
 #include "chain2_kernel.h"
 
 int rip_launch_chain_np9(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int k_dtype) {
-    // wave-specialised kernel for the common case (f32 ipc4d, 6 or 8 groups); general fused kernel otherwise
+    // wave-specialised kernel for the common case (f32 ipc4d, 6, 8 or 16 groups); general fused kernel otherwise
     if (k_dtype == RIP_F32 && ctx->use_chain2) {
         int rc = 1;
         if (a.ngrp == 8) rc = launch_chain2<9, 8>(ctx, plan, a);
         if (a.ngrp == 6) rc = launch_chain2<9, 6>(ctx, plan, a);
+        if (a.ngrp == 16) rc = launch_chain2<9, 16>(ctx, plan, a);
         if (rc != 1) {
             ctx->last_form = 2;
             return rc;

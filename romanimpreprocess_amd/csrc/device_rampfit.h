@@ -609,30 +609,37 @@ __device__ __forceinline__ uint32_t rip_spread_bit1(uint32_t t) {  // bytes hold
     return t;
 }
 template <int G>
-__device__ __forceinline__ uint32_t propagate_flags_packed(uint32_t w0, uint32_t w1, uint32_t jmask, int start,
+__device__ __forceinline__ uint32_t propagate_flags_packed(const uint32_t (&w)[(G + 3) / 4], uint32_t jmask, int start,
                                                            uint32_t pdq_in, uint8_t *gdq_row, unsigned gstride,
                                                            unsigned lane_off) {
-    static_assert(G > 4 && G <= 8, "two flag words");
-    constexpr uint32_t PAD1 = (G >= 8) ? 0u : (0x01010101u << (8 * (G - 4)));  // missing groups count as DO_NOT_USE
-    // bit i of jmask -> JUMP_DET (0x04) of byte i
-    const uint32_t rq0 = w0 | ((__umul24(jmask & 0xFu, 0x00204081u) & 0x01010101u) << 2);
-    const uint32_t rq1 = w1 | ((__umul24((jmask >> 4) & 0xFu, 0x00204081u) & 0x01010101u) << 2);
+    static_assert(G > 4 && G <= 16, "flag words");
+    constexpr int QW = (G + 3) / 4;
+    // bytes of the last word beyond group G-1: missing groups count as DO_NOT_USE in the all-groups test
+    constexpr uint32_t PADL = (G % 4 == 0) ? 0u : (0x01010101u << (8 * (G % 4)));
+    uint32_t rq[QW];
+#pragma unroll
+    for (int i = 0; i < QW; ++i)  // bit g of jmask -> JUMP_DET (0x04) of byte g
+        rq[i] = w[i] | ((__umul24((jmask >> (4 * i)) & 0xFu, 0x00204081u) & 0x01010101u) << 2);
     if (gdq_row) {  // uniform
         uint8_t *p = gdq_row;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            *(p + lane_off) = (uint8_t)((g < 4 ? rq0 : rq1) >> (8 * (g & 3)));
+            *(p + lane_off) = (uint8_t)(rq[g / 4] >> (8 * (g & 3)));
             p += gstride;
         }
     }
-    const uint32_t s0 = rq0 & 0x02020202u, s1 = rq1 & 0x02020202u;  // SATURATED bit of every group
-    const uint32_t u0 = rq0 & ~rip_spread_bit1(s0), u1 = rq1 & ~rip_spread_bit1(s1);  // flags of the unsaturated groups
-    uint32_t red = (u0 | u1) | (s0 | s1);  // OR over groups: bit 1 = any saturated, other bits = OR of the unsaturated
-    red |= red >> 16;
+    uint32_t red = 0, alld = 0x01010101u;
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+        const uint32_t sat = rq[i] & 0x02020202u;                      // SATURATED bit of every group
+        red |= (rq[i] & ~rip_spread_bit1(sat)) | sat;                  // flags of the unsaturated groups, plus the bit itself
+        alld &= (i == QW - 1) ? (rq[i] | PADL) : rq[i];
+    }
+    red |= red >> 16;  // OR over groups: bit 1 = any saturated, other bits = OR of the unsaturated groups' flags
     red |= red >> 8;
     uint32_t pdq2 = red & 0xFEu;  // without DO_NOT_USE
-    const bool all_dnu = ((rq0 & (rq1 | PAD1)) & 0x01010101u) == 0x01010101u;
-    const bool early = ((w0 >> (8 * (1 + start))) & DQ_SATURATED) != 0;  // rdq[1 + start]
+    const bool all_dnu = (alld & 0x01010101u) == 0x01010101u;
+    const bool early = ((w[0] >> (8 * (1 + start))) & DQ_SATURATED) != 0;  // rdq[1 + start]
     if (all_dnu || early) pdq2 |= DQ_DO_NOT_USE;
     return (pdq_in & DQ_REFERENCE_PIXEL) ? pdq_in : (pdq_in | pdq2);
 }

@@ -193,6 +193,8 @@ SPECIALISED = [
     ("g8_np11_start1", (40, 256), synth.READ_PATTERN_8, 10, True),
     ("g8_np9_start0", (56, 256), synth.READ_PATTERN_8, 8, False),
     ("g8_np4_start1", (40, 128), synth.READ_PATTERN_8, 3, True),
+    ("g16_np9_start1", (40, 256), synth.READ_PATTERN_16, 8, True),
+    ("g16_np4_start0", (32, 128), synth.READ_PATTERN_16, 3, False),
 ]
 
 
