@@ -85,6 +85,10 @@ typedef struct {
     /* biascorr file: data (ngrp_bias,ny-2nb,nx-2nb) f32; NULL = skip */
     int32_t ngrp_bias;
     const float *biascorr;
+    /* saturation file: data (ny,nx) f32 threshold in DN, dq (ny,nx) u32 (NO_SAT_CHECK honoured) or NULL.
+       Only needed for rip_ramp_desc::flag_saturation; NULL = not available. */
+    const float *saturation;
+    const uint32_t *saturation_dq;
 } rip_caldir_desc;
 
 /* ---- ramp-fit plan: MA table, weights, thresholds (host scalars) --- */
@@ -121,6 +125,16 @@ typedef struct {
     /* optional override of the channel-step line fit: (ngrp,nx/128,2) f64 (m,c) computed by the
        host with LAPACK exactly as reference_subtraction.py:57-60; NULL = fitted on the device */
     const double *channel_lines;
+    /* dq-init + saturation flagging on the device before the chain (gen_cal_image.py:148-185: romancal's dq_init and
+       saturation steps with n_pix_grow_sat = 1; stcal's source is not in the reference tree, so this follows the
+       documented behaviour restated in romanimpreprocess_amd/L1_to_L2/gen_cal_image.py:flag_saturation -- PARITY
+       UNPINNED).  flag_saturation != 0: group g >= sat_skip_firstn is SATURATED where data >= threshold in the 3x3
+       neighbourhood, sticky for later groups and set on the sat_backup preceding groups; pixeldq |= SATURATED where any
+       group is flagged; DO_NOT_USE is set on group 0 when the plan excludes the first group.  groupdq may then be NULL
+       (= zeros); pixeldq is the mask dq. */
+    int32_t flag_saturation;
+    int32_t sat_backup;      /* config SATURATION_BACKUP (gen_cal_image.py:172), default 1 */
+    int32_t sat_skip_firstn; /* 1 in the reference's call */
 } rip_ramp_desc;
 
 typedef struct {

@@ -95,8 +95,9 @@ def load_caldir_arrays(caldir):
     cal = {}
     for key in ("dark", "read", "gain", "linearitylegendre", "ipc4d", "flat"):
         cal[key] = calio.roman_branch(caldir[key])
-    if "biascorr" in caldir:
-        cal["biascorr"] = calio.roman_branch(caldir["biascorr"])
+    for key in ("biascorr", "saturation"):
+        if key in caldir:
+            cal[key] = calio.roman_branch(caldir[key])
     return cal
 
 
@@ -127,19 +128,26 @@ def calibrateimage(config, verbose=True, calibrator=None):
     meta["nborder"] = pars.nborder
     nb = pars.nborder
     mylog.append("Initialized data\n")
-    saturation_check(ramp, caldir, mylog, backup=backup)
-    mylog.append("Saturation check complete\n")
 
     cb = calibrator or pipeline.Calibrator()
     slot = _caldir_slot(cb, caldir)
+    # saturation flagging: on the device, inside the calibrate call (config SATURATION_ON_HOST = true keeps the numpy
+    # restatement above)
+    sat_on_device = "saturation" in caldir and not config.get("SATURATION_ON_HOST", False)
+    if not sat_on_device:
+        saturation_check(ramp, caldir, mylog, backup=backup)
+    mylog.append("Saturation check " + ("on the device\n" if sat_on_device else "complete\n"))
     exclude_first = config.get("EXCLUDE_FIRST", True)
     area = None
     if "AREAFACTOR" in config:
         with calio.open_tree(config["AREAFACTOR"]) as f:
             area = np.asarray(f["roman"]["data"], dtype=np.float64)
     ramp["read_pattern"], ramp["frame_time"] = meta["read_pattern"], meta["frame_time"]
+    if sat_on_device:
+        ramp["groupdq"] = None  # zeros + DO_NOT_USE on the first group: made on the device
     res = cb.calibrate(slot, ramp, exclude_first=exclude_first, ramp_opt_pars=config.get("RAMP_OPT_PARS"),
-                       jump_pars=config.get("JUMP_DETECT_PARS"), area_factor=area)
+                       jump_pars=config.get("JUMP_DETECT_PARS"), area_factor=area, flag_saturation=sat_on_device,
+                       saturation_backup=backup)
     K = res["K"]
     uopt = config.get("RAMP_OPT_PARS", planmod.DEFAULT_RAMP_OPT_PARS)
     mylog.append(f"\n\nRamp fit optimized for u = {planmod.ramp_opt_u(uopt):11.5E} s**-1\n")

@@ -37,6 +37,7 @@ class CaldirDesc(C.Structure):
         ("ipc4d", C.c_void_p), ("ipc_dtype", C.c_int32),
         ("flat", c_float_p),
         ("ngrp_bias", C.c_int32), ("biascorr", c_float_p),
+        ("saturation", c_float_p), ("saturation_dq", c_u32_p),
     ]
 
 
@@ -56,6 +57,7 @@ class RampDesc(C.Structure):
         ("location", C.c_int32), ("ngrp", C.c_int32), ("data", C.c_void_p), ("data_dtype", C.c_int32),
         ("amp33", C.c_void_p), ("groupdq", C.c_void_p), ("pixeldq", C.c_void_p), ("area_factor", C.c_void_p),
         ("channel_lines", C.c_void_p),
+        ("flag_saturation", C.c_int32), ("sat_backup", C.c_int32), ("sat_skip_firstn", C.c_int32),
     ]
 
 
@@ -254,6 +256,10 @@ class Context:
             b = cal["biascorr"]["data"]
             d.ngrp_bias = b.shape[0]
             d.biascorr = P(b, np.float32, c_float_p)
+        if cal.get("saturation") is not None:  # only needed for flag_saturation (device dq-init + saturation flagging)
+            d.saturation = P(cal["saturation"]["data"], np.float32, c_float_p)
+            if cal["saturation"].get("dq") is not None:
+                d.saturation_dq = P(cal["saturation"]["dq"], np.uint32, c_u32_p)
         self.check(self.lib.rip_caldir_upload(self.h, int(slot), C.byref(d)))
         return (ny, nx)
 

@@ -81,7 +81,7 @@ int dev_copy_in(rip_ctx *ctx, void **dst, const void *src, size_t bytes) {
 
 void free_cal(RipCal &c) {
     // everything else (linearity planes, gain if f32, read noise, dark rate, flat planes) lives in the slab
-    void *ptrs[] = {c.dark_data, c.dark_slope, c.dark_dq, c.amp33_med, c.ipc, c.bias, c.slab,
+    void *ptrs[] = {c.dark_data, c.dark_slope, c.dark_dq, c.amp33_med, c.ipc, c.bias, c.slab, c.sat_thr, c.sat_dq,
                     c.gain_dtype == RIP_F64 ? c.gain : nullptr};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -140,7 +140,7 @@ void rip_ctx_destroy(rip_ctx *ctx) {
             if (p->dev) (void)hipFree(p->dev);
             delete p;
         }
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 10; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) {
@@ -296,6 +296,8 @@ int rip_caldir_upload(rip_ctx *ctx, int slot, const rip_caldir_desc *d) {
     }
     UP(c.dark_slope, d->dark_slope, npix * 4);
     UP(c.dark_dq, d->dark_dq, npix * 4);
+    UP(c.sat_thr, d->saturation, npix * 4);
+    UP(c.sat_dq, d->saturation_dq, npix * 4);
     c.read_noise = plane(5);
     UPS(c.read_noise, d->read_noise, npix * 4);
     UP(c.amp33_med, d->amp33_med, (size_t)c.ny * RIP_CW * 4);
@@ -604,7 +606,10 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     if (do_ref && (!c.dark_data || c.ngrp_dark < G)) return rip_fail(ctx, RIP_EINVAL, "calibrate: dark.data has %d groups, ramp %d", c.ngrp_dark, G);
     if (do_bias && c.ngrp_bias < G) return rip_fail(ctx, RIP_EINVAL, "calibrate: biascorr has %d groups, ramp %d", c.ngrp_bias, G);
     if (do_lin && !c.lin_coefs) return rip_fail(ctx, RIP_EINVAL, "calibrate: no linearity arrays in caldir slot %d", slot);
-    if ((do_fit || do_lin) && (!in->groupdq || !in->pixeldq)) return rip_fail(ctx, RIP_EINVAL, "calibrate: groupdq/pixeldq required");
+    const bool do_sat = in->flag_saturation != 0;
+    if (do_sat && !c.sat_thr) return rip_fail(ctx, RIP_EINVAL, "calibrate: flag_saturation needs the saturation array in caldir slot %d", slot);
+    if ((do_fit || do_lin) && ((!in->groupdq && !do_sat) || !in->pixeldq))
+        return rip_fail(ctx, RIP_EINVAL, "calibrate: groupdq/pixeldq required");
     if (do_fit && (!out->slope || !out->err_read || !out->err_poisson || !out->pixeldq))
         return rip_fail(ctx, RIP_EINVAL, "calibrate: output planes required");
     if ((stages & RIP_STAGE_DARK) && !c.dark_rate) return rip_fail(ctx, RIP_EINVAL, "calibrate: no dark_slope in caldir");
@@ -640,6 +645,20 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         d_area = (const double *)put(in->area_factor, b_area);
         d_lines_ovr = (const double *)put(in->channel_lines, (size_t)G * nch * 16);
         RIP_HIP(ctx, hipGetLastError());
+    }
+    if (do_sat) {
+        // dq-init + saturation flagging into workspace copies of the flag arrays (the caller's inputs stay untouched)
+        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+        char *w = (char *)rip_ws(ctx, 8, al(b_gdq) + al(b_pdq));
+        if (!w) return RIP_ENOMEM;
+        uint8_t *g2 = (uint8_t *)w;
+        uint32_t *p2 = (uint32_t *)(w + al(b_gdq));
+        const int dnu_first = (plan && plan->h.start == 1) ? 1 : 0;  // the plan excludes the first group
+        int rcs = rip_launch_satflag(ctx, d_data, in->data_dtype, c.sat_thr, c.sat_dq, d_gdq, d_pdq, g2, p2, G, ny, nx,
+                                     in->sat_backup, in->sat_skip_firstn, dnu_first);
+        if (rcs) return rcs;
+        d_gdq = g2;
+        d_pdq = p2;
     }
     // ---- outputs on the device
     float *o_slope = out->slope, *o_er = out->err_read, *o_ep = out->err_poisson, *o_cube = out->cube;

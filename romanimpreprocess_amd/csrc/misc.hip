@@ -84,3 +84,75 @@ int rip_launch_flat_area(rip_ctx *ctx, const float *flat_dn, const double *area,
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// dq-init + saturation flagging (gen_cal_image.py:148-185; behaviour restated in
+// L1_to_L2/gen_cal_image.py:flag_saturation -- PARITY UNPINNED, stcal's source is not available).
+// One thread per pixel.  sat(g) = OR over the 3x3 neighbourhood (inside the frame) of
+// [data[g] >= threshold and the pixel is checked], g >= skip; sticky forward in g; set on the `backup` preceding groups
+// (never below `skip`).  groupdq = gdq_in | SATURATED(sat) | DO_NOT_USE on group 0 when dnu_first;
+// pixeldq = pdq_in | SATURATED where any group is flagged.
+template <typename T>
+__global__ __launch_bounds__(256) void satflag_kernel(const T *__restrict__ data, const float *__restrict__ thr,
+                                                      const uint32_t *__restrict__ sat_dq,
+                                                      const uint8_t *__restrict__ gdq_in,
+                                                      const uint32_t *__restrict__ pdq_in, uint8_t *__restrict__ gdq_out,
+                                                      uint32_t *__restrict__ pdq_out, int G, int ny, int nx, int backup,
+                                                      int skip, int dnu_first) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= nx) return;
+    const size_t npix = (size_t)ny * nx, p = (size_t)y * nx + x;
+    // thresholds of the up to nine neighbours; +inf where the neighbour is outside the frame or not checked
+    float t[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        float v = INFINITY;
+        if (yy >= 0 && yy < ny && xx >= 0 && xx < nx) {
+            const size_t q = (size_t)yy * nx + xx;
+            const float th = thr[q];
+            const bool nocheck = !(fabsf(th) <= 3.4e38f) || (sat_dq && (sat_dq[q] & (1u << 21)) != 0);  // NO_SAT_CHECK
+            v = nocheck ? INFINITY : th;
+        }
+        t[k] = v;
+    }
+    uint64_t sat = 0;  // bit g
+    for (int g = skip; g < G; ++g) {
+        bool s = false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (t[k] == INFINITY) continue;
+            const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+            const float d = (float)data[(size_t)g * npix + (size_t)yy * nx + xx];
+            s = s || (d >= t[k]);
+        }
+        if (s) sat |= (~0ull) << g;  // sticky for the later groups
+    }
+    sat &= (G >= 64) ? ~0ull : ((1ull << G) - 1ull);
+    for (int b = 0; b < backup; ++b) sat |= (sat >> 1);
+    sat &= ~((1ull << skip) - 1ull);  // never the first `skip` groups
+    for (int g = 0; g < G; ++g) {
+        uint8_t v = gdq_in ? gdq_in[(size_t)g * npix + p] : (uint8_t)0;
+        if ((sat >> g) & 1ull) v |= (uint8_t)DQ_SATURATED;
+        if (g == 0 && dnu_first) v |= (uint8_t)DQ_DO_NOT_USE;
+        gdq_out[(size_t)g * npix + p] = v;
+    }
+    pdq_out[p] = (pdq_in ? pdq_in[p] : 0u) | (sat ? DQ_SATURATED : 0u);
+}
+
+int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const float *thr, const uint32_t *sat_dq,
+                       const uint8_t *gdq_in, const uint32_t *pdq_in, uint8_t *gdq_out, uint32_t *pdq_out, int G, int ny,
+                       int nx, int backup, int skip_firstn, int dnu_first) {
+    if (G < 1 || G > 64 || backup < 0 || skip_firstn < 0 || skip_firstn > G)
+        return rip_fail(ctx, RIP_EINVAL, "saturation flagging: bad group / backup / skip arguments");
+    const dim3 grid((nx + 255) / 256, ny), block(256);
+    if (data_dtype == RIP_U16)
+        hipLaunchKernelGGL(satflag_kernel<uint16_t>, grid, block, 0, ctx->stream, (const uint16_t *)data, thr, sat_dq, gdq_in,
+                           pdq_in, gdq_out, pdq_out, G, ny, nx, backup, skip_firstn, dnu_first);
+    else
+        hipLaunchKernelGGL(satflag_kernel<float>, grid, block, 0, ctx->stream, (const float *)data, thr, sat_dq, gdq_in, pdq_in,
+                           gdq_out, pdq_out, G, ny, nx, backup, skip_firstn, dnu_first);
+    RIP_HIP(ctx, hipGetLastError());
+    return RIP_OK;
+}

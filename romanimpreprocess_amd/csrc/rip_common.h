@@ -100,6 +100,8 @@ struct RipCal {
     float *flat_dn = nullptr;     // output of get_flat (ny,nx); border = 1
     uint32_t *flat_flags = nullptr;  // NO_FLAT_FIELD / NO_GAIN_VALUE bits get_flat would OR into pdq
     float *bias = nullptr;        // (ngrp_bias, ny, nx) embedded in the full frame, border = 0
+    float *sat_thr = nullptr;     // saturation threshold (ny,nx) or null
+    uint32_t *sat_dq = nullptr;   // saturation dq (ny,nx) or null
     // one allocation holding the per-pixel planes the fused kernel walks together, in this order:
     //   [0,NP) Legendre planes | NP Smin | NP+1 Smax | NP+2 Sref | NP+3 lin dq (u32) | NP+4 gain (f32 only)
     //   | NP+5 read noise | NP+6 dark rate | NP+7 flat_dn | NP+8 flat flags (u32)
@@ -128,8 +130,8 @@ struct rip_ctx {
     bool use_fused = true;  // rip_set_option("fused", 0) forces the stage-by-stage kernels
     bool prof = false;
     std::vector<hipEvent_t> prof_events;  // 6 per rip_calibrate call
-    void *ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t ws_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void *ws[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // ---------------------------------------------------------------- host helpers
@@ -253,3 +255,7 @@ int rip_launch_embed(rip_ctx *ctx, const void *src, void *dst, int nplanes, int 
 int rip_launch_flat_prepare(rip_ctx *ctx, const float *flat, const void *gain, int g_dtype, int ny, int nx, int nb,
                             float *flat_padded, void *gain_clipped, uint32_t *flags, int with_gain);
 int rip_launch_flat_area(rip_ctx *ctx, const float *flat_dn, const double *area, float *out, size_t n);
+// dq-init + saturation flagging (misc.hip): gdq_in / pdq_in may be null (= zeros)
+int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const float *thr, const uint32_t *sat_dq,
+                       const uint8_t *gdq_in, const uint32_t *pdq_in, uint8_t *gdq_out, uint32_t *pdq_out, int G, int ny,
+                       int nx, int backup, int skip_firstn, int dnu_first);

@@ -45,11 +45,15 @@ class Calibrator:
 
     # ---- host arrays in, host arrays out --------------------------------------------------
     def calibrate(self, slot, ramp, exclude_first=True, ramp_opt_pars=None, jump_pars=None, area_factor=None,
-                  stages=STAGE_ALL, want_groupdq=True, want_cube=False, channel_lines=None):
+                  stages=STAGE_ALL, want_groupdq=True, want_cube=False, channel_lines=None, flag_saturation=False,
+                  saturation_backup=1, saturation_skip_firstn=1):
         """Run the chain on one ramp given as numpy arrays.
 
         ``ramp``: dict(data u16|f32 (G,ny,nx), amp33 u16 (G,ny,128)|None, groupdq u8, pixeldq u32,
         read_pattern, frame_time).  Returns dict(slope, err_read, err_poisson, pixeldq[, groupdq][, cube], K, meta).
+
+        ``flag_saturation``: dq-init + saturation flagging on the device before the chain (the CALDIR slot must hold
+        ``saturation``); ``ramp["groupdq"]`` may then be None and ``ramp["pixeldq"]`` is the mask dq.
         """
         ny, nx = self.shapes[slot]
         pid, meta = self.plan_for(ramp["read_pattern"], ramp["frame_time"], exclude_first, ramp_opt_pars, jump_pars)
@@ -59,9 +63,13 @@ class Calibrator:
         G = data.shape[0]
         if data.shape != (G, ny, nx):
             raise ValueError(f"ramp shape {data.shape} does not match the CALDIR frame {(ny, nx)}")
-        gdq = np.array(ramp["groupdq"], dtype=np.uint8, order="C", copy=True)
-        if exclude_first:
-            gdq[0] |= np.uint8(1)  # gen_cal_image.py:142-143
+        gdq = None
+        if ramp.get("groupdq") is not None:
+            gdq = np.array(ramp["groupdq"], dtype=np.uint8, order="C", copy=True)
+            if exclude_first:
+                gdq[0] |= np.uint8(1)  # gen_cal_image.py:142-143
+        elif not flag_saturation:
+            raise ValueError("ramp['groupdq'] is required unless flag_saturation is set")
         pdq = np.ascontiguousarray(ramp["pixeldq"], dtype=np.uint32)
         amp33 = None if ramp.get("amp33") is None else np.ascontiguousarray(ramp["amp33"], dtype=np.uint16)
         area = None if area_factor is None else np.ascontiguousarray(area_factor, dtype=np.float64)
@@ -71,7 +79,9 @@ class Calibrator:
         rd.location, rd.ngrp = _native.RIP_HOST, G
         rd.data, rd.data_dtype = data.ctypes.data, _native.dtype_code(data)
         rd.amp33 = None if amp33 is None else amp33.ctypes.data
-        rd.groupdq, rd.pixeldq = gdq.ctypes.data, pdq.ctypes.data
+        rd.groupdq, rd.pixeldq = (None if gdq is None else gdq.ctypes.data), pdq.ctypes.data
+        rd.flag_saturation = 1 if flag_saturation else 0
+        rd.sat_backup, rd.sat_skip_firstn = int(saturation_backup), int(saturation_skip_firstn)
         rd.area_factor = None if area is None else area.ctypes.data
         rd.channel_lines = None if lines is None else lines.ctypes.data
 

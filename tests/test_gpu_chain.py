@@ -246,3 +246,40 @@ def test_fused_forms_agree_across_seams():
             assert_same_bits(outs[0][k], other[k], f"{k}: specialised vs {label}")
     assert np.count_nonzero(outs[0]["pixeldq"] & 4) > 1000 and np.count_nonzero(outs[0]["pixeldq"] & 2) > 100
     cb.ctx.drop_caldir(5)
+
+
+def test_saturation_flagging_on_device_matches_host_restatement():
+    """dq-init + saturation flagging inside rip_calibrate against the numpy restatement
+    L1_to_L2.gen_cal_image.flag_saturation (parity unpinned: stcal's source is not in the reference tree): identical
+    flags, hence identical chain outputs.  Thresholds lowered so that many pixels saturate at different groups; some
+    pixels are NO_SAT_CHECK / NaN-threshold."""
+    from romanimpreprocess_amd.L1_to_L2 import gen_cal_image as gci
+    from romanimpreprocess_amd.dqflags import pixel
+
+    rp = synth.READ_PATTERN_8
+    ny, nx = 72, 256
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=41, bias_amplitude=2.0)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=42, cr_frac=0.02)
+    rng = np.random.default_rng(7)
+    thr = np.quantile(ramp["data"].astype(np.float32), 0.9, axis=0).astype(np.float32)  # ~10 % of the resultants exceed it
+    thr[rng.random((ny, nx)) < 0.97] = 65535.0  # ... at 3 % of the pixels
+    thr[3, 5] = np.nan
+    sdq = np.zeros((ny, nx), np.uint32)
+    sdq[rng.random((ny, nx)) < 0.01] = np.uint32(pixel.NO_SAT_CHECK)
+    cal = dict(cal)
+    cal["saturation"] = {"data": thr, "dq": sdq}
+    mask = ramp["pixeldq"].copy()
+    for backup in (1, 2, 0):
+        # host restatement
+        h = {"data": ramp["data"], "groupdq": np.zeros(ramp["data"].shape, np.uint8), "pixeldq": mask.copy()}
+        gci.flag_saturation(h, thr, backup=backup, skip_firstn=1, n_pix_grow_sat=1, sat_dq=sdq)
+        assert 50 < np.count_nonzero(h["groupdq"][-1] & 2) < 0.5 * ny * nx
+        cb = pipeline.Calibrator(ctx=gpu_context())
+        cb.load_caldir(6, cal)
+        r_host = dict(ramp, groupdq=h["groupdq"], pixeldq=h["pixeldq"])
+        a = cb.calibrate(6, r_host)
+        r_dev = dict(ramp, groupdq=None, pixeldq=mask)
+        b = cb.calibrate(6, r_dev, flag_saturation=True, saturation_backup=backup)
+        for k in ("groupdq", "pixeldq", "slope", "err_read", "err_poisson"):
+            assert_same_bits(a[k], b[k], f"{k} (backup {backup})")
+        cb.ctx.drop_caldir(6)

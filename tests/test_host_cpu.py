@@ -30,9 +30,11 @@ def test_ctypes_structs_match_the_header(tmp_path):
     """sizeof/offsetof of the ABI structs as gcc sees them == the ctypes mirrors."""
     src = tmp_path / "abi.c"
     fields = {
-        "rip_caldir_desc": ["ny", "dark_data", "refout_slope", "gain", "lin_coefs", "ipc4d", "flat", "biascorr"],
+        "rip_caldir_desc": ["ny", "dark_data", "refout_slope", "gain", "lin_coefs", "ipc4d", "flat", "biascorr", "saturation",
+                            "saturation_dq"],
         "rip_plan_desc": ["ngrp", "tbar", "nreads", "K", "nvariants", "variant_coef", "sthresh_a", "ithresh_b"],
-        "rip_ramp_desc": ["location", "data", "data_dtype", "amp33", "area_factor", "channel_lines"],
+        "rip_ramp_desc": ["location", "data", "data_dtype", "amp33", "area_factor", "channel_lines", "flag_saturation",
+                          "sat_skip_firstn"],
         "rip_outputs": ["location", "slope", "pixeldq", "groupdq", "cube"],
     }
     body = "".join(f'printf("{s} %zu\\n", sizeof({s}));\n' + "".join(
