@@ -646,20 +646,6 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         d_lines_ovr = (const double *)put(in->channel_lines, (size_t)G * nch * 16);
         RIP_HIP(ctx, hipGetLastError());
     }
-    if (do_sat) {
-        // dq-init + saturation flagging into workspace copies of the flag arrays (the caller's inputs stay untouched)
-        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-        char *w = (char *)rip_ws(ctx, 8, al(b_gdq) + al(b_pdq));
-        if (!w) return RIP_ENOMEM;
-        uint8_t *g2 = (uint8_t *)w;
-        uint32_t *p2 = (uint32_t *)(w + al(b_gdq));
-        const int dnu_first = (plan && plan->h.start == 1) ? 1 : 0;  // the plan excludes the first group
-        int rcs = rip_launch_satflag(ctx, d_data, in->data_dtype, c.sat_thr, c.sat_dq, d_gdq, d_pdq, g2, p2, G, ny, nx,
-                                     in->sat_backup, in->sat_skip_firstn, dnu_first);
-        if (rcs) return rcs;
-        d_gdq = g2;
-        d_pdq = p2;
-    }
     // ---- outputs on the device
     float *o_slope = out->slope, *o_er = out->err_read, *o_ep = out->err_poisson, *o_cube = out->cube;
     uint32_t *o_pdq = out->pixeldq;
@@ -696,6 +682,22 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     const int par = ctx->parity;
     const bool overlap = do_ref && !host && ctx->use_overlap;
     double *rowcorr = nullptr, *lines = nullptr;
+    // dq-init + saturation flagging into workspace copies of the flag arrays (the caller's inputs stay untouched), double
+    // buffered by call parity like the reference-pixel tables because the pass may run ahead on the second stream
+    auto sat_pass = [&]() -> int {
+        auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+        const size_t one = al(b_gdq) + al(b_pdq);
+        char *w = (char *)rip_ws(ctx, 8, 2 * one);
+        if (!w) return RIP_ENOMEM;
+        uint8_t *g2 = (uint8_t *)(w + (size_t)par * one);
+        uint32_t *p2 = (uint32_t *)(w + (size_t)par * one + al(b_gdq));
+        const int dnu_first = (plan && plan->h.start == 1) ? 1 : 0;  // the plan excludes the first group
+        const int rcs = rip_launch_satflag(ctx, d_data, in->data_dtype, c.sat_thr, c.sat_dq, d_gdq, d_pdq, g2, p2, G, ny, nx,
+                                           in->sat_backup, in->sat_skip_firstn, dnu_first);
+        d_gdq = g2;
+        d_pdq = p2;
+        return rcs;
+    };
     if (do_ref) {
         if (nx % RIP_CW) return rip_fail(ctx, RIP_EINVAL, "calibrate: nx=%d is not a multiple of 128", nx);
         if (!ws3) return RIP_ENOMEM;
@@ -711,6 +713,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         }
         mark();
         rc = rip_launch_refpix_prepass(ctx, ra);
+        if (!rc && do_sat) rc = sat_pass();  // same stream as the pre-pass: overlaps the previous ramp's main kernel
         mark();
         if (overlap) {
             if (!rc) {
@@ -724,6 +727,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         if (rc) return rc;
     } else {
         mark();
+        if (do_sat && (rc = sat_pass())) return rc;
         mark();
     }
     mark();

@@ -89,56 +89,89 @@ int rip_launch_flat_area(rip_ctx *ctx, const float *flat_dn, const double *area,
 // ---------------------------------------------------------------------------------------------
 // dq-init + saturation flagging (gen_cal_image.py:148-185; behaviour restated in
 // L1_to_L2/gen_cal_image.py:flag_saturation -- PARITY UNPINNED, stcal's source is not available).
-// One thread per pixel.  sat(g) = OR over the 3x3 neighbourhood (inside the frame) of
-// [data[g] >= threshold and the pixel is checked], g >= skip; sticky forward in g; set on the `backup` preceding groups
-// (never below `skip`).  groupdq = gdq_in | SATURATED(sat) | DO_NOT_USE on group 0 when dnu_first;
-// pixeldq = pdq_in | SATURATED where any group is flagged.
+//   sat(g) = OR over the 3x3 neighbourhood (inside the frame) of [data[g] >= threshold and the pixel is checked],
+//   g >= skip; sticky forward in g; set on the `backup` preceding groups (never below `skip`).
+//   groupdq = gdq_in | SATURATED(sat) | DO_NOT_USE on group 0 when dnu_first; pixeldq = pdq_in | SATURATED if any.
+// Two passes, one thread per pixel: (1) bit g of a per-pixel word = that pixel's own resultant g exceeds its own
+// threshold (the cube is read once, coalesced); (2) OR of the nine neighbours' words, the time logic on the bits, flags.
+// four consecutive pixels per thread (nx is a multiple of 4): 8-byte loads of the u16 cube, 4-byte stores of the flags
 template <typename T>
-__global__ __launch_bounds__(256) void satflag_kernel(const T *__restrict__ data, const float *__restrict__ thr,
-                                                      const uint32_t *__restrict__ sat_dq,
-                                                      const uint8_t *__restrict__ gdq_in,
-                                                      const uint32_t *__restrict__ pdq_in, uint8_t *__restrict__ gdq_out,
-                                                      uint32_t *__restrict__ pdq_out, int G, int ny, int nx, int backup,
-                                                      int skip, int dnu_first) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= nx) return;
-    const size_t npix = (size_t)ny * nx, p = (size_t)y * nx + x;
-    // thresholds of the up to nine neighbours; +inf where the neighbour is outside the frame or not checked
-    float t[9];
+__global__ __launch_bounds__(256) void sat_exceed_kernel(const T *__restrict__ data, const float *__restrict__ thr,
+                                                         const uint32_t *__restrict__ sat_dq, uint64_t *__restrict__ ex,
+                                                         int G, size_t npix, int skip) {
+    const size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (p >= npix) return;
+    const float4 th = *reinterpret_cast<const float4 *>(thr + p);
+    const float tv[4] = {th.x, th.y, th.z, th.w};
+    uint4 sq = {0u, 0u, 0u, 0u};
+    if (sat_dq) sq = *reinterpret_cast<const uint4 *>(sat_dq + p);
+    const uint32_t sv[4] = {sq.x, sq.y, sq.z, sq.w};
+    float t[4];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-        float v = INFINITY;
-        if (yy >= 0 && yy < ny && xx >= 0 && xx < nx) {
-            const size_t q = (size_t)yy * nx + xx;
-            const float th = thr[q];
-            const bool nocheck = !(fabsf(th) <= 3.4e38f) || (sat_dq && (sat_dq[q] & (1u << 21)) != 0);  // NO_SAT_CHECK
-            v = nocheck ? INFINITY : th;
-        }
-        t[k] = v;
-    }
-    uint64_t sat = 0;  // bit g
+    for (int i = 0; i < 4; ++i)  // NaN / inf / NO_SAT_CHECK -> never exceeded
+        t[i] = (!(fabsf(tv[i]) <= 3.4e38f) || (sv[i] & (1u << 21)) != 0) ? INFINITY : tv[i];
+    uint64_t m[4] = {0, 0, 0, 0};
     for (int g = skip; g < G; ++g) {
-        bool s = false;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            if (t[k] == INFINITY) continue;
-            const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-            const float d = (float)data[(size_t)g * npix + (size_t)yy * nx + xx];
-            s = s || (d >= t[k]);
+        float d[4];
+        if constexpr (sizeof(T) == 2) {
+            const uint2 w = *reinterpret_cast<const uint2 *>(data + (size_t)g * npix + p);
+            d[0] = (float)(w.x & 0xffffu), d[1] = (float)(w.x >> 16), d[2] = (float)(w.y & 0xffffu), d[3] = (float)(w.y >> 16);
+        } else {
+            const float4 w = *reinterpret_cast<const float4 *>(data + (size_t)g * npix + p);
+            d[0] = w.x, d[1] = w.y, d[2] = w.z, d[3] = w.w;
         }
-        if (s) sat |= (~0ull) << g;  // sticky for the later groups
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (d[i] >= t[i]) m[i] |= 1ull << g;
     }
-    sat &= (G >= 64) ? ~0ull : ((1ull << G) - 1ull);
-    for (int b = 0; b < backup; ++b) sat |= (sat >> 1);
-    sat &= ~((1ull << skip) - 1ull);  // never the first `skip` groups
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ex[p + i] = m[i];
+}
+
+__global__ __launch_bounds__(256) void sat_flags_kernel(const uint64_t *__restrict__ ex, const uint8_t *__restrict__ gdq_in,
+                                                        const uint32_t *__restrict__ pdq_in, uint8_t *__restrict__ gdq_out,
+                                                        uint32_t *__restrict__ pdq_out, int G, int ny, int nx, int backup,
+                                                        int skip, int dnu_first) {
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    if (x0 >= nx) return;
+    const size_t npix = (size_t)ny * nx, p = (size_t)y * nx + x0;
+    // column-wise OR over the three rows for columns x0-1 .. x0+4, then the 3-wide OR along the row
+    uint64_t c[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= ny) continue;
+        const uint64_t *row = ex + (size_t)yy * nx;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int xx = x0 - 1 + i;
+            if (xx >= 0 && xx < nx) c[i] |= row[xx];
+        }
+    }
+    const uint64_t full = (G >= 64) ? ~0ull : ((1ull << G) - 1ull);
+    uint64_t sat[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t m = c[i] | c[i + 1] | c[i + 2];
+        uint64_t s = m ? (~((m & (~m + 1ull)) - 1ull)) & full : 0ull;  // every group from the first exceeding one on
+        for (int b = 0; b < backup; ++b) s |= (s >> 1);
+        sat[i] = s & ~((1ull << skip) - 1ull);  // never the first `skip` groups
+    }
     for (int g = 0; g < G; ++g) {
-        uint8_t v = gdq_in ? gdq_in[(size_t)g * npix + p] : (uint8_t)0;
-        if ((sat >> g) & 1ull) v |= (uint8_t)DQ_SATURATED;
-        if (g == 0 && dnu_first) v |= (uint8_t)DQ_DO_NOT_USE;
-        gdq_out[(size_t)g * npix + p] = v;
+        uint32_t v = gdq_in ? *reinterpret_cast<const uint32_t *>(gdq_in + (size_t)g * npix + p) : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((sat[i] >> g) & 1ull) v |= DQ_SATURATED << (8 * i);
+        if (g == 0 && dnu_first) v |= 0x01010101u * DQ_DO_NOT_USE;
+        *reinterpret_cast<uint32_t *>(gdq_out + (size_t)g * npix + p) = v;
     }
-    pdq_out[p] = (pdq_in ? pdq_in[p] : 0u) | (sat ? DQ_SATURATED : 0u);
+    uint4 pd = {0u, 0u, 0u, 0u};
+    if (pdq_in) pd = *reinterpret_cast<const uint4 *>(pdq_in + p);
+    pd.x |= sat[0] ? DQ_SATURATED : 0u;
+    pd.y |= sat[1] ? DQ_SATURATED : 0u;
+    pd.z |= sat[2] ? DQ_SATURATED : 0u;
+    pd.w |= sat[3] ? DQ_SATURATED : 0u;
+    *reinterpret_cast<uint4 *>(pdq_out + p) = pd;
 }
 
 int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const float *thr, const uint32_t *sat_dq,
@@ -146,13 +179,19 @@ int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const flo
                        int nx, int backup, int skip_firstn, int dnu_first) {
     if (G < 1 || G > 64 || backup < 0 || skip_firstn < 0 || skip_firstn > G)
         return rip_fail(ctx, RIP_EINVAL, "saturation flagging: bad group / backup / skip arguments");
-    const dim3 grid((nx + 255) / 256, ny), block(256);
+    if (nx % 4) return rip_fail(ctx, RIP_EINVAL, "saturation flagging: nx=%d is not a multiple of 4", nx);
+    const size_t npix = (size_t)ny * nx;
+    uint64_t *ex = (uint64_t *)rip_ws(ctx, 9, npix * 8);
+    if (!ex) return RIP_ENOMEM;
+    const dim3 g1((unsigned)((npix / 4 + 255) / 256)), block(256);
     if (data_dtype == RIP_U16)
-        hipLaunchKernelGGL(satflag_kernel<uint16_t>, grid, block, 0, ctx->stream, (const uint16_t *)data, thr, sat_dq, gdq_in,
-                           pdq_in, gdq_out, pdq_out, G, ny, nx, backup, skip_firstn, dnu_first);
+        hipLaunchKernelGGL(sat_exceed_kernel<uint16_t>, g1, block, 0, ctx->stream, (const uint16_t *)data, thr, sat_dq, ex, G, npix,
+                           skip_firstn);
     else
-        hipLaunchKernelGGL(satflag_kernel<float>, grid, block, 0, ctx->stream, (const float *)data, thr, sat_dq, gdq_in, pdq_in,
-                           gdq_out, pdq_out, G, ny, nx, backup, skip_firstn, dnu_first);
+        hipLaunchKernelGGL(sat_exceed_kernel<float>, g1, block, 0, ctx->stream, (const float *)data, thr, sat_dq, ex, G, npix,
+                           skip_firstn);
+    hipLaunchKernelGGL(sat_flags_kernel, dim3((nx / 4 + 255) / 256, ny), block, 0, ctx->stream, ex, gdq_in, pdq_in, gdq_out, pdq_out, G,
+                       ny, nx, backup, skip_firstn, dnu_first);
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
 }

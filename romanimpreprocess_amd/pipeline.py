@@ -110,11 +110,15 @@ class Calibrator:
     # ---- device pointers in, device pointers out (asynchronous) ---------------------------
     def calibrate_device(self, slot, plan_id, ngrp, data_ptr, data_is_u16, amp33_ptr, groupdq_ptr, pixeldq_ptr,
                          slope_ptr, err_read_ptr, err_poisson_ptr, pixeldq_out_ptr, groupdq_out_ptr=None,
-                         area_ptr=None, stages=STAGE_ALL):
+                         area_ptr=None, stages=STAGE_ALL, flag_saturation=False, saturation_backup=1,
+                         saturation_skip_firstn=1):
+        """``groupdq_ptr`` may be None with ``flag_saturation`` (dq-init + saturation flagging on the device)."""
         rd = _native.RampDesc()
         rd.location, rd.ngrp = _native.RIP_DEVICE, int(ngrp)
         rd.data, rd.data_dtype = data_ptr, (_native.RIP_U16 if data_is_u16 else _native.RIP_F32)
         rd.amp33, rd.groupdq, rd.pixeldq, rd.area_factor = amp33_ptr, groupdq_ptr, pixeldq_ptr, area_ptr
+        rd.flag_saturation = 1 if flag_saturation else 0
+        rd.sat_backup, rd.sat_skip_firstn = int(saturation_backup), int(saturation_skip_firstn)
         out = _native.Outputs()
         out.location = _native.RIP_DEVICE
         out.slope, out.err_read, out.err_poisson = slope_ptr, err_read_ptr, err_poisson_ptr
