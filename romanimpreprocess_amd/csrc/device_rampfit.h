@@ -335,6 +335,7 @@ struct RipFitConst {
     float ia, ib;       // f32(IthreshA), f32(IthreshB)
     float sa32;         // f32(SthreshA)
     float slope_th;     // f32((SthreshB - SthreshA) / log(IthreshB / IthreshA))
+    float inv_ia;       // f32(1 / IthreshA): argument of the APPROXIMATE log only (its 1e-7 relative error is far inside band0)
 };
 __device__ __forceinline__ RipFitConst rip_fit_const(const RipPlanHeader *h) {
     RipFitConst c;
@@ -342,6 +343,7 @@ __device__ __forceinline__ RipFitConst rip_fit_const(const RipPlanHeader *h) {
     c.ib = KLD(h->ib);
     c.sa32 = (float)KLD(h->sa);
     c.slope_th = (float)(KLD(h->dsb) / KLD(h->loglen));
+    c.inv_ia = 1.0f / c.ia;
     return c;
 }
 
@@ -429,7 +431,7 @@ __device__ __forceinline__ void fit_full_pk_a(const rf2 (&dA)[G / 2], const RipF
     st.xc = xc;
     const bool need_log = xc != fc.ia;  // log(1) = 0 exactly otherwise
     float lx = 0.0f;
-    if (__any(need_log)) lx = need_log ? __logf(xc / fc.ia) : 0.0f;
+    if (__any(need_log)) lx = need_log ? __logf(xc * fc.inv_ia) : 0.0f;
     const float slope_th = fc.slope_th;
     const float sth32 = fc.sa32 + slope_th * lx;
     // Acceptance test of the approximate significance sm (DESIGN.md "jump significance fast path"):
@@ -437,7 +439,7 @@ __device__ __forceinline__ void fit_full_pk_a(const rf2 (&dA)[G / 2], const RipF
     //   t = 8e-7 |s| rs  (rounding of num*inv_dt and of q - s, using |q| <= |delta| + |s|);  the threshold itself is
     //   known to +-band0.  With thp + t > 0 and thm - t > 0 (checked per pixel through rsmax >= every rs):
     //   sm > (thp + t) k1  => sure hit,   sm < (thm - t) k2  => surely no hit,   anything else (NaN included) -> exact pass.
-    const float band0 = 2e-6f * fabsf(sth32) + 4e-6f * fabsf(slope_th) + 1e-30f;
+    const float band0 = 2e-6f * fabsf(sth32) + 4.5e-6f * fabsf(slope_th) + 1e-30f;  // 4e-6: __logf; 0.5e-6: its argument
     const float s2 = st.s2;
     const float s8 = fabsf(s) * 8.1e-7f;
     const float thp = sth32 + band0, thm = sth32 - band0;
