@@ -204,6 +204,37 @@ int rip_stage_ramp_fit(rip_ctx *ctx, int plan_id, const float *data, uint8_t *rd
 int rip_stage_get_flat(rip_ctx *ctx, const float *flat, int ny, int nx, int nb, const void *gain, int g_dtype,
                        const void *kernel, int k_dtype, int ipc_deconvolve, uint32_t *pdq, float *out);
 
+/* ---- post-path 2-D reductions: between the chain's outputs and the L2 file; host arrays ------ */
+
+/* maskhandling.CombinedMask.build (maskhandling.py:82-117): grow[bit] in {0, 1, 5, 9, 25} = how the layer of that dq bit
+   is grown (copy, plus, 3x3, 5x5; zero padded); mask (ny,nx) u8 = 1 where masked.  Exact. */
+int rip_stage_build_mask(rip_ctx *ctx, const uint32_t *dq, int ny, int nx, const uint8_t grow[32], uint8_t *mask);
+
+/* SLICEOUT endslice (gen_cal_image.py:697-712): (ny-2nb, nx-2nb) i8, iend-1 of the last group that first saturates, -1 if
+   none.  Exact. */
+int rip_stage_endslice(rip_ctx *ctx, const uint8_t *rdq, int ngrp, int ny, int nx, int nb, int8_t *out);
+
+/* sky.binkxk(np.where(mask, nan, arr), k) (sky.py:20-41): (ny/k, nx/k) f32 block means, NaN where the block holds a
+   masked or NaN pixel; mask may be NULL.  f32 sums in row-then-column order (numpy's order differs: ~1e-7 relative). */
+int rip_stage_bin_mean(rip_ctx *ctx, const float *arr, const uint8_t *mask, int ny, int nx, int k, float *out);
+
+/* Order statistics ignoring NaN, per block of ky x kx pixels (nby x nbx blocks from (y0,x0)) of an (ny,nx) f32 image:
+   the building block of np.nanpercentile (sky.py:72-74) and of the block nan-medians of medfit (sky.py:152).
+   counts[blk] = non-NaN elements; vals[blk*nranks + r] = element of 0-based ascending rank ranks[blk*nranks + r] (NaN
+   when out of range).  ranks may be NULL with nranks = 0 (counts only).  Exact. */
+int rip_stage_select_ranks(rip_ctx *ctx, const float *arr, int ny, int nx, int y0, int x0, int ky, int kx, int nby, int nbx,
+                           int nranks, const int64_t *ranks, int64_t *counts, float *vals);
+
+/* smoothed histogram of smooth_mode (sky.py:80-84): out[i] = sum over non-NaN x of exp(-0.5 ((z[i]-x)/scale)^2), nz <= 32,
+   f64 (summation order differs from numpy: ~1e-13 relative). */
+int rip_stage_gauss_hist(rip_ctx *ctx, const float *arr, int64_t n, const double *z, int nz, double scale, double *out);
+
+/* Legendre model of medfit (sky.py:183-191): model = f32(sum_k coef[k] * outer(LPY[j_k], LPX[i_k])) accumulated in f64 in
+   the order k = 0.. with (i, j): i = 0..order, j = 0..order-i; LPX (order+1, nx), LPY (order+1, ny) f64 from the host.
+   subtract != 0: arr -= model in place; model_out (ny,nx) f32 optional.  Exact. */
+int rip_stage_legendre2d(rip_ctx *ctx, float *arr, int ny, int nx, int order, const double *LPX, const double *LPY,
+                         const double *coef, int subtract, float *model_out);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* When enabled, rip_calibrate brackets each kernel group with HIP events on the ctx stream.
    rip_profile_read synchronises and returns the summed device time (ms) since the last read:

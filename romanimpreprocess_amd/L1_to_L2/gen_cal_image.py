@@ -22,7 +22,7 @@ import numpy as np
 
 from .. import calio, pars, pipeline, plan as planmod
 from ..dqflags import group, pixel
-from ..utils import processlog
+from ..utils import maskhandling, processlog, sky
 
 _cal_cache = {}  # (ctx id, tuple of CALDIR paths) -> slot
 
@@ -113,7 +113,7 @@ def _caldir_slot(cb, caldir):
 
 def calibrateimage(config, verbose=True, calibrator=None):
     """Run the calibrations specified by ``config`` (dict, normally from YAML) and write the L2 file."""
-    for unsupported in ("SKYORDER", "romancal_ramp_fit", "correct_wfi18_transient"):
+    for unsupported in ("romancal_ramp_fit", "correct_wfi18_transient"):
         if config.get(unsupported):
             raise NotImplementedError(f"{unsupported} is outside the GPU L1->L2 path of this package")
     if config.get("FITSOUT"):
@@ -157,38 +157,50 @@ def calibrateimage(config, verbose=True, calibrator=None):
     slope, pdq, rdq = res["slope"], res["pixeldq"], res["groupdq"]
     err_read, err_poisson = res["err_read"], res["err_poisson"]
     with calio.open_tree(caldir["gain"]) as g_:
-        medgain = float(np.median(g_["roman"]["data"]))
+        gain_plane = np.asarray(g_["roman"]["data"])
+    if gain_plane.dtype == np.float32 and gain_plane.ndim == 2:
+        medgain = float(sky.block_nanmedians(gain_plane, 1, ctx=cb.ctx)[0, 0])  # = np.median for a NaN-free f32 plane
+    else:
+        medgain = float(np.median(gain_plane))
     mylog.append(f"median gain = {medgain:8.5f} e/DN\n")
 
+    # sky information (gen_cal_image.py:639-651): grown mask, mode of the 4x4-binned unmasked image, optional low-order
+    # sky model subtraction -- all on the GPU (utils/maskhandling.py, utils/sky.py)
     act = (slice(nb, -nb), slice(nb, -nb))
+    m = maskhandling.PixelMask1.build(pdq, ctx=cb.ctx)
+    medsky, _ = sky.smooth_mode(sky.binkxk(slope, 4, mask=m, ctx=cb.ctx), ctx=cb.ctx)
+    medsky = float(medsky)
+    data_act = np.ascontiguousarray(slope[act])
+    data_withsky = data_act.copy()
+    if "SKYORDER" in config:
+        skyorder = int(config["SKYORDER"])
+        skycoefs, _ = sky.medfit(data_act, order=skyorder, subtract=True, ctx=cb.ctx)
+        skycoefs = np.asarray(skycoefs)
+    else:
+        skycoefs = np.array([]).astype(np.float32)
+        skyorder = -1  # not used
+
     var_r, var_p = err_read[act] ** 2, err_poisson[act] ** 2
     im2 = {
         "meta": ramp["meta"],
-        "data": slope[act].copy(),
+        "data": data_act,
         "dq": pdq[act].copy(),
         "var_poisson": var_p,
         "var_rnoise": var_r,
         "var_flat": np.zeros_like(var_r),
         "err": np.sqrt(var_r + var_p),
-        "data_withsky": slope[act].copy(),
+        "data_withsky": data_withsky,
     }
     if ramp["amp33"] is not None:
         im2["amp33"] = ramp["amp33"]
     processinfo = {
-        "medsky": None, "medgain": medgain, "skyorder": -1, "skycoefs": np.array([], dtype=np.float32),
+        "medsky": medsky, "medgain": medgain, "skyorder": skyorder, "skycoefs": skycoefs,
         "ramp_opt_pars": dict(uopt), "weights": K, "config": config, "log": mylog.output,
         "exclude_first": bool(exclude_first),
         "meta": {k: (v if not isinstance(v, np.ndarray) else v) for k, v in meta.items() if k != "read_pattern"},
     }
     if config.get("SLICEOUT"):
-        ngrp = rdq.shape[0]
-        if ngrp >= 128:
-            raise ValueError("too many groups")
-        endslice = np.zeros(slope[act].shape, dtype=np.int8) - 1
-        sat8 = np.uint8(group.SATURATED)
-        for iend in range(1, ngrp):
-            first = ((rdq[iend][act] & ~rdq[iend - 1][act]) & sat8) != 0
-            endslice = np.where(first, np.int8(iend - 1), endslice)
+        endslice = sky.endslice(rdq, nb, ctx=cb.ctx)  # raises ValueError("too many groups") for >= 128 groups
         processinfo["endslice"] = endslice
     calio.write_asdf(config["OUT"], {"roman": im2, "processinfo": processinfo})
     if verbose:

@@ -113,14 +113,8 @@ __global__ __launch_bounds__(C2_THREADS, (G > 8 ? 2 : 4)) void chain2_kernel(Cha
     const int ay0 = nb, ay1 = ny - nb, ax0 = nb, ax1 = nx - nb;
     const unsigned npix = (unsigned)ny * (unsigned)nx;
     const unsigned pl4 = npix * 4u;
-    const float *__restrict__ kern = reinterpret_cast<const float *>(a.kern);
     const int nch = nx / RIP_CW;
     const uint32_t bad = DQ_NO_LIN_CORR | DQ_REFERENCE_PIXEL;
-    const float *__restrict__ planes = a.planes;
-    const uint16_t *__restrict__ d16 = reinterpret_cast<const uint16_t *>(a.data);
-    const uint8_t *__restrict__ gdq = a.gdq;
-    const float *__restrict__ dark = a.dark_data;
-    const float *__restrict__ bias = a.bias;
 
     float c1[NP], c2[NP], chf[NP];
 #pragma unroll

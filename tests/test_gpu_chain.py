@@ -161,7 +161,8 @@ def test_calibrateimage_files_end_to_end(tmp_path):
     calio.write_asdf(str(tmp_path / "l1.asdf"), l1)
     config = {"IN": str(tmp_path / "l1.asdf"), "OUT": str(tmp_path / "l2.asdf"), "CALDIR": caldir,
               "JUMP_DETECT_PARS": {"SthreshA": 5.0, "IthreshB": 800.0}, "SLICEOUT": True}
-    gen_cal_image.calibrateimage(config, verbose=False, calibrator=pipeline.Calibrator(ctx=gpu_context()))
+    cb_files = pipeline.Calibrator(ctx=gpu_context())
+    gen_cal_image.calibrateimage(config, verbose=False, calibrator=cb_files)
     out = calio.read_asdf(config["OUT"])
 
     # oracle on the same inputs (dq-init + this package's saturation flagging are host steps shared by both)
@@ -179,8 +180,25 @@ def test_calibrateimage_files_end_to_end(tmp_path):
     with pytest.raises(KeyError):
         gen_cal_image.calibrateimage({"IN": config["IN"], "OUT": config["OUT"], "CALDIR": {"gain": caldir["gain"]}},
                                      verbose=False)
+    # post-path reductions: sky mode of the masked, binned image; endslice; optional sky model
+    from romanimpreprocess_amd.utils import maskhandling, sky
+    pi = out["processinfo"]
+    m = maskhandling.PixelMask1.build(ref["pixeldq"], ctx=gpu_context())
+    want_sky, _ = sky.smooth_mode(sky.binkxk(ref["slope"], 4, mask=m, ctx=gpu_context()), ctx=gpu_context())
+    np.testing.assert_allclose(pi["medsky"], want_sky, rtol=1e-4)
+    assert pi["skyorder"] == -1 and np.asarray(pi["skycoefs"]).size == 0
+    assert np.asarray(pi["endslice"]).dtype == np.int8 and np.asarray(pi["endslice"]).shape == out["roman"]["data"].shape
+    np.testing.assert_allclose(pi["medgain"], np.median(cal["gain"]["data"]), rtol=0, atol=0)
+    cfg2 = dict(config, SKYORDER=2, OUT=str(tmp_path / "l2_sky.asdf"))
+    gen_cal_image.calibrateimage(cfg2, verbose=False, calibrator=cb_files)
+    out2 = calio.read_asdf(cfg2["OUT"])
+    assert out2["processinfo"]["skyorder"] == 2 and np.asarray(out2["processinfo"]["skycoefs"]).shape == (6,)
+    assert_same_bits(np.asarray(out2["roman"]["data_withsky"]), np.asarray(out["roman"]["data"]), "data before the sky model")
+    coef, model = sky.medfit(np.asarray(out2["roman"]["data_withsky"]), order=2, ctx=gpu_context())
+    assert_same_bits(np.asarray(out2["roman"]["data"]), np.asarray(out2["roman"]["data_withsky"]) - model, "sky-subtracted data",
+                     zero_sign_ok=True)
     with pytest.raises(NotImplementedError):
-        gen_cal_image.calibrateimage(dict(config, SKYORDER=2), verbose=False)
+        gen_cal_image.calibrateimage(dict(config, romancal_ramp_fit=True), verbose=False)
 
 
 # ---- the wave-specialised fused kernel (chain2_kernel.h): every instantiation the dispatcher can pick, and the seams

@@ -51,13 +51,34 @@ def _install_stubs():
     asdf.open = lambda path, *a, **k: _Tree(_STORE[path])
     sys.modules["asdf"] = asdf
 
-    class pixel(np.uint32, enum.Enum):
+    class pixel(np.uint32, enum.Enum):  # bit values: SURVEY.md Appendix C (the full table; maskhandling.py names most of it)
         DO_NOT_USE = 2**0
         SATURATED = 2**1
         JUMP_DET = 2**2
+        DROPOUT = 2**3
+        GW_AFFECTED_DATA = 2**4
+        PERSISTENCE = 2**5
+        AD_FLOOR = 2**6
+        OUTLIER = 2**7
+        UNRELIABLE_ERROR = 2**8
+        NON_SCIENCE = 2**9
+        DEAD = 2**10
+        HOT = 2**11
+        WARM = 2**12
+        LOW_QE = 2**13
+        TELEGRAPH = 2**15
+        NONLINEAR = 2**16
+        BAD_REF_PIXEL = 2**17
         NO_FLAT_FIELD = 2**18
         NO_GAIN_VALUE = 2**19
         NO_LIN_CORR = 2**20
+        NO_SAT_CHECK = 2**21
+        UNRELIABLE_BIAS = 2**22
+        UNRELIABLE_DARK = 2**23
+        UNRELIABLE_SLOPE = 2**24
+        UNRELIABLE_FLAT = 2**25
+        UNRELIABLE_RESET = 2**28
+        OTHER_BAD_PIXEL = 2**30
         REFERENCE_PIXEL = 2**31
 
     class group(np.uint32, enum.Enum):
@@ -65,6 +86,14 @@ def _install_stubs():
         SATURATED = 2**1
         JUMP_DET = 2**2
 
+    # maskhandling.py imports astropy.io.fits for its file writer only (convert_file); build() never touches it
+    astropy = types.ModuleType("astropy")
+    astropy_io = types.ModuleType("astropy.io")
+    astropy_fits = types.ModuleType("astropy.io.fits")
+    astropy.io, astropy_io.fits = astropy_io, astropy_fits
+    sys.modules.setdefault("astropy", astropy)
+    sys.modules.setdefault("astropy.io", astropy_io)
+    sys.modules.setdefault("astropy.io.fits", astropy_fits)
     rdm = types.ModuleType("roman_datamodels")
     dq = types.ModuleType("roman_datamodels.dqflags")
     dq.pixel, dq.group = pixel, group
@@ -92,6 +121,8 @@ from romanimpreprocess.utils import fitting as ref_fit  # noqa: E402
 from romanimpreprocess.utils import flatutils as ref_flat  # noqa: E402
 from romanimpreprocess.utils import ipc_linearity as ref_il  # noqa: E402
 from romanimpreprocess.utils import reference_subtraction as ref_rs  # noqa: E402
+from romanimpreprocess.utils import maskhandling as ref_mh  # noqa: E402
+from romanimpreprocess.utils import sky as ref_sky  # noqa: E402
 
 import golden_cases as gc  # noqa: E402
 from romanimpreprocess_amd import synth  # noqa: E402
@@ -299,10 +330,46 @@ def case_chain():
              pixeldq_before_flat=pdq_before_flat, pixeldq_out=pdq, dark_slope_ipc=dslope[0], flat_out=flat, K=meta["K"])
 
 
+def case_post():
+    """Post-path reductions with the reference's own maskhandling.PixelMask1 and sky functions."""
+    rng = np.random.default_rng(71)
+    ny, nx = 90, 140
+    dq = np.zeros((ny, nx), np.uint32)
+    for bit in (0, 2, 3, 6, 10, 11, 12, 13, 18, 20, 24, 30, 1, 7, 31):  # masked and unmasked flags alike
+        hits = rng.random((ny, nx)) < 0.004
+        dq[hits] |= np.uint32(1 << bit)
+    dq[0, 0] |= np.uint32(1 << 3)   # a DROPOUT in the corner (5x5 growth clipped by the frame)
+    dq[ny - 1, nx - 2] |= np.uint32(1 << 10)
+    mask = ref_mh.PixelMask1.build(dq)
+    save("post_mask", dq=dq, mask=mask.astype(np.uint8))
+
+    ny, nx = 268, 300   # neither a multiple of 8 nor of 4
+    y, x = np.mgrid[0:ny, 0:nx]
+    img = (0.8 + 0.3 * x / nx - 0.2 * (y / ny) ** 2 + 0.05 * rng.standard_normal((ny, nx))).astype(np.float32)
+    for _ in range(12):   # a few bright sources
+        cy, cx = rng.integers(10, ny - 10), rng.integers(10, nx - 10)
+        img[cy - 3:cy + 4, cx - 3:cx + 4] += np.float32(5.0)
+    m = rng.random((ny, nx)) < 0.03
+    binned = ref_sky.binkxk(np.where(np.logical_not(m), img, np.nan), 4)
+    ctr, width = ref_sky.smooth_mode(binned)
+    withnan = img.copy()
+    withnan[rng.random((ny, nx)) < 0.01] = np.nan
+    withnan[0:33, 0:37] = np.nan   # one block of the 8x8 grid is empty
+    out = {"img": img, "mask": m.astype(np.uint8), "binned": binned, "mode": np.array([ctr, width], dtype=np.float64),
+           "withnan": withnan}
+    for order in (1, 2, 3):
+        coef, model = ref_sky.medfit(withnan, order=order)
+        out[f"coef{order}"] = np.asarray(coef, dtype=np.float64)
+        out[f"model{order}"] = model
+    c8, m8 = ref_sky.medfit(img, N=4, order=2)
+    out["coef_n4"], out["model_n4"] = np.asarray(c8, dtype=np.float64), m8
+    save("post_sky", **out)
+
+
 CASES = {
     "lin_known_answer": case_lin_known_answer, "multilin": case_multilin, "ipc": case_ipc,
     "weights": case_weights, "rampfit": case_rampfit, "flat": case_flat, "refpix": case_refpix,
-    "chain": case_chain,
+    "chain": case_chain, "post": case_post,
 }
 
 if __name__ == "__main__":
