@@ -170,3 +170,36 @@ def test_chain_composition(name):
     assert_same_bits(out["slope"], s, "slope")
     assert_same_bits(out["err_read"], er, "err_read")
     assert_same_bits(out["err_poisson"], ep, "err_poisson")
+
+
+def test_post_path_reductions_against_reference_goldens():
+    """oracle/post.py (numpy restatement of maskhandling.PixelMask1.build and sky.binkxk / smooth_mode / medfit) against
+    the goldens made by the reference's own modules."""
+    from oracle import post
+    g = load_golden("post_mask")
+    assert_same_bits(post.build_mask(g["dq"]).astype(np.uint8), g["mask"], "PixelMask1.build")
+    s = load_golden("post_sky")
+    binned = post.binkxk(np.where(s["mask"].astype(bool), np.nan, s["img"]), 4)
+    assert_same_bits(binned, s["binned"], "binkxk")
+    ctr, width = post.smooth_mode(s["binned"])
+    assert_same_bits(np.array([ctr, width], dtype=np.float64), s["mode"], "smooth_mode")
+    for order in (1, 2, 3):
+        coef, model = post.medfit(s["withnan"], order=order)
+        assert_same_bits(np.asarray(coef, np.float64), s[f"coef{order}"], f"medfit coefficients, order {order}")
+        assert_same_bits(model, s[f"model{order}"], f"medfit model, order {order}")
+    coef, model = post.medfit(s["img"], N=4, order=2)
+    assert_same_bits(model, s["model_n4"], "medfit model (N=4)")
+
+
+def test_numpy_percentile_arithmetic_of_the_sky_mirror():
+    """utils/sky.py reproduces np.nanpercentile on float32 data from two order statistics: index and weight arithmetic
+    checked here with a sort standing in for the device selection."""
+    from romanimpreprocess_amd.utils import sky
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        n = int(rng.integers(1, 5000))
+        a = (rng.standard_normal(n) * rng.choice([1.0, 100.0, 1e-3])).astype(np.float32)
+        v = np.sort(a)
+        for q in (0.0, 10.0, 25.0, 50.0, 75.0, 99.9, 100.0, float(rng.uniform(0, 100))):
+            p, nx_, w = sky._linear_index(n, q)
+            assert np.float32(sky._lerp32(v[p], v[nx_], w)).tobytes() == np.float32(np.nanpercentile(a, q)).tobytes()
