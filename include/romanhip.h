@@ -235,6 +235,30 @@ int rip_stage_gauss_hist(rip_ctx *ctx, const float *arr, int64_t n, const double
 int rip_stage_legendre2d(rip_ctx *ctx, float *arr, int ny, int nx, int order, const double *LPX, const double *LPY,
                          const double *coef, int subtract, float *model_out);
 
+/* ---- statistics over many noise realisations of one ramp -- DEVICE pointers, asynchronous ------- */
+/* Replaces the per-pixel arithmetic of validation_tests/many_realizations.py:57-106 on stacks (nseeds, rows, nx) that stay
+   in HBM (256 realisations of a 4096 x 4096 SCA: 56 GB).  All results are exact (f32 operations in the reference's order,
+   medians by selection). */
+
+/* :69-72  out (ny,nx) f32 = f32(cube[ga]) - f32(cube[gb]) of a Level-1 cube (ngrp,ny,nx) u16 (the reference: ga = last
+   group, gb = 1). */
+int rip_stats_l1_diff(rip_ctx *ctx, const uint16_t *cube, int ngrp, int ny, int nx, int ga, int gb, float *out);
+
+/* :74-77  one realisation's L2 planes into the stacks: image = slope and err = sqrt(err_read^2 + err_poisson^2) inside a
+   zero border of nb pixels; good = 1 where the pixel passes the grown mask (grow[bit] as rip_stage_build_mask, host array)
+   of the dq plane trimmed by nb (maskhandling.PixelMask1.build on the L2 file's dq), 0 elsewhere and in the border. */
+int rip_stats_l2_pack(rip_ctx *ctx, const float *slope, const float *err_read, const float *err_poisson,
+                      const uint32_t *pixeldq, int ny, int nx, int nb, const uint8_t grow[32], float *image, float *err,
+                      uint8_t *good);
+
+/* :78-101  the eight output planes for rows [y0, y0+nrows) of the (ny,nx) frame from stacks (nseeds,nrows,nx) holding every
+   realisation in order; out (8,nrows,nx) f32 = ideal, median(diffs), median(images), N, mean, std, mean - ideal,
+   median(err); N = mean = std = 0 in the border, mean = std = -1000 where N = 0 (:87).  alias_err != 0 reproduces the
+   reference as written: its `images` and `err` stacks are memory maps of the same file (:58-59), so plane 2 equals
+   plane 7.  ideal (nrows,nx) f32. */
+int rip_stats_reduce(rip_ctx *ctx, int nseeds, const float *diffs, const float *images, const float *errs, const uint8_t *good,
+                     const float *ideal, int y0, int nrows, int ny, int nx, int nb, int alias_err, float *out);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 /* When enabled, rip_calibrate brackets each kernel group with HIP events on the ctx stream.
    rip_profile_read synchronises and returns the summed device time (ms) since the last read:

@@ -95,6 +95,9 @@ SYMBOLS = {
     "rip_stage_select_ranks": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
     "rip_stage_gauss_hist": (_I, [_VP, _VP, C.c_int64, _VP, _I, C.c_double, _VP]),
     "rip_stage_legendre2d": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _VP]),
+    "rip_stats_l1_diff": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
+    "rip_stats_l2_pack": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "rip_stats_reduce": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     "rip_set_guard_band": (None, [C.c_double]),
     "rip_set_option": (_I, [_VP, C.c_char_p, _I]),
     "rip_last_chain_form": (_I, [_VP]),

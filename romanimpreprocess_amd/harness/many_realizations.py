@@ -1,73 +1,118 @@
-"""Variance validation over many noise realisations of one ramp -- this package's counterpart of the
-reference's ``validation_tests/many_realizations.py:47-106`` (BASELINE config 5).
+"""Statistics over many noise realisations of one ramp -- this package's counterpart of the reference's
+``validation_tests/many_realizations.py:47-106`` (BASELINE config 5).
 
 For seeds SEED+10, SEED+20, ... one noisy L1 ramp of a fixed ideal-slope scene is generated (own generator:
-``synth.make_ramp`` with a fixed ``rate``; the reference uses romanisim+galsim, not available offline), run
-through the GPU chain, and the per-pixel moments of the unmasked slopes are accumulated:
-    N = sum 1, S1 = sum x, S2 = sum x^2      (over realisations whose pixel dq passes ``good_mask``)
-    mean = S1/N, std = sqrt(S2/N - mean^2)   (many_realizations.py:80-89; sentinel -1000 where N == 0, :87)
-Seeds are shared round-robin between ranks; the three moment planes are summed with one all-reduce.
-Output planes (f32): ideal, N, mean, std, mean - ideal, mean err.  (The reference additionally stores medians
-over seeds of L1 differences, L2 and err, which need every seed's plane on one rank; not produced here.)
+``synth.make_ramp`` with a fixed ``rate``; the reference uses romanisim + galsim, not available offline), run through
+the GPU chain, and kept in HBM as one layer of four stacks: ``diffs`` = L1[-1] - L1[1], the L2 ``images`` and ``err``
+embedded in the 4096 x 4096 frame, and ``good`` = not ``PixelMask1.build(dq)``.  The eight output planes follow the
+reference's arithmetic exactly (``rip_stats_reduce``):
+
+    0 ideal   1 median(diffs)   2 median(images)   3 N   4 mean   5 std   6 mean - ideal   7 median(err)
+
+with N, mean, std from f32 sums in realisation order (``:78-89``; -1000 where N = 0, ``:87``; zero border).  The
+reference maps ``images`` and ``err`` onto the same file (``:58-59``), so as written its plane 2 is median(err);
+``reference_alias=True`` (default) reproduces that, ``False`` gives the median of the images.
+
+Several GPUs: realisations are shared round robin; before the statistics the stacks are transposed over RCCL from
+"my realisations, all rows" to "all realisations, my rows" (``sharding.seeds_to_rows``), which keeps the sums in
+realisation order -- the result is bit-identical for any number of ranks -- and rank 0 collects the planes.
 """
 
 import numpy as np
 
-from .. import pars, sharding, synth
-from ..dqflags import pixel
+from .. import _native, pars, sharding, synth
+from ..utils import maskhandling
 
-# bits that make a pixel unusable for the statistics (subset of maskhandling.PixelMask1 of the reference)
-BAD_BITS = np.uint32(pixel.DO_NOT_USE | pixel.SATURATED | pixel.JUMP_DET | pixel.NO_LIN_CORR | pixel.NO_FLAT_FIELD
-                     | pixel.NO_GAIN_VALUE | pixel.HOT | pixel.DEAD | pixel.REFERENCE_PIXEL)
+NPLANES = 8
 
 
-def good_mask(dq):
-    return (dq & BAD_BITS) == 0
+class SeedStacks:
+    """The four device stacks for ``nlocal`` realisations of an (ny, nx) frame."""
+
+    def __init__(self, nlocal, ny, nx, device, nb=pars.nborder, mask=maskhandling.PixelMask1, ctx=None):
+        import torch
+
+        self.ctx = ctx or _native.default_context(device.index if device.index is not None else 0)
+        self.ny, self.nx, self.nb, self.grow = ny, nx, nb, np.ascontiguousarray(mask.array, dtype=np.uint8)
+        self.diffs = torch.empty((nlocal, ny, nx), dtype=torch.float32, device=device)
+        self.images = torch.empty_like(self.diffs)
+        self.err = torch.empty_like(self.diffs)
+        self.good = torch.empty((nlocal, ny, nx), dtype=torch.uint8, device=device)
+
+    def push(self, k, cube, slope, err_read, err_poisson, pixeldq):
+        """Store realisation ``k`` from device tensors: the u16 L1 cube (ngrp, ny, nx) and the chain's four planes
+        (``many_realizations.py:69-77``)."""
+        c, ny, nx = self.ctx, self.ny, self.nx
+        ngrp = cube.shape[0]
+        c.check(c.lib.rip_stats_l1_diff(c.h, cube.data_ptr(), ngrp, ny, nx, ngrp - 1, 1, self.diffs[k].data_ptr()))
+        c.check(c.lib.rip_stats_l2_pack(c.h, slope.data_ptr(), err_read.data_ptr(), err_poisson.data_ptr(), pixeldq.data_ptr(),
+                                        ny, nx, self.nb, self.grow.ctypes.data, self.images[k].data_ptr(),
+                                        self.err[k].data_ptr(), self.good[k].data_ptr()))
 
 
-def accumulate(moments, slope, err, dq):
-    """moments: dict of f64 planes N, S1, S2, E1 updated in place with one realisation."""
-    ok = good_mask(dq)
-    x = np.where(ok, slope, 0.0).astype(np.float64)
-    moments["N"] += ok
-    moments["S1"] += x
-    moments["S2"] += x * x
-    moments["E1"] += np.where(ok, err, 0.0)
-    return moments
+def reduce_rows(diffs, images, err, good, ideal_rows, y0, ny, nb=pars.nborder, reference_alias=True, ctx=None):
+    """The eight planes (8, nrows, nx) for rows [y0, y0+nrows) from stacks (nseeds, nrows, nx) holding every
+    realisation in order (``many_realizations.py:78-101``)."""
+    import torch
 
-
-def finalize(moments, ideal):
-    N = moments["N"]
-    with np.errstate(divide="ignore", invalid="ignore"):
-        mean = moments["S1"] / N
-        std = np.sqrt(np.clip(moments["S2"] / N - mean**2, 0.0, None))
-        merr = moments["E1"] / N
-    empty = N == 0
-    out = np.stack([ideal, N, mean, std, mean - ideal, merr]).astype(np.float32)
-    out[2:, empty] = -1000.0
+    ctx = ctx or _native.default_context(diffs.device.index or 0)
+    nseeds, nrows, nx = diffs.shape
+    for t in (diffs, images, err, good, ideal_rows):
+        assert t.is_contiguous() and t.device == diffs.device
+    out = torch.empty((NPLANES, nrows, nx), dtype=torch.float32, device=diffs.device)
+    torch.cuda.synchronize(diffs.device)
+    ctx.check(ctx.lib.rip_stats_reduce(ctx.h, nseeds, diffs.data_ptr(), images.data_ptr(), err.data_ptr(), good.data_ptr(),
+                                       ideal_rows.data_ptr(), y0, nrows, ny, nx, nb, 1 if reference_alias else 0,
+                                       out.data_ptr()))
+    ctx.synchronize()
     return out
 
 
-def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device="cpu"):
-    """Generate + calibrate ``nseeds`` realisations (this rank's share) and return the 6 output planes."""
+def ideal_slope(cal, rate, nb=pars.nborder):
+    """The scene's slope in the L2 image's units (DN/s after the flat), zero in the border."""
+    ny, nx = rate.shape
+    ideal = np.zeros((ny, nx), np.float32)
+    flat = np.clip(cal["flat"]["data"].astype(np.float64), 0.1, 10)
+    ideal[nb:-nb, nb:-nb] = (rate / flat)[nb:-nb, nb:-nb]
+    return ideal
+
+
+def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=None, reference_alias=True):
+    """Generate and calibrate ``nseeds`` realisations (this rank's share of them), exchange, reduce.  Returns the
+    (8, ny, nx) f32 planes as a numpy array on rank 0, None on the other ranks."""
     import torch
 
+    device = device or torch.device("cuda", calibrator.ctx.device)
     rp = synth.READ_PATTERN_8 if read_pattern is None else read_pattern
     ny, nx = cal["gain"]["data"].shape
+    nb = pars.nborder
     rate = synth.make_rate_image(ny, nx, seed0)
     seeds = sharding.scatter_items([seed0 + 10 * (j + 1) for j in range(nseeds)], device=device)
-    m = {k: np.zeros((ny, nx), dtype=np.float64) for k in ("N", "S1", "S2", "E1")}
-    for sd in seeds:
+    pid, _ = calibrator.plan_for(rp, synth.FRAME_TIME)
+    st = SeedStacks(len(seeds), ny, nx, device, nb=nb, ctx=calibrator.ctx)
+    slope = torch.empty((ny, nx), dtype=torch.float32, device=device)
+    er, ep = torch.empty_like(slope), torch.empty_like(slope)
+    pdq = torch.empty((ny, nx), dtype=torch.int32, device=device)
+    for k, sd in enumerate(seeds):
         ramp = synth.make_ramp(cal, read_pattern=rp, seed=sd, rate=rate)
-        res = calibrator.calibrate(slot, ramp, want_groupdq=False)
-        accumulate(m, res["slope"], np.hypot(res["err_read"], res["err_poisson"]), res["pixeldq"])
-    planes = [torch.from_numpy(m[k]).to(device) for k in ("N", "S1", "S2", "E1")]
-    sharding.allreduce_sum_(planes)
-    for k, t in zip(("N", "S1", "S2", "E1"), planes):
-        m[k] = t.cpu().numpy()
-    flat = cal["flat"]["data"].astype(np.float64)
-    nb = pars.nborder
-    ideal = np.zeros((ny, nx))
-    with np.errstate(divide="ignore", invalid="ignore"):
-        ideal[nb:-nb, nb:-nb] = (rate / np.clip(flat, 0.1, 10))[nb:-nb, nb:-nb]
-    return finalize(m, ideal)
+        gdq = ramp["groupdq"].copy()
+        gdq[0] |= 1
+        cube = torch.from_numpy(ramp["data"].view(np.int16)).to(device)
+        a33 = torch.from_numpy(ramp["amp33"].view(np.int16)).to(device)
+        t_gdq = torch.from_numpy(gdq).to(device)
+        t_pdq = torch.from_numpy(ramp["pixeldq"].view(np.int32)).to(device)
+        torch.cuda.synchronize(device)
+        calibrator.calibrate_device(slot, pid, len(rp), cube.data_ptr(), True, a33.data_ptr(), t_gdq.data_ptr(),
+                                    t_pdq.data_ptr(), slope.data_ptr(), er.data_ptr(), ep.data_ptr(), pdq.data_ptr())
+        st.push(k, cube, slope, er, ep, pdq)
+        calibrator.synchronize()
+    ideal = torch.from_numpy(ideal_slope(cal, rate, nb)).to(device)
+    rows = []
+    for stack in (st.diffs, st.images, st.err, st.good):
+        t, y0 = sharding.seeds_to_rows(stack, nseeds)
+        rows.append(t)
+    nrows = rows[0].shape[1]
+    planes = reduce_rows(*rows, ideal[y0:y0 + nrows].contiguous(), y0, ny, nb=nb, reference_alias=reference_alias,
+                         ctx=calibrator.ctx)
+    full = sharding.gather_rows(planes, ny)
+    return None if full is None else full.cpu().numpy()

@@ -131,3 +131,47 @@ def refpix_fullframe_inputs(seed, nside=4096):
     std = (4 + rng.integers(0, 3, size=(nside, cw)) / 2.0).astype(np.float32)
     return {"data": data, "dark": dark, "amp33": amp33, "med": med, "std": std,
             "M_PINK": 0.8, "RU_PINK": 1.0, "C_PINK": 0.8}
+
+
+# ---- many-realisations statistics (validation_tests/many_realizations.py): full 4096 x 4096 frames, regenerated ----
+
+HARNESS_ROWS = (0, 3, 4, 5, 2047, 4091, 4092, 4095)   # sampled rows stored in the fixture (every 29th column)
+HARNESS_EXPTIME = 139.8
+HARNESS_CASES = {"harness_a": dict(seed=61, nrun=5, scanum=3), "harness_b": dict(seed=62, nrun=4, scanum=4)}
+
+
+def harness_truth(seed, nside=4096, nb=4):
+    """The 'truth' image of the scene in electrons (what the reference reads from its input FITS file)."""
+    rng = np.random.default_rng(seed)
+    na = nside - 2 * nb
+    y, x = np.mgrid[0:na, 0:na]
+    return ((0.6 + 0.3 * x / na + 0.2 * (y / na) ** 2) * HARNESS_EXPTIME * 1.458
+            + 40.0 * (rng.random((na, na)) < 1e-4)).astype(np.float32)
+
+
+def harness_realisation(seed, j, ideal_act, nside=4096, nb=4):
+    """Realisation j: the two L1 groups the statistics use (u16) and the L2 planes data / err / dq (active region).
+    ``ideal_act``: the oriented ideal slope in the active region.  Values are quantised so that realisations tie."""
+    rng = np.random.default_rng([seed, j])
+    na = nside - 2 * nb
+    first = rng.integers(5000, 5200, size=(nside, nside), dtype=np.uint16)
+    last = (first + rng.integers(0, 12, size=(nside, nside), dtype=np.uint16) * 16).astype(np.uint16)
+    last[7, 9] = first[7, 9] - 3   # a negative difference
+    data = (ideal_act + np.round(rng.standard_normal((na, na)) * 0.05 * 64) / 64).astype(np.float32)
+    err = (0.04 + rng.integers(0, 8, size=(na, na)) / 256.0).astype(np.float32)
+    dq = np.zeros((na, na), np.uint32)
+    for bit in (0, 2, 3, 10, 12, 20, 1, 7):     # copied, plus-grown, 5x5, 3x3 and unmasked flags
+        dq[rng.random((na, na)) < 0.002] |= np.uint32(1 << bit)
+    dq[100:108, 200:216] |= np.uint32(1)        # never usable: N = 0 -> sentinel
+    dq[0, 0] |= np.uint32(1 << 3)               # growth clipped by the edge of the active region
+    if j % 2 == 1:
+        dq[300:340, 10:50] |= np.uint32(1 << 11)  # usable in some realisations only
+    data[104, 208] = np.nan                     # masked everywhere: must not reach the sums
+    if j == 1:
+        err[500, 600] = np.nan                  # np.median of a column holding a NaN is NaN
+        data[2000:2004, 2000:2004] = -0.0
+    return {"l1_first": first, "l1_last": last, "data": data, "err": err, "dq": dq}
+
+
+def harness_orient(ideal_big, scanum):
+    return ideal_big[:, ::-1] if scanum % 3 == 0 else ideal_big[::-1, :]

@@ -156,25 +156,24 @@ _GLOO_WORKER = textwrap.dedent("""
     sys.path.insert(0, {repo!r})
     import numpy as np, torch, torch.distributed as dist
     from romanimpreprocess_amd import sharding
-    from romanimpreprocess_amd.harness import many_realizations as mr
     dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     rank, world = dist.get_rank(), dist.get_world_size()
     mine = sharding.scatter_items(list(range(100, 172)) if rank == 0 else [])
     assert mine == list(range(100, 172))[rank::world], mine
-    # moment planes: every rank accumulates its seeds, one all-reduce gives the full statistics
-    rng = np.random.default_rng(0)
-    slopes = rng.normal(1.0, 0.1, size=(8, 5, 7)).astype(np.float32)
-    dq = (rng.uniform(size=(8, 5, 7)) < 0.2).astype(np.uint32) * 4
-    m = {{k: np.zeros((5, 7)) for k in ("N", "S1", "S2", "E1")}}
-    for j in range(rank, 8, world):
-        mr.accumulate(m, slopes[j], np.full((5, 7), 0.1, np.float32), dq[j])
-    planes = [torch.from_numpy(m[k]) for k in ("N", "S1", "S2", "E1")]
-    sharding.allreduce_sum_(planes)
-    ref = {{k: np.zeros((5, 7)) for k in ("N", "S1", "S2", "E1")}}
-    for j in range(8):
-        mr.accumulate(ref, slopes[j], np.full((5, 7), 0.1, np.float32), dq[j])
-    for k, t in zip(("N", "S1", "S2", "E1"), planes):
-        np.testing.assert_allclose(t.numpy(), ref[k], rtol=1e-12)
+    # many-realisations exchange: realisations round robin -> all realisations of this rank's rows, in order
+    for nseeds, ny, nx, dtype in ((7, 9, 5, np.float32), (4, 10, 3, np.uint8), (1, 4, 6, np.float32)):
+        full = (np.arange(nseeds * ny * nx).reshape(nseeds, ny, nx) % 251).astype(dtype)
+        rows, y0 = sharding.seeds_to_rows(torch.from_numpy(full[rank::world].copy()), nseeds)
+        b = sharding.row_bounds(ny, world)
+        assert y0 == b[rank] and rows.shape == (nseeds, b[rank + 1] - b[rank], nx), (y0, rows.shape)
+        assert np.array_equal(rows.numpy(), full[:, b[rank]:b[rank + 1]])
+        # per-row-range results collected on rank 0
+        planes = torch.from_numpy(np.stack([full[:, b[rank]:b[rank + 1]].sum(axis=0), full[0, b[rank]:b[rank + 1]]]).astype(np.float32))
+        got = sharding.gather_rows(planes, ny)
+        if rank == 0:
+            assert np.array_equal(got.numpy(), np.stack([full.sum(axis=0), full[0]]).astype(np.float32))
+        else:
+            assert got is None
     assert sharding.max_over_ranks(1.0 + rank) == float(world)
     dist.barrier(); dist.destroy_process_group()
     print("rank", rank, "ok")
@@ -193,13 +192,3 @@ def test_sharding_world_size_2_gloo(tmp_path):
         assert f"rank {r} ok" in o
 
 
-def test_many_realizations_finalize_sentinel():
-    from romanimpreprocess_amd.harness import many_realizations as mr
-    m = {k: np.zeros((2, 2)) for k in ("N", "S1", "S2", "E1")}
-    mr.accumulate(m, np.array([[1.0, 2.0], [3.0, 4.0]], np.float32), np.ones((2, 2), np.float32),
-                  np.array([[0, 4], [0, 0]], np.uint32))
-    mr.accumulate(m, np.array([[3.0, 2.0], [5.0, 4.0]], np.float32), np.ones((2, 2), np.float32),
-                  np.array([[0, 2], [0, 0]], np.uint32))
-    out = mr.finalize(m, np.zeros((2, 2)))
-    assert out[1, 0, 0] == 2 and out[2, 0, 0] == 2.0 and out[3, 0, 0] == 1.0
-    assert out[1, 0, 1] == 0 and (out[2:, 0, 1] == -1000.0).all()

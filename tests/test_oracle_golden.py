@@ -203,3 +203,24 @@ def test_numpy_percentile_arithmetic_of_the_sky_mirror():
         for q in (0.0, 10.0, 25.0, 50.0, 75.0, 99.9, 100.0, float(rng.uniform(0, 100))):
             p, nx_, w = sky._linear_index(n, q)
             assert np.float32(sky._lerp32(v[p], v[nx_], w)).tobytes() == np.float32(np.nanpercentile(a, q)).tobytes()
+
+
+def harness_check(out, g, what):
+    """Compare eight (4096, 4096) planes with a harness fixture: per-plane SHA-256 plus the stored samples."""
+    for i, plane in enumerate(out):
+        assert_same_bits(plane[list(gc.HARNESS_ROWS)][:, ::29], g["sample"][i], f"{what}: plane {i} rows")
+        assert_same_bits(plane[96:112, 196:220], g["block"][i], f"{what}: plane {i} block")
+        assert hashlib.sha256(np.ascontiguousarray(plane)).hexdigest() == str(g["plane_sha256"][i]), f"{what}: plane {i}"
+
+
+def test_many_realizations_statistics_against_the_reference_script():
+    """oracle/harness.py against the output of the reference's own many_realizations.py (one case: full 4096 x 4096 frames
+    are the script's fixed geometry)."""
+    from oracle import harness
+    g = load_golden("harness_b")
+    c = gc.HARNESS_CASES["harness_b"]
+    ideal = harness.ideal_slope(gc.harness_truth(c["seed"]), gc.HARNESS_EXPTIME, float(g["g_ideal"]), c["scanum"])
+    rs = (gc.harness_realisation(c["seed"], j, ideal[4:-4, 4:-4]) for j in range(c["nrun"]))
+    out = harness.statistics(rs, ideal)
+    assert np.isnan(g["nanpix"][7]) and np.isnan(g["nanpix"][2]) and not np.isnan(g["nanpix"][4])
+    harness_check(out, g, "oracle")

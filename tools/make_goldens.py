@@ -366,10 +366,96 @@ def case_post():
     save("post_sky", **out)
 
 
+def case_harness():
+    """Statistics over many realisations: the reference's validation_tests/many_realizations.py is EXECUTED as it stands
+    (read from /root/reference at run time) with its simulation and calibration calls replaced by stand-ins that put the
+    synthetic realisations of golden_cases.harness_realisation where the script looks for its L1 and L2 files; the FITS
+    reader / writer are stand-ins too.  Outputs are reduced to hashes and sampled rows."""
+    import shutil
+    import yaml
+
+    from romanimpreprocess import pars as ref_pars
+
+    script = "/root/reference/validation_tests/many_realizations.py"
+    tmp = os.path.join(REPO, "gpurun_out", "_tmp_harness")
+    fits = sys.modules["astropy.io.fits"]
+    state = {}
+
+    class _Hdu:
+        def __init__(self, data, header=None):
+            self.data, self.header = data, header or {}
+
+        def writeto(self, path, overwrite=False):
+            state["out"] = np.array(self.data)
+
+    class _Open:
+        def __init__(self, hdus):
+            self.hdus = hdus
+
+        def __enter__(self):
+            return self.hdus
+
+        def __exit__(self, *exc):
+            return False
+
+    fits.open = lambda path: _Open([_Hdu(state["truth"], {"EXPTIME": gc.HARNESS_EXPTIME})])
+    fits.PrimaryHDU = _Hdu
+
+    sim = types.ModuleType("romanimpreprocess.from_sim.sim_to_isim")
+    cal = types.ModuleType("romanimpreprocess.L1_to_L2.gen_cal_image")
+
+    def run_config(cfg):   # "simulate": the realisation index follows from the seed the script has just advanced
+        j = (cfg["SEED"] - 100) // 10 - 1
+        state["r"] = gc.harness_realisation(state["seed"], j, state["ideal_act"])
+        r = state["r"]
+        cube = np.stack([r["l1_first"] - 7, r["l1_first"], r["l1_first"] + 9, r["l1_last"]])
+        register(cfg["OUT"], {"data": cube})
+
+    def calibrateimage(cfg):
+        r = state["r"]
+        register(cfg["OUT"], {"data": r["data"], "err": r["err"], "dq": r["dq"]})
+
+    sim.run_config, cal.calibrateimage = run_config, calibrateimage
+    pk_sim, pk_cal = types.ModuleType("romanimpreprocess.from_sim"), types.ModuleType("romanimpreprocess.L1_to_L2")
+    pk_sim.sim_to_isim, pk_cal.gen_cal_image = sim, cal
+    pk_val = types.ModuleType("romanimpreprocess.validation_tests")
+    pk_val.__path__ = []
+    sys.modules.update({"romanimpreprocess.from_sim": pk_sim, "romanimpreprocess.from_sim.sim_to_isim": sim,
+                        "romanimpreprocess.L1_to_L2": pk_cal, "romanimpreprocess.L1_to_L2.gen_cal_image": cal,
+                        "romanimpreprocess.validation_tests": pk_val})
+    source = open(script).read()
+    for name, c in gc.HARNESS_CASES.items():
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        state.update(seed=c["seed"], truth=gc.harness_truth(c["seed"]))
+        big = np.zeros((4096, 4096), np.float32)
+        big[4:-4, 4:-4] = state["truth"] / float(gc.HARNESS_EXPTIME) / ref_pars.g_ideal
+        state["ideal_act"] = gc.harness_orient(big, c["scanum"])[4:-4, 4:-4].copy()
+        cfg1 = {"IN": os.path.join(tmp, f"truth_{c['scanum']}.fits"), "OUT": os.path.join(tmp, "l1.asdf")}
+        cfg2 = {"IN": cfg1["OUT"], "OUT": os.path.join(tmp, "l2.asdf")}
+        for k, cfg in (("c1.yaml", cfg1), ("c2.yaml", cfg2)):
+            with open(os.path.join(tmp, k), "w") as f:
+                yaml.safe_dump(cfg, f)
+        argv = sys.argv
+        sys.argv = ["many_realizations", os.path.join(tmp, "c1.yaml"), os.path.join(tmp, "c2.yaml"), str(c["nrun"]), tmp]
+        try:
+            exec(compile(source, script, "exec"), {"__name__": "romanimpreprocess.validation_tests.many_realizations",
+                                                   "__package__": "romanimpreprocess.validation_tests"})
+        finally:
+            sys.argv = argv
+        out = state.pop("out")
+        assert out.shape == (8, 4096, 4096) and out.dtype == np.float32
+        save(name, seed=c["seed"], nrun=c["nrun"], scanum=c["scanum"], g_ideal=np.float64(ref_pars.g_ideal),
+             plane_sha256=np.array([hashlib.sha256(np.ascontiguousarray(p)).hexdigest() for p in out]),
+             sample=out[:, list(gc.HARNESS_ROWS)][:, :, ::29].copy(),
+             block=out[:, 96:112, 196:220].copy(), nanpix=out[:, 504, 604].copy())
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 CASES = {
     "lin_known_answer": case_lin_known_answer, "multilin": case_multilin, "ipc": case_ipc,
     "weights": case_weights, "rampfit": case_rampfit, "flat": case_flat, "refpix": case_refpix,
-    "chain": case_chain, "post": case_post,
+    "chain": case_chain, "post": case_post, "harness": case_harness,
 }
 
 if __name__ == "__main__":
