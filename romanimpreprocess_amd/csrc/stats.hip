@@ -99,38 +99,33 @@ __device__ __forceinline__ uint32_t f2key(float v) {
 }
 __device__ __forceinline__ float key2f(uint32_t k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
 
-// One wave per 64 pixels; the column of S keys of each pixel sits in LDS (tile[s*64 + lane]) or, when S*256 B does not fit,
-// is re-read from the stack.  k-th smallest key by radix selection, two bits per pass; np.median semantics: mean of the two
-// middle elements in f32 for even S ((a + b) / 2), NaN if the column holds a NaN.
+// One workgroup of four waves per 64 pixels; the column of S keys of each pixel sits in LDS (tile[s*64 + lane]) or, when
+// S*256 B does not fit, is re-read from the stack.  k-th smallest key by radix selection, two bits per pass: wave w counts
+// over the realisations s = w (mod 4), the four partial counts meet in LDS and every wave takes the same decision.
+// np.median semantics: mean of the two middle elements in f32 for even S ((a + b) / 2), NaN if the column holds a NaN.
 template <bool LDS>
-__global__ __launch_bounds__(64) void seed_median_kernel(const float *__restrict__ stack, int S, size_t npix,
-                                                         float *__restrict__ out) {
+__global__ __launch_bounds__(256) void seed_median_kernel(const float *__restrict__ stack, int S, size_t npix,
+                                                          float *__restrict__ out) {
     extern __shared__ uint32_t tile[];
-    const int lane = threadIdx.x;
+    __shared__ uint32_t part[2][4][3][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t p = (size_t)blockIdx.x * 64 + lane;
     const bool live = p < npix;
     const size_t pp = live ? p : npix - 1;
-    bool nan = false;
-    if (LDS) {
-        for (int s = 0; s < S; ++s) {
-            const float v = stack[(size_t)s * npix + pp];
-            nan |= v != v;
-            tile[s * 64 + lane] = f2key(v);
-        }
-    } else {
-        for (int s = 0; s < S; ++s) {
-            const float v = stack[(size_t)s * npix + pp];
-            nan |= v != v;
-        }
+    uint32_t nan = 0;
+    for (int s = w; s < S; s += 4) {
+        const float v = stack[(size_t)s * npix + pp];
+        nan |= v != v ? 1u : 0u;
+        if (LDS) tile[s * 64 + lane] = f2key(v);
     }
     auto key = [&](int s) -> uint32_t { return LDS ? tile[s * 64 + lane] : f2key(stack[(size_t)s * npix + pp]); };
-    int k = (S - 1) / 2;
+    int k = (S - 1) / 2, buf = 0;
     uint32_t prefix = 0;
     for (int sh = 30; sh >= 0; sh -= 2) {
         const uint32_t hi = sh == 30 ? 0u : (0xFFFFFFFFu << (sh + 2));
-        int c0 = 0, c1 = 0, c2 = 0;
+        uint32_t c0 = 0, c1 = 0, c2 = 0;
 #pragma unroll 8
-        for (int s = 0; s < S; ++s) {
+        for (int s = w; s < S; s += 4) {
             const uint32_t e = key(s);
             const bool in = (e & hi) == prefix;
             const uint32_t d = (e >> sh) & 3u;
@@ -138,26 +133,47 @@ __global__ __launch_bounds__(64) void seed_median_kernel(const float *__restrict
             c1 += (in && d <= 1) ? 1 : 0;
             c2 += (in && d <= 2) ? 1 : 0;
         }
+        part[buf][w][0][lane] = c0;
+        part[buf][w][1][lane] = c1;
+        part[buf][w][2][lane] = c2;
+        __syncthreads();   // also orders the tile stores of the load loop before the first reads of other waves' keys
+        c0 = c1 = c2 = 0;
+        for (int q = 0; q < 4; ++q) {
+            c0 += part[buf][q][0][lane];
+            c1 += part[buf][q][1][lane];
+            c2 += part[buf][q][2][lane];
+        }
+        buf ^= 1;   // the other buffer is free: every wave has passed the barrier after reading it
         uint32_t d;
-        if (k < c0) d = 0;
-        else if (k < c1) { d = 1; k -= c0; }
-        else if (k < c2) { d = 2; k -= c1; }
+        if (k < (int)c0) d = 0;
+        else if (k < (int)c1) { d = 1; k -= c0; }
+        else if (k < (int)c2) { d = 2; k -= c1; }
         else { d = 3; k -= c2; }
         prefix |= d << sh;
     }
-    float med = key2f(prefix);
+    uint32_t le = 0, nxt = 0xFFFFFFFFu;
     if ((S & 1) == 0) {
-        int le = 0;
-        uint32_t nxt = 0xFFFFFFFFu;
 #pragma unroll 8
-        for (int s = 0; s < S; ++s) {
+        for (int s = w; s < S; s += 4) {
             const uint32_t e = key(s);
             le += e <= prefix ? 1 : 0;
             if (e > prefix && e < nxt) nxt = e;
         }
-        const uint32_t second = le >= S / 2 + 1 ? prefix : nxt;
-        med = __fadd_rn(med, key2f(second)) / 2.0f;
     }
+    part[buf][w][0][lane] = le;
+    part[buf][w][1][lane] = nxt;
+    part[buf][w][2][lane] = nan;
+    __syncthreads();
+    if (w != 0) return;
+    le = nan = 0;
+    nxt = 0xFFFFFFFFu;
+    for (int q = 0; q < 4; ++q) {
+        le += part[buf][q][0][lane];
+        nxt = min(nxt, part[buf][q][1][lane]);
+        nan |= part[buf][q][2][lane];
+    }
+    float med = key2f(prefix);
+    if ((S & 1) == 0) med = __fadd_rn(med, key2f((int)le >= S / 2 + 1 ? prefix : nxt)) / 2.0f;
     if (nan) med = __uint_as_float(0x7FC00000u);
     if (live) out[p] = med;
 }
@@ -169,9 +185,9 @@ int launch_median(rip_ctx *ctx, const float *stack, int S, size_t npix, float *o
         if (bytes > 48 * 1024)
             RIP_HIP(ctx, hipFuncSetAttribute((const void *)seed_median_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)bytes));
-        hipLaunchKernelGGL(seed_median_kernel<true>, grid, dim3(64), bytes, ctx->stream, stack, S, npix, out);
+        hipLaunchKernelGGL(seed_median_kernel<true>, grid, dim3(256), bytes, ctx->stream, stack, S, npix, out);
     } else {
-        hipLaunchKernelGGL(seed_median_kernel<false>, grid, dim3(64), 0, ctx->stream, stack, S, npix, out);
+        hipLaunchKernelGGL(seed_median_kernel<false>, grid, dim3(256), 0, ctx->stream, stack, S, npix, out);
     }
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
