@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--groups", type=int, default=8, choices=(8, 16))
     ap.add_argument("--side", type=int, default=4096)
+    ap.add_argument("--ipc-dtype", default="f32", choices=("f32", "f64"),
+                    help="dtype of the ipc4d coefficients (the reference's production writer stores f64)")
+    ap.add_argument("--p-order", type=int, default=8, choices=(3, 8, 10), help="Legendre order of the linearity file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -115,9 +118,10 @@ def main():
     from romanimpreprocess_amd import pipeline, synth
 
     rp = synth.READ_PATTERN_8 if args.groups == 8 else synth.READ_PATTERN_16
-    G, N, nb, p_order = len(rp), args.side, 4, 8
+    G, N, nb, p_order = len(rp), args.side, 4, args.p_order
+    kdt = np.float64 if args.ipc_dtype == "f64" else np.float32
     # synthetic CALDIR + ramp (seeded; a strip repeated down the frame so that the host prepares it in seconds)
-    cal, ramp = synth.make_tiled_inputs(N, N, read_pattern=rp, p_order=p_order, seed=1 + rank, strip_rows=128)
+    cal, ramp = synth.make_tiled_inputs(N, N, read_pattern=rp, p_order=p_order, seed=1 + rank, strip_rows=128, ipc_dtype=kdt)
     cb = pipeline.Calibrator(device=local_rank)
     cb.load_caldir(0, cal)
     pid, meta = cb.plan_for(rp, ramp["frame_time"])
@@ -181,7 +185,7 @@ def main():
         raise SystemExit(f"bench sanity check failed: good fraction {frac_good}, finite {finite}")
 
     if rank == 0:
-        total, per_kernel = alg_bytes(G, N, N, nb, p_order + 1)
+        total, per_kernel = alg_bytes(G, N, N, nb, p_order + 1, ipc_size=8 if args.ipc_dtype == "f64" else 4)
         fused = ms[2] < 0.05 * max(ncalls, 1) and ms[3] < 0.05 * max(ncalls, 1)  # only event gaps
         names = ["refpix_prepass", "chain_fused" if fused else "cube_stage", "ipc", "rampfit"]
         per_kernel["chain_fused"] = total - G * N * 128 * 2 - N * 128 * 4  # everything but the reference-output block
@@ -195,7 +199,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC measurement of the same command, committed under profiles/
         traffic = None
         tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
-        if dom == "chain_fused" and (G, N) == (8, 4096) and os.path.exists(tpath):
+        if dom == "chain_fused" and (G, N, p_order, args.ipc_dtype) == (8, 4096, 8, "f32") and os.path.exists(tpath):
             with open(tpath) as tf:
                 traffic = json.load(tf).get("traffic_bytes_per_launch")
         out = {
@@ -209,10 +213,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.ipc_dtype == "f32" else "f32 (IPC stage in f64)",
             "data": "synthetic",
             "config": {"workload": f"single {N}x{N}x{G}-group ramp, full CALDIR (linearitylegendre P_ORDER {p_order} + ipc4d + "
-                                   "biascorr + dark + read + flat), u16 cube resident in HBM, f32 gain / f32 ipc4d",
+                                   f"biascorr + dark + read + flat), u16 cube resident in HBM, f32 gain / {args.ipc_dtype} ipc4d",
                        "ramps_per_step_per_gpu": 1, "sharding": f"ramps round-robin over {world} GPU(s), index list broadcast over RCCL"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

@@ -1,4 +1,4 @@
-// Fused L1->L2 kernel, wave-specialised form (f32 ipc4d, f32 gain, G <= 8): the arithmetic, the strip geometry and
+// Fused L1->L2 kernel, wave-specialised form (f32 gain; f32 ipc4d with 6, 8 or 16 groups, f64 ipc4d with 6 or 8): the arithmetic, the strip geometry and
 // the packed-pair forms are those of chain_kernel.h; what changes is WHO does what.
 //
 // chain_kernel.h is bound by instruction issue at 2 waves/SIMD (one wave carries the registers of the linearity
@@ -84,18 +84,31 @@ __device__ __forceinline__ const RIP_K C2KernArgs *c2_args(const RIP_K C2KernArg
     return p;
 }
 
-template <int NP, int G, int START>
-__global__ __launch_bounds__(C2_THREADS, (G > 8 ? 2 : 4)) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
+struct C2AllT {
+    static constexpr bool value = true;
+};
+struct C2SomeT {
+    static constexpr bool value = false;
+};
+
+template <int NP, int G, int START, typename KT = float>
+__global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
                                                                const RipVariant *__restrict__ vars,
                                                                const float *__restrict__ kvals,
                                                                const RipDiff *__restrict__ diffs, double guard) {
     static_assert(G % 2 == 0 && G > 4 && G <= 16, "pairs of groups; the groupdq bytes travel packed four to a word");
     constexpr int QW = (G + 3) / 4;  // words of packed group flags per pixel
     constexpr int GP = G / 2;
+    // f64 ipc4d (KT = double; the reference's production writer stores f64): x = gain*phi stays f32, the Neumann iterates and
+    // the division by the gain are f64 (numpy promotion, ipc_linearity.py:95-142), so the O1 ring holds doubles, one plane per
+    // group: 94 KB of LDS for 8 groups, one workgroup per CU (2 waves/SIMD, up to 256 VGPRs)
+    constexpr bool K64 = sizeof(KT) == 8;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     f2 *X2 = reinterpret_cast<f2 *>(lds_raw);                       // [GP][4][C2_COLS]  x = gain*phi, pair-interleaved
     f2 *O12 = X2 + GP * 4 * C2_COLS;                                // [GP][3][C2_COLS]  first Neumann iterate
-    uint32_t *DQ = reinterpret_cast<uint32_t *>(O12 + GP * 3 * C2_COLS);  // [4][C2_COLS] linearity dq of the row
+    double *O1d = reinterpret_cast<double *>(O12);                  // f64 ipc4d: [G][3][C2_COLS] instead
+    uint32_t *DQ = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(O12) +
+                                                (size_t)G * 3 * C2_COLS * sizeof(KT));  // [4][C2_COLS] linearity dq of the row
     uint32_t *QS = DQ + 4 * C2_COLS;                                // [4][QW][C2_COLS] groupdq bytes of the pixel, packed
     double *LN = reinterpret_cast<double *>(QS + 4 * QW * C2_COLS);  // [3][G][2] channel lines of this strip
 
@@ -204,6 +217,50 @@ __global__ __launch_bounds__(C2_THREADS, (G > 8 ? 2 : 4)) void chain2_kernel(Cha
         }
         const unsigned um = (want && y >= ay0 && y < ay1) ? rowbits : 0u;
         return lane_mask & um;
+    };
+
+    // f64 coefficients: the same walk with 8-byte loads, nine scalars in the reference's term order
+    auto load_kd = [&](const void *kern_base, int y, bool want, double (&kk)[9]) -> unsigned {
+        unsigned rowoff[3];
+        bool rok[3];
+#pragma unroll
+        for (int dyi = 0; dyi < 3; ++dyi) {
+            const int sy = y - (dyi - 1);
+            rok[dyi] = sy >= ay0 && sy < ay1;
+            rowoff[dyi] = (unsigned)min(max(sy, 0), ny - 1) * (row4 * 2u);
+        }
+        const unsigned rowbits = (rok[0] ? 0x184u : 0u) | (rok[1] ? 0x019u : 0u) | (rok[2] ? 0x062u : 0u);
+        const __amdgpu_buffer_rsrc_t kr = c2_rsrc(kern_base);
+        unsigned pofs = 0;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const int dy = p / 3 - 1, dx = p % 3 - 1;
+            const int k = (dy == 0) ? (dx == 0 ? 0 : dx == 1 ? 3 : 4) : (dy == 1) ? (dx == 0 ? 1 : dx == 1 ? 5 : 6)
+                                                                                  : (dx == 0 ? 2 : dx == 1 ? 7 : 8);
+            kk[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(kr, cx4[dx + 1] * 2u, pofs + rowoff[dy + 1], 0));
+            pofs += pl4 * 2u;
+        }
+        const unsigned um = (want && y >= ay0 && y < ay1) ? rowbits : 0u;
+        return lane_mask & um;
+    };
+    // forward IPC operator in f64 at one column: at_m / at_0 / at_p read rows y-1 / y / y+1 at a column offset; term order
+    // and edge rule of ipc_linearity.py:69-94 (fwd_rows in chain_kernel.h)
+    auto ipc9 = [&](auto allc, auto at_m, auto at_0, auto at_p, const double (&kk)[9], unsigned valid) -> double {
+        constexpr bool ALL = decltype(allc)::value;
+        double acc = (double)at_0(0) * kk[0];
+        auto term = [&](int k, double v) {
+            const double p_ = v * kk[k];
+            acc = (ALL || ((valid >> k) & 1u)) ? acc + p_ : acc;
+        };
+        term(1, (double)at_m(0));
+        term(2, (double)at_p(0));
+        term(3, (double)at_0(-1));
+        term(4, (double)at_0(1));
+        term(5, (double)at_m(-1));
+        term(6, (double)at_m(1));
+        term(7, (double)at_p(-1));
+        term(8, (double)at_p(1));
+        return acc;
     };
 
 #ifdef CH_STAMP
@@ -438,8 +495,13 @@ __global__ __launch_bounds__(C2_THREADS, (G > 8 ? 2 : 4)) void chain2_kernel(Cha
             // IPC coefficients of row yc, consumed by C after the barrier; issued here so that their registers are not live
             // during A
             f2 kC[5];
+            double kCd[9];
             kC[4].y = 0.0f;
-            const unsigned vC = load_k(ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
+            unsigned vC;
+            if constexpr (K64)
+                vC = load_kd(ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kCd);
+            else
+                vC = load_k(ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
             CH_T(2)
             C2_SYNC();
             CH_T(3)
@@ -452,7 +514,25 @@ __global__ __launch_bounds__(C2_THREADS, (G > 8 ? 2 : 4)) void chain2_kernel(Cha
                 const bool all = __all(vC == 0x1ffu || vC == 0u);
                 const int sm = (yc - 1) & 3, s0 = yc & 3, sp = (yc + 1) & 3;
                 const int so = so_c;
-                if (do_c && all && !(dbg & 1)) {
+                if constexpr (K64) {
+                    const float *Xf = reinterpret_cast<const float *>(X2);
+#pragma unroll
+                    for (int p0 = 0; p0 < GP; ++p0) {
+                        fetch_coefs(kb2, r + 4, p0 * CO_STEP, (p0 * CO_STEP + CO_STEP < NCO) ? p0 * CO_STEP + CO_STEP : NCO, rr);
+                        if (do_c) {
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const float *xb = Xf + (size_t)p0 * 4 * C2_COLS * 2 + e;  // scalar view of the pair-interleaved ring
+                                auto at_m = [&](int dx) { return xb[((sm * C2_COLS) + col + dx) * 2]; };
+                                auto at_0 = [&](int dx) { return xb[((s0 * C2_COLS) + col + dx) * 2]; };
+                                auto at_p = [&](int dx) { return xb[((sp * C2_COLS) + col + dx) * 2]; };
+                                const double f = all ? ipc9(C2AllT{}, at_m, at_0, at_p, kCd, vC) : ipc9(C2SomeT{}, at_m, at_0, at_p, kCd, vC);
+                                const float xc = at_0(0);
+                                O1d[((2 * p0 + e) * 3 + so) * C2_COLS + col] = (double)(xc + xc) - f;
+                            }
+                        }
+                    }
+                } else if (do_c && all && !(dbg & 1)) {
                     // interior wave: one straight-line block (see O2)
 #pragma unroll
                     for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(kC[i]));
@@ -488,9 +568,12 @@ __global__ __launch_bounds__(C2_THREADS, (G > 8 ? 2 : 4)) void chain2_kernel(Cha
     } else {
         // =========================================================================== fit waves
         f2 kF[5];
+        double kFd[9];
         unsigned vF = 0;
 #pragma unroll
         for (int k = 0; k < 5; ++k) kF[k] = f2{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) kFd[k] = 0.0;
         const RipVariant v0 = rip_load_variant(vars, 0);
         const RipFitConst fc0 = rip_fit_const(h);
         constexpr int start = START;  // first group of the fit (exclude_first)
@@ -539,7 +622,27 @@ __global__ __launch_bounds__(C2_THREADS, (G > 8 ? 2 : 4)) void chain2_kernel(Cha
                 const bool all = __all(vF == 0x1ffu || !act);
                 const int o0_ = o0_r, om_ = (o0_r == 0) ? 2 : o0_r - 1, op_ = (o0_r == 2) ? 0 : o0_r + 1;
                 constexpr int NB = (GP % 2 == 0) ? 2 : 1;
-                if (all && fastdiv && __all(act) && !(dbg & 2)) {
+                if constexpr (K64) {
+                    // f64 iterate: (O1 + x) - fwd(O1) and the division by the gain in f64, one rounding to f32 at the end
+                    const float *Xf = reinterpret_cast<const float *>(X2);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float xc = Xf[(((g / 2) * 4 + sx) * C2_COLS + col) * 2 + (g & 1)];
+                        float val = xc;
+                        if (act) {
+                            const double *ob = O1d + (size_t)g * 3 * C2_COLS;
+                            auto at_m = [&](int dx) { return ob[om_ * C2_COLS + col + dx]; };
+                            auto at_0 = [&](int dx) { return ob[o0_ * C2_COLS + col + dx]; };
+                            auto at_p = [&](int dx) { return ob[op_ * C2_COLS + col + dx]; };
+                            const double f = all ? ipc9(C2AllT{}, at_m, at_0, at_p, kFd, vF) : ipc9(C2SomeT{}, at_m, at_0, at_p, kFd, vF);
+                            const double o2 = (at_0(0) + (double)xc) - f;
+                            val = (float)(o2 / (double)e_gain);
+                        }
+                        d[g] = val;
+                    }
+#pragma unroll
+                    for (int p0 = 0; p0 < GP; ++p0) dpair[p0] = f2{d[2 * p0], d[2 * p0 + 1]};
+                } else if (all && fastdiv && __all(act) && !(dbg & 2)) {
                     // interior wave: one straight-line block (the coefficient pairs stay 64-bit registers whose halves the
                     // packed multiplies broadcast through op_sel)
 #pragma unroll
@@ -613,9 +716,14 @@ __global__ __launch_bounds__(C2_THREADS, (G > 8 ? 2 : 4)) void chain2_kernel(Cha
             const RIP_K C2KernArgs *kg = c2_args(kargs);  // S2 copy
             // ---- S2: coefficients and gain of the next row's O2, second half of the fit, tail of pixel (r, c)
             f2 kN[5];
+            double kNd[9];
             kN[4].y = 0.0f;
             const bool next_on = (r + 1 >= R0) && (r + 1 < R1) && col >= 2 && col < C2_COLS - 2;
-            const unsigned vN = load_k(kg->a.kern, r + 1, next_on, kN);
+            unsigned vN;
+            if constexpr (K64)
+                vN = load_kd(kg->a.kern, r + 1, next_on, kNd);
+            else
+                vN = load_k(kg->a.kern, r + 1, next_on, kN);
             gain_next = c2_ld_f32(c2_rsrc(kg->a.planes), cc4, (unsigned)(NP + 4) * pl4 + (unsigned)min(max(r + 1, 0), ny - 1) * row4);
             CH_T(4)
             C2_DRAIN()
@@ -706,6 +814,10 @@ __global__ __launch_bounds__(C2_THREADS, (G > 8 ? 2 : 4)) void chain2_kernel(Cha
             vF = vN;
 #pragma unroll
             for (int k = 0; k < 5; ++k) kF[k] = kN[k];
+            if constexpr (K64) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) kFd[k] = kNd[k];
+            }
         }
     }
 #ifdef CH_STAMP
@@ -716,14 +828,15 @@ __global__ __launch_bounds__(C2_THREADS, (G > 8 ? 2 : 4)) void chain2_kernel(Cha
 #endif
 }
 
-static inline size_t chain2_lds_bytes(int G) {
-    return (size_t)(G / 2) * C2_COLS * 8 * (4 + 3) + (size_t)C2_COLS * 4 * 4 * (1 + (G + 3) / 4) + (size_t)3 * G * 2 * 8;
+static inline size_t chain2_lds_bytes(int G, size_t ksize = 4) {
+    return (size_t)(G / 2) * C2_COLS * 8 * 4 + (size_t)G * C2_COLS * ksize * 3 + (size_t)C2_COLS * 4 * 4 * (1 + (G + 3) / 4) +
+           (size_t)3 * G * 2 * 8;
 }
 
-template <int NP, int G, int START>
+template <int NP, int G, int START, typename KT = float>
 static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
     extern double rip_guard_band;
-    const size_t lds = chain2_lds_bytes(G);
+    const size_t lds = chain2_lds_bytes(G, sizeof(KT));
     static int ncu = 0;
     if (!ncu) {
         hipDeviceProp_t prop;
@@ -732,7 +845,7 @@ static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
     }
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
-    const int max_wg = (G > 8 ? 8 : 16) / (C2_THREADS / 64);  // 4 waves/SIMD at <= 128 VGPRs (2 at 256 for G = 16)
+    const int max_wg = ((G > 8 || sizeof(KT) == 8) ? 8 : 16) / (C2_THREADS / 64);  // 4 waves/SIMD at <= 128 VGPRs (2 at 256 for G = 16 / f64)
     if (per_cu > max_wg) per_cu = max_wg;
     const int nstrips = (a.nx + C2_OUTW - 1) / C2_OUTW;
     int nranges = (int)(((long)ncu * per_cu) / nstrips);
@@ -740,9 +853,9 @@ static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
     if (nranges < 1) nranges = 1;
     const long grid = (long)nranges * nstrips;
     if (lds > 48 * 1024)
-        RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chain2_kernel<NP, G, START>),
+        RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chain2_kernel<NP, G, START, KT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((chain2_kernel<NP, G, START>), dim3((unsigned)grid), dim3(C2_THREADS), lds, ctx->stream, a,
+    hipLaunchKernelGGL((chain2_kernel<NP, G, START, KT>), dim3((unsigned)grid), dim3(C2_THREADS), lds, ctx->stream, a,
                        reinterpret_cast<const RipPlanHeader *>(plan->dev), plan->d_variants, plan->d_k, plan->d_diffs,
                        rip_guard_band);
     RIP_HIP(ctx, hipGetLastError());
@@ -750,9 +863,9 @@ static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
 }
 
 // returns the launch status, or 1 when the plan is not one the specialised kernel was compiled for
-template <int NP, int G>
+template <int NP, int G, typename KT = float>
 static int launch_chain2(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
-    if (plan->h.start == 0 && plan->dense.valid == rip_full_valid<G, 0>()) return launch_chain2_s<NP, G, 0>(ctx, plan, a);
-    if (plan->h.start == 1 && plan->dense.valid == rip_full_valid<G, 1>()) return launch_chain2_s<NP, G, 1>(ctx, plan, a);
+    if (plan->h.start == 0 && plan->dense.valid == rip_full_valid<G, 0>()) return launch_chain2_s<NP, G, 0, KT>(ctx, plan, a);
+    if (plan->h.start == 1 && plan->dense.valid == rip_full_valid<G, 1>()) return launch_chain2_s<NP, G, 1, KT>(ctx, plan, a);
     return 1;
 }

@@ -1,8 +1,18 @@
 // Instantiations of the fused chain kernels for 11 Legendre planes (chain_kernel.h, chain2_kernel.h).
 #include "chain2_kernel.h"
 
+int rip_launch_chain2_k64_np11(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a);  // chain_np11_k64.hip
+
 int rip_launch_chain_np11(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int k_dtype) {
-    // wave-specialised kernel for the common case (f32 ipc4d, 6, 8 or 16 groups); general fused kernel otherwise
+    // wave-specialised kernel for the common cases (f32 ipc4d: 6, 8 or 16 groups; f64 ipc4d: 6 or 8 groups); general fused
+    // kernel otherwise
+    if (k_dtype == RIP_F64 && ctx->use_chain2) {
+        const int rc = rip_launch_chain2_k64_np11(ctx, plan, a);
+        if (rc != 1) {
+            ctx->last_form = 2;
+            return rc;
+        }
+    }
     if (k_dtype == RIP_F32 && ctx->use_chain2) {
         int rc = 1;
         if (a.ngrp == 8) rc = launch_chain2<11, 8>(ctx, plan, a);

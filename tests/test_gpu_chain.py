@@ -205,24 +205,30 @@ def test_calibrateimage_files_end_to_end(tmp_path):
 # between its column strips / row ranges
 
 SPECIALISED = [
-    # name, (ny, nx), read pattern, p_order (NP = p + 1 planes), exclude_first
-    ("g6_np9_start1", (48, 384), synth.READ_PATTERN_6, 8, True),
-    ("g6_np4_start0", (40, 256), synth.READ_PATTERN_6, 3, False),
-    ("g8_np11_start1", (40, 256), synth.READ_PATTERN_8, 10, True),
-    ("g8_np9_start0", (56, 256), synth.READ_PATTERN_8, 8, False),
-    ("g8_np4_start1", (40, 128), synth.READ_PATTERN_8, 3, True),
-    ("g16_np9_start1", (40, 256), synth.READ_PATTERN_16, 8, True),
-    ("g16_np4_start0", (32, 128), synth.READ_PATTERN_16, 3, False),
+    # name, (ny, nx), read pattern, p_order (NP = p + 1 planes), exclude_first, ipc4d dtype
+    ("g6_np9_start1", (48, 384), synth.READ_PATTERN_6, 8, True, np.float32),
+    ("g6_np4_start0", (40, 256), synth.READ_PATTERN_6, 3, False, np.float32),
+    ("g8_np11_start1", (40, 256), synth.READ_PATTERN_8, 10, True, np.float32),
+    ("g8_np9_start0", (56, 256), synth.READ_PATTERN_8, 8, False, np.float32),
+    ("g8_np4_start1", (40, 128), synth.READ_PATTERN_8, 3, True, np.float32),
+    ("g16_np9_start1", (40, 256), synth.READ_PATTERN_16, 8, True, np.float32),
+    ("g16_np4_start0", (32, 128), synth.READ_PATTERN_16, 3, False, np.float32),
+    # f64 ipc4d (the reference's production writer): f64 Neumann iterates
+    ("g8_np9_start1_k64", (56, 384), synth.READ_PATTERN_8, 8, True, np.float64),
+    ("g8_np11_start0_k64", (40, 256), synth.READ_PATTERN_8, 10, False, np.float64),
+    ("g6_np4_start1_k64", (48, 128), synth.READ_PATTERN_6, 3, True, np.float64),
+    ("g6_np9_start0_k64", (40, 256), synth.READ_PATTERN_6, 8, False, np.float64),
 ]
 
 
-@pytest.mark.parametrize("name,shape,rp,p,exclude_first", SPECIALISED)
-def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first):
+@pytest.mark.parametrize("name,shape,rp,p,exclude_first,kdt", SPECIALISED)
+def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first, kdt):
     ny, nx = shape
     ctx = gpu_context()
     ctx.set_option("fused", 1)
     ctx.set_option("chain2", 1)
-    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=p, seed=91, bias_amplitude=2.0, bad_lin_frac=0.01)
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=p, seed=91, bias_amplitude=2.0, bad_lin_frac=0.01,
+                            ipc_dtype=kdt)
     ramp = synth.make_ramp(cal, read_pattern=rp, seed=92, cr_frac=0.03)
     ref = oracle.calibrate_arrays(ramp, cal, exclude_first=exclude_first)
     cb = pipeline.Calibrator(ctx=ctx)
@@ -239,12 +245,14 @@ def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first):
     cb.ctx.drop_caldir(4)
 
 
-def test_fused_forms_agree_across_seams():
+@pytest.mark.parametrize("kdt", [np.float32, np.float64])
+def test_fused_forms_agree_across_seams(kdt):
     """A frame wider than several 252-column strips and taller than several row ranges: the wave-specialised kernel, the
     general fused kernel and the stage kernels must give identical bits (halo columns, range boundaries, frame edges)."""
     rp = synth.READ_PATTERN_8
     ny, nx = 1160, 896
-    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=31, bias_amplitude=2.0, bad_lin_frac=0.005)
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=31, bias_amplitude=2.0, bad_lin_frac=0.005,
+                            ipc_dtype=kdt)
     ramp = synth.make_ramp(cal, read_pattern=rp, seed=32, cr_frac=0.02)
     ctx = gpu_context()
     cb = pipeline.Calibrator(ctx=ctx)
