@@ -229,8 +229,13 @@ def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first, kdt):
     ctx.set_option("chain2", 1)
     cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=p, seed=91, bias_amplitude=2.0, bad_lin_frac=0.01,
                             ipc_dtype=kdt)
+    # degenerate gains: the waves holding them leave the shared-reciprocal division for the division operator
+    cal["gain"]["data"][20, 30] = 0.0
+    cal["gain"]["data"][21, 40] = 1e-25
+    cal["gain"]["data"][22, 50] = -1.5
     ramp = synth.make_ramp(cal, read_pattern=rp, seed=92, cr_frac=0.03)
-    ref = oracle.calibrate_arrays(ramp, cal, exclude_first=exclude_first)
+    with np.errstate(all="ignore"):
+        ref = oracle.calibrate_arrays(ramp, cal, exclude_first=exclude_first)
     cb = pipeline.Calibrator(ctx=ctx)
     cb.load_caldir(4, cal)
     lines = _oracle_lines(ref, len(rp), nx // 128)

@@ -4,7 +4,7 @@
 set -e
 REPO=$(cd "$(dirname "$0")/../.." && pwd)
 C=$1; T=$2
-W=/tmp/variant_$T
+W=$REPO/gpurun_out/tmp/variant_$T
 rm -rf $W && mkdir -p $W
 git -C $REPO archive $C romanimpreprocess_amd/csrc include | tar -x -C $W
 make -C $W/romanimpreprocess_amd/csrc -j8 LIB=$REPO/romanimpreprocess_amd/libromanhip_$T.so 2>&1 | grep -E "error" || true

@@ -13,7 +13,8 @@ from romanimpreprocess_amd import pipeline, synth
 
 rp = synth.READ_PATTERN_8
 N = 4096
-cal, ramp = synth.make_tiled_inputs(N, N, read_pattern=rp, p_order=8, seed=1, strip_rows=64)
+KDT = np.float64 if os.environ.get("IPC64") == "1" else np.float32  # IPC64=1: f64 ipc4d coefficients
+cal, ramp = synth.make_tiled_inputs(N, N, read_pattern=rp, p_order=8, seed=1, strip_rows=64, ipc_dtype=KDT)
 cb = pipeline.Calibrator(device=0)
 cb.ctx.set_option("chain2", int(os.environ.get("CHAIN2", "1")))
 cb.load_caldir(0, cal)
