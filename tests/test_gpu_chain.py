@@ -314,3 +314,43 @@ def test_saturation_flagging_on_device_matches_host_restatement():
         for k in ("groupdq", "pixeldq", "slope", "err_read", "err_poisson"):
             assert_same_bits(a[k], b[k], f"{k} (backup {backup})")
         cb.ctx.drop_caldir(6)
+
+
+def test_full_frame_4096x4096x8_vs_oracle_and_between_forms():
+    """BASELINE config 2 at its full size (the bench workload): the numpy oracle on the whole frame (about a minute of CPU)
+    against the wave-specialised kernel, bit for bit with LAPACK's channel lines handed in; then the three device forms
+    (specialised, general fused, stage kernels) against each other with the lines fitted on the device."""
+    rp = synth.READ_PATTERN_8
+    n = 4096
+    cal, ramp = synth.make_tiled_inputs(n, n, read_pattern=rp, p_order=8, seed=1, strip_rows=128)
+    ref = oracle.calibrate_arrays(ramp, cal)
+    ctx = gpu_context()
+    cb = pipeline.Calibrator(ctx=ctx)
+    cb.load_caldir(6, cal)
+    try:
+        ctx.set_option("fused", 1)
+        ctx.set_option("chain2", 1)
+        got = cb.calibrate(6, ramp, channel_lines=_oracle_lines(ref, len(rp), n // 128))
+        assert ctx.last_chain_form() == 2
+        assert_same_bits(got["groupdq"], ref["groupdq"], "groupdq")
+        assert_same_bits(got["pixeldq"], ref["pixeldq"], "pixeldq")
+        for k in ("slope", "err_read", "err_poisson"):
+            assert_same_bits(got[k], ref[k], k, zero_sign_ok=True)
+        frac_good = np.mean(got["pixeldq"][4:-4, 4:-4] == 0)
+        assert frac_good > 0.9 and np.count_nonzero(got["pixeldq"] & 4) > 10000
+        del ref
+        outs = []
+        for fused, chain2 in ((1, 1), (1, 0), (0, 0)):
+            ctx.set_option("fused", fused)
+            ctx.set_option("chain2", chain2)
+            outs.append(cb.calibrate(6, ramp))
+        for other, label in ((outs[1], "general fused"), (outs[2], "stage kernels")):
+            for k in ("slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
+                assert_same_bits(outs[0][k], other[k], f"{k}: specialised vs {label}")
+        # device-fitted lines against LAPACK's: flags identical, slopes within the north-star tolerance
+        assert_same_bits(outs[0]["pixeldq"], got["pixeldq"], "pixeldq (device lines)")
+        np.testing.assert_allclose(outs[0]["slope"], got["slope"], rtol=1e-5, atol=1e-7)
+    finally:
+        ctx.set_option("fused", 1)
+        ctx.set_option("chain2", 1)
+        cb.ctx.drop_caldir(6)
