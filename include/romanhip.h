@@ -235,6 +235,14 @@ int rip_stage_gauss_hist(rip_ctx *ctx, const float *arr, int64_t n, const double
 int rip_stage_legendre2d(rip_ctx *ctx, float *arr, int ny, int nx, int order, const double *LPX, const double *LPY,
                          const double *coef, int subtract, float *model_out);
 
+/* ---- simulation side ------------------------------------------------- */
+/* ipc_linearity.invlinearity (ipc_linearity.py:347-394): 24 bisection steps on z in (-1, 1) of the Legendre series evaluated
+   as ipc_linearity._lin does without the extrapolation branch, then S = Smin + (Smax - Smin)/2 * (1 + z).  slin (ny,nx) f32 or
+   f64 (dtype); coefs (nplanes,ny,nx), smin, smax f32 already cut to the block; S has slin's dtype; exflag (ny,nx) u8 or NULL
+   (|z| > 1 at the last evaluation: the reference's second return value).  Host arrays.  Exact. */
+int rip_stage_invlinearity(rip_ctx *ctx, const void *slin, int dtype, int ny, int nx, int nplanes, const float *coefs,
+                           const float *smin, const float *smax, void *S, uint8_t *exflag);
+
 /* ---- statistics over many noise realisations of one ramp -- DEVICE pointers, asynchronous ------- */
 /* Replaces the per-pixel arithmetic of validation_tests/many_realizations.py:57-106 on stacks (nseeds, rows, nx) that stay
    in HBM (256 realisations of a 4096 x 4096 SCA: 56 GB).  All results are exact (f32 operations in the reference's order,

@@ -69,3 +69,29 @@ def attempt_corr_from_groupdq(groupdq):
     """``attempt_corr = ~rdq & pixel.SATURATED`` (``gen_cal_image.py:585-586``): nonzero where the
     group is NOT saturated."""
     return (~groupdq) & np.uint8(2)
+
+
+def invlinearity(Slin, coefs, Smin, Smax):
+    """``ipc_linearity.invlinearity`` (:347-394) on arrays already cut to the block: 24 bisection steps on z with the series
+    evaluated without linear extrapolation; returns (S, exflag of the last evaluation)."""
+    z = np.zeros_like(Slin)
+    for j in range(1, 25):
+        phi, exflag = legendre_series(z, coefs, linextrap=False)
+        z += np.where(phi < Slin, 1 / 2**j, -1 / 2**j)
+    return Smin + (Smax - Smin) / 2.0 * (1 + z), exflag
+
+
+def il_apply(counts, K, gain, coefs, Smin, Smax, Sref, start_e=0.0, electrons=False, electrons_out=False):
+    """``ipc_linearity.IL.apply`` (:459-513): counts (active region) -> DN_raw (or electrons).  ``K`` None skips the IPC;
+    full-frame linearity arrays, cut by the reference's border rule ``nb = (8192 - ny//2) % 16``."""
+    from . import ipc
+    conv = ipc.ipc_fwd(counts + start_e, K) if K is not None else counts + start_e
+    nyc, nxc = counts.shape
+    g = gain
+    if g.shape[0] > nyc:
+        b = (g.shape[0] - nyc) // 2
+        g = g[b:-b, b:-b]
+    nb = (8192 - nyc // 2) % 16
+    sl = (slice(nb, nb + nyc), slice(nb, nb + nxc))
+    S, _ = invlinearity(conv / (g if electrons else 1.0), coefs[(slice(None),) + sl], Smin[sl], Smax[sl])
+    return g * (S - Sref[sl]) if electrons_out else S

@@ -1,7 +1,9 @@
 """IPC and linearity on the GPU -- same call surface as the reference's ``utils/ipc_linearity.py``
-(``ipc_fwd`` :37, ``ipc_rev`` :102, ``correct_cube`` :145, ``multilin`` :276).  The simulation-side
-inverse (``invlinearity``, ``IL``) is outside the L1->L2 path.
+(``ipc_fwd`` :37, ``ipc_rev`` :102, ``correct_cube`` :145, ``multilin`` :276) and, from the simulation side
+(SURVEY.md 8f row 4), the inverse linearity ``invlinearity`` :347 and the ``IL`` class :397 that romanisim calls.
 """
+
+import sys
 
 import numpy as np
 
@@ -93,3 +95,75 @@ def multilin(S, linearity_file, origin=(0, 0), do_not_flag_first=True, attempt_c
         sref.ctypes.data, dq0.ctypes.data, int(bool(do_not_flag_first)), None if ac is None else ac.ctypes.data,
         phi.ctypes.data, dq.ctypes.data))
     return phi, dq
+
+
+def invlinearity(Slin, linearity_file, origin=(0, 0), ctx=None):
+    """Inverse linearity by 24 bisection steps (``ipc_linearity.py:347-394``; the reference's slowest simulation step).
+    ``Slin`` (ny,nx) in DN_lin -> ``(S, exflag)``: S in DN_raw with Slin's float dtype, exflag bool."""
+    ctx = ctx or _native.default_context()
+    Slin = _float_array(Slin)
+    dy, dx = Slin.shape
+    y0, x0 = origin[1], origin[0]
+    sl = (slice(y0, y0 + dy), slice(x0, x0 + dx))
+    with calio.open_tree(linearity_file) as F:
+        r = F["roman"]
+        smin = np.ascontiguousarray(r["Smin"][sl], dtype=np.float32)
+        smax = np.ascontiguousarray(r["Smax"][sl], dtype=np.float32)
+        coefs = np.ascontiguousarray(r["data"][(slice(None),) + sl], dtype=np.float32)
+    if smin.shape != (dy, dx):
+        raise ValueError(f"block {Slin.shape} at origin {origin} leaves the linearity file's frame")
+    S = np.empty_like(Slin)
+    ex = np.empty((dy, dx), np.uint8)
+    ctx.check(ctx.lib.rip_stage_invlinearity(ctx.h, Slin.ctypes.data, _native.dtype_code(Slin), dy, dx, coefs.shape[0],
+                                             coefs.ctypes.data, smin.ctypes.data, smax.ctypes.data, S.ctypes.data,
+                                             ex.ctypes.data))
+    return S, ex.astype(bool)
+
+
+class IL:
+    """IPC + inverse linearity as romanisim calls it (``ipc_linearity.py:397-513``): ``apply`` turns a linearised signal
+    into the non-linear, IPC-convolved one.  Same constructor, attributes and methods as the reference's class; the two
+    array operations run on the GPU (``rip_stage_ipc_image``, ``rip_stage_invlinearity``)."""
+
+    def __init__(self, linearity_file, gain_file, ipc_file, start_e=0.0, ctx=None):
+        self.linearity_file = linearity_file
+        self.gain_file = gain_file
+        self.ipc_file = ipc_file
+        self.start_e = start_e
+        self.ctx = ctx
+        with calio.open_tree(self.linearity_file) as f:
+            self._dq = np.copy(f["roman"]["dq"])
+
+    def set_dq(self, ngroup=1, nborder=4):
+        ny, nx = np.shape(self._dq)
+        self.dq = np.zeros((ngroup, ny - 2 * nborder, nx - 2 * nborder), dtype=np.uint32)
+        self.dq[:, :, :] = self._dq[None, nborder:ny - nborder, nborder:nx - nborder]
+
+    def apply(self, counts, electrons=False, electrons_out=False):
+        print("apply", electrons, electrons_out, np.shape(counts))
+        sys.stdout.flush()
+        if self.ipc_file is not None:
+            with calio.open_tree(self.ipc_file) as f:
+                counts_conv = ipc_fwd(counts + self.start_e, f["roman"]["data"], ctx=self.ctx)
+        else:
+            counts_conv = counts + self.start_e
+        nyc, nxc = np.shape(counts)
+        g_in = 1.0
+        g_out = 1.0
+        if electrons or electrons_out:
+            with calio.open_tree(self.gain_file) as f:
+                g = np.asarray(f["roman"]["data"])
+                nyg = np.shape(g)[0]
+                if nyg > nyc:
+                    nb = (nyg - nyc) // 2
+                    g = g[nb:-nb, nb:-nb]
+            if electrons:
+                g_in = g
+            if electrons_out:
+                g_out = g
+        nb = (8192 - nyc // 2) % 16
+        S, _ = invlinearity(counts_conv / g_in, self.linearity_file, origin=(nb, nb), ctx=self.ctx)
+        if not electrons_out:
+            return S
+        with calio.open_tree(self.linearity_file) as F:
+            return g_out * (S - F["roman"]["Sref"][nb:nb + nyc, nb:nb + nxc])

@@ -175,3 +175,26 @@ def harness_realisation(seed, j, ideal_act, nside=4096, nb=4):
 
 def harness_orient(ideal_big, scanum):
     return ideal_big[:, ::-1] if scanum % 3 == 0 else ideal_big[::-1, :]
+
+
+# ---- inverse linearity / IL.apply (simulation side): frames whose active height obeys the reference's border rule ----
+
+IL_SHAPE = (64, 80)   # active (56, 72): (8192 - 56 // 2) % 16 == 4 == the border width
+
+
+def il_case(seed, p_order, ipc_dtype, counts_dtype):
+    cal = small_cal(synth.READ_PATTERN_8, p_order, seed, ipc_dtype=ipc_dtype, shape=IL_SHAPE)
+    rng = np.random.default_rng(seed + 5)
+    na = (IL_SHAPE[0] - 8, IL_SHAPE[1] - 8)
+    counts = rng.uniform(-500.0, 6.0e4, size=na)           # DN_lin scale; electrons when divided by the gain
+    counts[rng.random(na) < 0.02] = 3.0e5                  # far beyond the well: z runs into +1
+    counts[rng.random(na) < 0.02] = -4.0e4                 # far below: z runs into -1
+    counts[3, 5] = np.nan
+    lin = cal["linearitylegendre"]
+    return {"counts": counts.astype(counts_dtype), "coefs": lin["data"], "Smin": lin["Smin"], "Smax": lin["Smax"],
+            "Sref": lin["Sref"], "lin_dq": lin["dq"], "gain": cal["gain"]["data"], "K": cal["ipc4d"]["data"],
+            "start_e": rng.uniform(0, 50, size=na).astype(np.float32)}
+
+
+IL_CASES = {"il_p8_f64": (81, 8, np.float32, np.float64), "il_p3_f32_k64": (82, 3, np.float64, np.float32),
+            "il_p10_f64_k64": (83, 10, np.float64, np.float64)}

@@ -171,3 +171,45 @@ def test_refpix_fullframe(name):
     assert np.count_nonzero(diff) < 2000, np.count_nonzero(diff)
     ulp = np.abs(img_b.view(np.int32).astype(np.int64) - img_a.view(np.int32).astype(np.int64))
     assert ulp.max() <= 1 or np.abs(img_b - img_a).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", list(gc.IL_CASES))
+def test_inverse_linearity_and_il_class(name):
+    """ipc_linearity.invlinearity / IL (simulation side) against the reference's own outputs."""
+    g = load_golden(name)
+    ctx = gpu_context()
+    lin = {"data": g["coefs"], "Smin": g["Smin"], "Smax": g["Smax"], "Sref": g["Sref"], "dq": g["lin_dq"]}
+    gain, ipc = {"data": g["gain"]}, {"data": g["K"]}
+    S, ex = ipc_linearity.invlinearity(g["counts"], lin, origin=(4, 4), ctx=ctx)
+    assert S.dtype == g["inv_S"].dtype and ex.dtype == bool
+    assert_same_bits(S, g["inv_S"], "invlinearity")
+    assert_same_bits(ex.astype(np.uint8), g["inv_ex"], "exflag")
+    with np.errstate(all="ignore"):
+        assert_same_bits(ipc_linearity.IL(lin, gain, ipc, ctx=ctx).apply(g["counts"]), g["apply_dn"], "IL.apply DN -> DN")
+        assert_same_bits(ipc_linearity.IL(lin, gain, ipc, ctx=ctx).apply(g["counts"], electrons=True), g["apply_e_in"],
+                         "IL.apply e -> DN")
+        assert_same_bits(ipc_linearity.IL(lin, gain, ipc, start_e=g["start_e"], ctx=ctx).apply(g["counts"], electrons=True,
+                                                                                             electrons_out=True),
+                         g["apply_e_both"], "IL.apply e -> e")
+        assert_same_bits(ipc_linearity.IL(lin, gain, None, start_e=25.0, ctx=ctx).apply(g["counts"], electrons_out=True),
+                         g["apply_noipc"], "IL.apply without IPC")
+    il = ipc_linearity.IL(lin, gain, ipc, ctx=ctx)
+    il.set_dq(ngroup=3)
+    assert_same_bits(il.dq, g["il_dq"], "IL.dq")
+    # round trip with the forward linearity (the reference's forward_backward check, test_workflow.py:335-379): < 0.002 DN
+    inside = np.isfinite(g["counts"]) & (g["counts"] > 0) & (g["counts"] < 3.0e4) & (g["lin_dq"][4:-4, 4:-4] == 0)
+    phi, _ = ipc_linearity.multilin(S[None].astype(np.float32), lin, origin=(4, 4), ctx=ctx)
+    assert np.nanmax(np.abs(phi[0][inside] - g["counts"][inside])) < 0.01
+
+
+def test_il_known_answers_of_the_reference_workflow_test():
+    """IL.apply's steps on the GPU against the reference's literals (test_workflow.py:402-407) and its class's output."""
+    from test_oracle_golden import il_example_inputs
+    g = load_golden("il_example")
+    ctx = gpu_context()
+    lin = {"data": g["coefs"], "Smin": g["Smin"], "Smax": g["Smax"]}
+    for ne, target, ref_out in zip(il_example_inputs(g), (g["target1"], g["target2"]), (g["ref_out1"], g["ref_out2"])):
+        conv = ipc_linearity.ipc_fwd(ne + 0.0, g["K"], ctx=ctx)
+        S, _ = ipc_linearity.invlinearity(conv / g["gain"], lin, ctx=ctx)
+        assert np.all(np.abs(S[10:12, 10:13] - target) < 0.002)
+        assert_same_bits(S[1:-1, 1:-1], ref_out[1:-1, 1:-1], "IL.apply block")

@@ -224,3 +224,46 @@ def test_many_realizations_statistics_against_the_reference_script():
     out = harness.statistics(rs, ideal)
     assert np.isnan(g["nanpix"][7]) and np.isnan(g["nanpix"][2]) and not np.isnan(g["nanpix"][4])
     harness_check(out, g, "oracle")
+
+
+@pytest.mark.parametrize("name", list(gc.IL_CASES))
+def test_inverse_linearity_and_il_apply(name):
+    """oracle.linearity.invlinearity / il_apply against the reference's ipc_linearity.invlinearity and IL.apply."""
+    g = load_golden(name)
+    with np.errstate(all="ignore"):
+        sl = (slice(4, -4), slice(4, -4))
+        S, ex = linearity.invlinearity(g["counts"], g["coefs"][(slice(None),) + sl], g["Smin"][sl], g["Smax"][sl])
+        assert_same_bits(S, g["inv_S"], "invlinearity")
+        assert_same_bits(ex.astype(np.uint8), g["inv_ex"], "exflag")
+        args = (g["K"], g["gain"], g["coefs"], g["Smin"], g["Smax"], g["Sref"])
+        assert_same_bits(linearity.il_apply(g["counts"], *args), g["apply_dn"], "IL.apply DN -> DN")
+        assert_same_bits(linearity.il_apply(g["counts"], *args, electrons=True), g["apply_e_in"], "IL.apply e -> DN")
+        assert_same_bits(linearity.il_apply(g["counts"], *args, start_e=g["start_e"], electrons=True, electrons_out=True),
+                         g["apply_e_both"], "IL.apply e -> e")
+        assert_same_bits(linearity.il_apply(g["counts"], None, *args[1:], start_e=25.0, electrons_out=True),
+                         g["apply_noipc"], "IL.apply without IPC")
+    # the bisection ends inside the well: out-of-range targets saturate at the ends of [Smin, Smax]
+    lo, hi = np.minimum(g["Smin"][sl], g["Smax"][sl]), np.maximum(g["Smin"][sl], g["Smax"][sl])
+    assert np.all((g["inv_S"] >= lo - 1) & (g["inv_S"] <= hi + 1))
+
+
+def il_example_inputs(g):
+    """The two count images of the reference's il_example (test_workflow.py:409-420) on the fixture's block."""
+    y0, x0 = (int(v) for v in g["block_origin"])
+    ny, nx = g["gain"].shape
+    ne1 = np.zeros((ny, nx), np.float32)
+    ne2 = np.zeros((ny, nx), np.float32)
+    yy, xx = np.mgrid[y0:y0 + ny, x0:x0 + nx]
+    ne2[(yy % 3 == 0) & (xx % 3 == 0)] = 2.0e3
+    return ne1, ne2
+
+
+def test_il_known_answers_of_the_reference_workflow_test():
+    """The reference's own literals for IL.apply (test_workflow.py:402-407, tolerance 0.002 as there) and the reference
+    class's output on the surrounding block, bit for bit (one pixel in from the block's edge: the IPC footprint)."""
+    g = load_golden("il_example")
+    for ne, target, ref_out in zip(il_example_inputs(g), (g["target1"], g["target2"]), (g["ref_out1"], g["ref_out2"])):
+        conv = ipc.ipc_fwd(ne + 0.0, g["K"])
+        S, _ = linearity.invlinearity(conv / g["gain"], g["coefs"], g["Smin"], g["Smax"])
+        assert np.all(np.abs(S[10:12, 10:13] - target) < 0.002)
+        assert_same_bits(S[1:-1, 1:-1], ref_out[1:-1, 1:-1], "IL.apply block")

@@ -366,6 +366,84 @@ def case_post():
     save("post_sky", **out)
 
 
+def case_il():
+    """Inverse linearity and IL.apply with the reference's own ipc_linearity.py (ipc_linearity.py:347-513)."""
+    for name, (seed, p, kdt, cdt) in gc.IL_CASES.items():
+        c = gc.il_case(seed, p, kdt, cdt)
+        lin = register(f"/mem/{name}_lin.asdf", {"data": c["coefs"], "Smin": c["Smin"], "Smax": c["Smax"], "Sref": c["Sref"],
+                                                 "dq": c["lin_dq"]})
+        gain = register(f"/mem/{name}_gain.asdf", {"data": c["gain"]})
+        ipc = register(f"/mem/{name}_ipc.asdf", {"data": c["K"]})
+        out = {}
+        with np.errstate(all="ignore"):
+            S, ex = ref_il.invlinearity(c["counts"], lin, origin=(4, 4))
+            out["inv_S"], out["inv_ex"] = S, ex.astype(np.uint8)
+            out["apply_dn"] = ref_il.IL(lin, gain, ipc).apply(c["counts"])
+            out["apply_e_in"] = ref_il.IL(lin, gain, ipc).apply(c["counts"], electrons=True)
+            out["apply_e_both"] = ref_il.IL(lin, gain, ipc, start_e=c["start_e"]).apply(c["counts"], electrons=True, electrons_out=True)
+            out["apply_noipc"] = ref_il.IL(lin, gain, None, start_e=25.0).apply(c["counts"], electrons_out=True)
+            il = ref_il.IL(lin, gain, ipc)
+            il.set_dq(ngroup=3)
+            out["il_dq"] = il.dq
+        save(name, **c, **out)
+
+
+def case_il_example():
+    """The reference's known-answer test of the IL class (tests/romanimpreprocess/test_workflow.py:382-422: two literal
+    2 x 3 arrays) on the reference's own synthetic CALDIR.  `gencal` (:117-332, RandomState(1000), numpy only) and
+    `il_example` are taken from the test file with `ast` at run time and executed as they stand, with
+    asdf.AsdfFile(tree).write_to(path) keeping the trees in memory.  The fixture keeps the blocks of the calibration arrays
+    around the pixels the test looks at, the literals, and what the reference's IL class returns there."""
+    import ast
+
+    path = "/root/reference/tests/romanimpreprocess/test_workflow.py"
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name in ("_trim", "gencal", "il_example"))
+            or isinstance(n, ast.Assign)]
+    mod = ast.Module(body=keep, type_ignores=[])
+
+    class _AF:
+        def __init__(self, tr):
+            self.tr = tr
+
+        def write_to(self, path_):
+            _STORE[path_] = self.tr
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+    sys.modules["asdf"].AsdfFile = _AF
+    captured = {}
+
+    class _ILSpy(ref_il.IL):   # the reference's class, recording what apply returns
+        def apply(self, counts, **kw):
+            out = super().apply(counts, **kw)
+            captured.setdefault("outs", []).append(np.array(out[250:272, 130:153]))
+            return out
+
+    spy = types.SimpleNamespace(**{k: getattr(ref_il, k) for k in dir(ref_il) if not k.startswith("__")})
+    spy.IL = _ILSpy
+    ns = {"np": np, "asdf": sys.modules["asdf"], "pixel": sys.modules["roman_datamodels.dqflags"].pixel,
+          "ipc_linearity": spy, "os": os}
+    exec(compile(mod, path, "exec"), ns)
+    ns["gencal"]("/mem/kat", np.random.RandomState(1000))
+    files = {k: next(p_ for p_ in _STORE if p_.startswith("/mem/kat_" + k + "_")) for k in ("linearitylegendre", "gain", "ipc4d")}
+    ns["il_example"](files["linearitylegendre"], files["gain"], files["ipc4d"])   # the reference's own assertions pass
+    targets = [np.array(ast.literal_eval(n.value.args[0]))
+               for f in keep if isinstance(f, ast.FunctionDef) and f.name == "il_example"
+               for n in f.body if isinstance(n, ast.Assign) and ast.unparse(n.targets[0]) in ("target1", "target2")]
+    lin = _STORE[files["linearitylegendre"]]["roman"]
+    ya, xa = slice(250, 272), slice(130, 153)          # active-region block; the test reads [260:262, 140:143]
+    yf, xf = slice(254, 276), slice(134, 157)          # the same block in full-frame coordinates (border 4)
+    save("il_example", coefs=np.array(lin["data"][:, yf, xf]), Smin=np.array(lin["Smin"][yf, xf]),
+         Smax=np.array(lin["Smax"][yf, xf]), gain=np.array(_STORE[files["gain"]]["roman"]["data"][yf, xf]),
+         K=np.array(_STORE[files["ipc4d"]]["roman"]["data"][:, :, ya, xa]), block_origin=np.array([250, 130]),
+         target1=targets[0], target2=targets[1], ref_out1=captured["outs"][0], ref_out2=captured["outs"][1])
+
+
 def case_harness():
     """Statistics over many realisations: the reference's validation_tests/many_realizations.py is EXECUTED as it stands
     (read from /root/reference at run time) with its simulation and calibration calls replaced by stand-ins that put the
@@ -455,7 +533,7 @@ def case_harness():
 CASES = {
     "lin_known_answer": case_lin_known_answer, "multilin": case_multilin, "ipc": case_ipc,
     "weights": case_weights, "rampfit": case_rampfit, "flat": case_flat, "refpix": case_refpix,
-    "chain": case_chain, "post": case_post, "harness": case_harness,
+    "chain": case_chain, "post": case_post, "harness": case_harness, "il": case_il, "il_example": case_il_example,
 }
 
 if __name__ == "__main__":
