@@ -155,6 +155,10 @@ const char *rip_last_error(const rip_ctx *ctx); /* ctx may be NULL: message of t
 int rip_synchronize(rip_ctx *ctx);
 /* the HIP stream all work of this ctx is enqueued on (hipStream_t as void*) */
 void *rip_stream(rip_ctx *ctx);
+/* page-locked host memory for arrays handed to the library with location RIP_HOST (the reference's numpy arrays are
+   pageable; buffers from here are copied at PCIe rate).  NULL on failure (rip_last_error). */
+void *rip_host_alloc(rip_ctx *ctx, size_t bytes);
+void rip_host_free(rip_ctx *ctx, void *p);
 
 /* CALDIR: replaces the per-call asdf.open(caldir[...]) of the reference with device-resident
    copies (plus the per-SCA constants derived from them: IPC-deconvolved dark rate

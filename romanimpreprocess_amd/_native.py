@@ -78,6 +78,8 @@ SYMBOLS = {
     "rip_last_error": (C.c_char_p, [_VP]),
     "rip_synchronize": (_I, [_VP]),
     "rip_stream": (_VP, [_VP]),
+    "rip_host_alloc": (_VP, [_VP, C.c_size_t]),
+    "rip_host_free": (None, [_VP, _VP]),
     "rip_caldir_upload": (_I, [_VP, _I, C.POINTER(CaldirDesc)]),
     "rip_caldir_drop": (_I, [_VP, _I]),
     "rip_plan_create": (_I, [_VP, C.POINTER(PlanDesc), C.POINTER(_I)]),
@@ -187,6 +189,19 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.rip_synchronize(self.h))
+
+    def pinned_empty(self, shape, dtype):
+        """A numpy array in page-locked host memory (``rip_host_alloc``), freed with the array."""
+        import weakref
+
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.rip_host_alloc(self.h, nbytes)
+        if not p:
+            self.check(-2, MemoryError)
+        buf = (C.c_ubyte * max(nbytes, 1)).from_address(p)
+        arr = np.frombuffer(buf, dtype=np.uint8, count=nbytes).view(dtype).reshape(shape)
+        weakref.finalize(buf, self.lib.rip_host_free, self.h, p).atexit = False   # at exit the process returns it
+        return arr
 
     def set_option(self, name, value):
         self.check(self.lib.rip_set_option(self.h, name.encode(), int(value)))

@@ -158,6 +158,20 @@ int rip_synchronize(rip_ctx *ctx) {
 
 void *rip_stream(rip_ctx *ctx) { return (void *)ctx->stream; }
 
+// page-locked host memory for the caller's arrays: copies from / to it run at PCIe rate and asynchronously
+void *rip_host_alloc(rip_ctx *ctx, size_t bytes) {
+    void *p = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)rip_fail(ctx, RIP_ENOMEM, "rip_host_alloc: %zu bytes of page-locked memory", bytes);
+        return nullptr;
+    }
+    return p;
+}
+void rip_host_free(rip_ctx *ctx, void *p) {
+    (void)ctx;
+    if (p) (void)hipHostFree(p);
+}
+
 void rip_set_guard_band(double rel) { rip_guard_band = rel; }
 
 int rip_set_option(rip_ctx *ctx, const char *name, int value) {

@@ -46,7 +46,7 @@ class Calibrator:
     # ---- host arrays in, host arrays out --------------------------------------------------
     def calibrate(self, slot, ramp, exclude_first=True, ramp_opt_pars=None, jump_pars=None, area_factor=None,
                   stages=STAGE_ALL, want_groupdq=True, want_cube=False, channel_lines=None, flag_saturation=False,
-                  saturation_backup=1, saturation_skip_firstn=1):
+                  saturation_backup=1, saturation_skip_firstn=1, out=None):
         """Run the chain on one ramp given as numpy arrays.
 
         ``ramp``: dict(data u16|f32 (G,ny,nx), amp33 u16 (G,ny,128)|None, groupdq u8, pixeldq u32,
@@ -54,6 +54,10 @@ class Calibrator:
 
         ``flag_saturation``: dq-init + saturation flagging on the device before the chain (the CALDIR slot must hold
         ``saturation``); ``ramp["groupdq"]`` may then be None and ``ramp["pixeldq"]`` is the mask dq.
+
+        ``out``: optional dict of preallocated C-contiguous result arrays (any of slope, err_read, err_poisson f32 (ny,nx),
+        pixeldq u32 (ny,nx), groupdq u8 (G,ny,nx), cube f32 (G,ny,nx)) that are filled instead of new ones.  With page-locked
+        arrays (``Calibrator.pinned_empty``) on both sides the copies run at PCIe rate (tools/gpu_checks/host_path_timing.py).
         """
         ny, nx = self.shapes[slot]
         pid, meta = self.plan_for(ramp["read_pattern"], ramp["frame_time"], exclude_first, ramp_opt_pars, jump_pars)
@@ -65,8 +69,9 @@ class Calibrator:
             raise ValueError(f"ramp shape {data.shape} does not match the CALDIR frame {(ny, nx)}")
         gdq = None
         if ramp.get("groupdq") is not None:
-            gdq = np.array(ramp["groupdq"], dtype=np.uint8, order="C", copy=True)
-            if exclude_first:
+            gdq = np.ascontiguousarray(ramp["groupdq"], dtype=np.uint8)
+            if exclude_first and not np.all(gdq[0] & np.uint8(1)):
+                gdq = gdq.copy()  # the caller's array stays as it is
                 gdq[0] |= np.uint8(1)  # gen_cal_image.py:142-143
         elif not flag_saturation:
             raise ValueError("ramp['groupdq'] is required unless flag_saturation is set")
@@ -85,19 +90,29 @@ class Calibrator:
         rd.area_factor = None if area is None else area.ctypes.data
         rd.channel_lines = None if lines is None else lines.ctypes.data
 
+        given = out
+
+        def result(name, shape, dtype):
+            a = None if given is None else given.get(name)
+            if a is None:
+                return np.empty(shape, dtype)
+            if a.shape != shape or a.dtype != dtype or not a.flags.c_contiguous:
+                raise ValueError(f"out[{name!r}] must be a C-contiguous {np.dtype(dtype).name} array of shape {shape}")
+            return a
+
         res = {
-            "slope": np.empty((ny, nx), np.float32), "err_read": np.empty((ny, nx), np.float32),
-            "err_poisson": np.empty((ny, nx), np.float32), "pixeldq": np.empty((ny, nx), np.uint32),
+            "slope": result("slope", (ny, nx), np.float32), "err_read": result("err_read", (ny, nx), np.float32),
+            "err_poisson": result("err_poisson", (ny, nx), np.float32), "pixeldq": result("pixeldq", (ny, nx), np.uint32),
         }
         out = _native.Outputs()
         out.location = _native.RIP_HOST
         out.slope, out.err_read = res["slope"].ctypes.data, res["err_read"].ctypes.data
         out.err_poisson, out.pixeldq = res["err_poisson"].ctypes.data, res["pixeldq"].ctypes.data
         if want_groupdq:
-            res["groupdq"] = np.empty((G, ny, nx), np.uint8)
+            res["groupdq"] = result("groupdq", (G, ny, nx), np.uint8)
             out.groupdq = res["groupdq"].ctypes.data
         if want_cube:
-            res["cube"] = np.empty((G, ny, nx), np.float32)
+            res["cube"] = result("cube", (G, ny, nx), np.float32)
             out.cube = res["cube"].ctypes.data
         self.ctx.calibrate_raw(slot, pid, stages, rd, out)
         if not (stages & STAGE_RAMPFIT):
@@ -124,6 +139,10 @@ class Calibrator:
         out.slope, out.err_read, out.err_poisson = slope_ptr, err_read_ptr, err_poisson_ptr
         out.pixeldq, out.groupdq = pixeldq_out_ptr, groupdq_out_ptr
         self.ctx.calibrate_raw(slot, plan_id, stages, rd, out)
+
+    def pinned_empty(self, shape, dtype):
+        """A page-locked numpy array: host buffers the library copies from / to at PCIe rate."""
+        return self.ctx.pinned_empty(shape, dtype)
 
     def synchronize(self):
         self.ctx.synchronize()

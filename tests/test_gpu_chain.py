@@ -354,3 +354,26 @@ def test_full_frame_4096x4096x8_vs_oracle_and_between_forms():
         ctx.set_option("fused", 1)
         ctx.set_option("chain2", 1)
         cb.ctx.drop_caldir(6)
+
+
+def test_preallocated_and_page_locked_host_arrays():
+    """``out=`` fills the caller's arrays; page-locked arrays from the library behave like any numpy array."""
+    rp = synth.READ_PATTERN_8
+    ny, nx = 40, 256
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=3, seed=3)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=4, cr_frac=0.02)
+    cb = pipeline.Calibrator(ctx=gpu_context())
+    cb.load_caldir(7, cal)
+    ref = cb.calibrate(7, ramp)
+    pinned = {k: cb.pinned_empty(v.shape, v.dtype) for k, v in ramp.items() if isinstance(v, np.ndarray)}
+    for k, v in pinned.items():
+        v[...] = ramp[k]
+    out = {k: cb.pinned_empty(ref[k].shape, ref[k].dtype) for k in ("slope", "err_read", "err_poisson", "pixeldq", "groupdq")}
+    got = cb.calibrate(7, dict(ramp, **pinned), out=out)
+    for k in out:
+        assert got[k] is out[k]
+        assert_same_bits(out[k], ref[k], k)
+    assert not (ramp["groupdq"][0] & 1).all()   # the caller's groupdq is not modified by the DO_NOT_USE of the first group
+    with pytest.raises(ValueError):
+        cb.calibrate(7, ramp, out={"slope": np.empty((ny, nx), np.float64)})
+    cb.ctx.drop_caldir(7)
