@@ -373,7 +373,13 @@ def test_preallocated_and_page_locked_host_arrays():
     for k in out:
         assert got[k] is out[k]
         assert_same_bits(out[k], ref[k], k)
-    assert not (ramp["groupdq"][0] & 1).all()   # the caller's groupdq is not modified by the DO_NOT_USE of the first group
+    # a groupdq without DO_NOT_USE on the first group: the library sets it on its own copy, the caller's array stays
+    bare = ramp["groupdq"].copy()
+    bare[0] &= np.uint8(0xFE)
+    keep = bare.copy()
+    got2 = cb.calibrate(7, dict(ramp, groupdq=bare))
+    assert np.array_equal(bare, keep)
+    assert_same_bits(got2["slope"], ref["slope"], "slope (first group flagged by the library)")
     with pytest.raises(ValueError):
         cb.calibrate(7, ramp, out={"slope": np.empty((ny, nx), np.float64)})
     cb.ctx.drop_caldir(7)
