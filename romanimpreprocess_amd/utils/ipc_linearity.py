@@ -1,5 +1,5 @@
 """IPC and linearity on the GPU -- same call surface as the reference's ``utils/ipc_linearity.py``
-(``ipc_fwd`` :37, ``ipc_rev`` :102, ``correct_cube`` :145, ``multilin`` :276) and, from the simulation side
+(``ipc_fwd`` :37, ``ipc_rev`` :102, ``correct_cube`` :145, ``linearity`` :234, ``multilin`` :276) and, from the simulation side
 (SURVEY.md 8f row 4), the inverse linearity ``invlinearity`` :347 and the ``IL`` class :397 that romanisim calls.
 """
 
@@ -95,6 +95,29 @@ def multilin(S, linearity_file, origin=(0, 0), do_not_flag_first=True, attempt_c
         sref.ctypes.data, dq0.ctypes.data, int(bool(do_not_flag_first)), None if ac is None else ac.ctypes.data,
         phi.ctypes.data, dq.ctypes.data))
     return phi, dq
+
+
+def linearity(S, linearity_file, origin=(0, 0), ctx=None):
+    """Linearity correction of one 2-D image (``ipc_linearity.py:234-273``): the Legendre series with linear extrapolation
+    at every pixel (no substitution at flagged pixels, no clipping); dq = file dq | NO_LIN_CORR where extrapolated."""
+    ctx = ctx or _native.default_context()
+    S = np.ascontiguousarray(S, dtype=np.float32)
+    dy, dx = S.shape
+    y0, x0 = origin[1], origin[0]
+    sl = (slice(y0, y0 + dy), slice(x0, x0 + dx))
+    with calio.open_tree(linearity_file) as F:
+        r = F["roman"]
+        smin = np.ascontiguousarray(r["Smin"][sl], dtype=np.float32)
+        smax = np.ascontiguousarray(r["Smax"][sl], dtype=np.float32)
+        dq0 = np.array(r["dq"][sl], dtype=np.uint32)
+        coefs = np.ascontiguousarray(r["data"][(slice(None),) + sl], dtype=np.float32)
+    nodq = np.zeros((dy, dx), np.uint32)   # the cube entry substitutes S - Sref where the file's dq says so: not here
+    phi = np.empty((1, dy, dx), np.float32)
+    dq = np.empty((dy, dx), np.uint32)
+    ctx.check(ctx.lib.rip_stage_multilin(
+        ctx.h, S.ctypes.data, 1, dy, dx, coefs.shape[0], coefs.ctypes.data, smin.ctypes.data, smax.ctypes.data,
+        smin.ctypes.data, nodq.ctypes.data, 0, None, phi.ctypes.data, dq.ctypes.data))
+    return phi[0], dq0 | dq
 
 
 def invlinearity(Slin, linearity_file, origin=(0, 0), ctx=None):

@@ -213,3 +213,14 @@ def test_il_known_answers_of_the_reference_workflow_test():
         S, _ = ipc_linearity.invlinearity(conv / g["gain"], lin, ctx=ctx)
         assert np.all(np.abs(S[10:12, 10:13] - target) < 0.002)
         assert_same_bits(S[1:-1, 1:-1], ref_out[1:-1, 1:-1], "IL.apply block")
+
+
+@pytest.mark.parametrize("name", list(gc.IL_CASES))
+def test_linearity_of_one_image(name):
+    """ipc_linearity.linearity (:234-273) on a sub-block with an origin, against the reference's output."""
+    g = load_golden(name)
+    lin = {"data": g["coefs"], "Smin": g["Smin"], "Smax": g["Smax"], "Sref": g["Sref"], "dq": g["lin_dq"]}
+    phi, dq = ipc_linearity.linearity(g["raw"], lin, origin=(3, 6), ctx=gpu_context())
+    assert_same_bits(phi, g["lin_phi"], "linearity phi")
+    assert_same_bits(dq, g["lin_out_dq"], "linearity dq")
+    assert np.count_nonzero(dq & (1 << 20)) > 10

@@ -232,6 +232,11 @@ def test_inverse_linearity_and_il_apply(name):
     g = load_golden(name)
     with np.errstate(all="ignore"):
         sl = (slice(4, -4), slice(4, -4))
+        blk = (slice(6, 40), slice(3, 60))
+        z = -1 + 2 * (g["raw"] - g["Smin"][blk]) / (g["Smax"][blk] - g["Smin"][blk])
+        phi, exf = linearity.legendre_series(z, g["coefs"][(slice(None),) + blk])
+        assert_same_bits(phi, g["lin_phi"], "linearity (one image)")
+        assert_same_bits(g["lin_dq"][blk] | np.where(exf, np.uint32(2**20), np.uint32(0)), g["lin_out_dq"], "linearity dq")
         S, ex = linearity.invlinearity(g["counts"], g["coefs"][(slice(None),) + sl], g["Smin"][sl], g["Smax"][sl])
         assert_same_bits(S, g["inv_S"], "invlinearity")
         assert_same_bits(ex.astype(np.uint8), g["inv_ex"], "exflag")

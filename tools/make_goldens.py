@@ -376,6 +376,9 @@ def case_il():
         ipc = register(f"/mem/{name}_ipc.asdf", {"data": c["K"]})
         out = {}
         with np.errstate(all="ignore"):
+            raw = (c["Smin"] + (c["Smax"] - c["Smin"]) * np.linspace(-0.05, 1.05, c["Smin"].size).reshape(c["Smin"].shape)).astype(np.float32)
+            out["raw"] = raw[6:40, 3:60].copy()
+            out["lin_phi"], out["lin_dq"] = ref_il.linearity(out["raw"], lin, origin=(3, 6))
             S, ex = ref_il.invlinearity(c["counts"], lin, origin=(4, 4))
             out["inv_S"], out["inv_ex"] = S, ex.astype(np.uint8)
             out["apply_dn"] = ref_il.IL(lin, gain, ipc).apply(c["counts"])
@@ -385,6 +388,7 @@ def case_il():
             il = ref_il.IL(lin, gain, ipc)
             il.set_dq(ngroup=3)
             out["il_dq"] = il.dq
+        out["lin_out_dq"] = out.pop("lin_dq")
         save(name, **c, **out)
 
 
