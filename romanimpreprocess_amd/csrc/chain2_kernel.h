@@ -54,18 +54,49 @@ __device__ __forceinline__ unsigned c2_opaque(unsigned x) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t c2_rsrc(const void *p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
 }
+// Cache policy of the loads (experiment, off by default): every array but the IPC coefficients is read exactly once per
+// ramp, so those loads can carry the non-temporal hint (aux bit 1 = nt on gfx940+); the coefficients are read twice, one row
+// step apart (ingest role for C, fit role for O2), and the first read stays a normal one so that the second finds the lines
+// in L2.  Measured (profiles/r01_summary.md, item 8): HBM reads -8 %, kernel time +11 % -- the hint costs more than the
+// traffic it saves, so C2_NT* default to 0.
+#ifndef C2_NT
+#define C2_NT 0
+#endif
+#ifndef C2_NT_G   // per-group arrays of the ingest role: cube, groupdq, dark, bias
+#define C2_NT_G C2_NT
+#endif
+#ifndef C2_NT_C   // coefficient-type planes of the ingest role
+#define C2_NT_C C2_NT
+#endif
+#ifndef C2_NT_F   // loads of the fit role (second read of the IPC coefficients, tail planes)
+#define C2_NT_F C2_NT
+#endif
+template <int AUX = C2_NT>
 __device__ __forceinline__ float c2_ld_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
 }
+template <int AUX = C2_NT>
+__device__ __forceinline__ double c2_ld_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
+}
+template <int AUX = C2_NT>
 __device__ __forceinline__ uint32_t c2_ld_u32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX);
 }
+template <int AUX = C2_NT>
 __device__ __forceinline__ uint32_t c2_ld_u16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+    return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, AUX);
 }
+template <int AUX = C2_NT>
 __device__ __forceinline__ uint32_t c2_ld_u8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
+    return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, AUX);
 }
+struct C2Keep {   // first of two reads: keep the line
+    static constexpr int value = 0;
+};
+struct C2Last {   // last read of the line
+    static constexpr int value = C2_NT_F;
+};
 
 // The kernel arguments re-read from the kernarg segment (scalar loads from the constant address space) through a
 // pointer made opaque once per phase: the ~25 pointers and sizes of ChainArgs then live in scalar registers only
@@ -183,7 +214,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
 
     // coefficient loader: raw loads at clamped source positions + validity mask for destination (y, c);
     // `want` is wave-uniform.  Planes are walked in memory order (plane = 3*(1+dy) + (1+dx)).
-    auto load_k = [&](const void *kern_base, int y, bool want, f2 (&kk2)[5]) -> unsigned {
+    auto load_k = [&](auto pol, const void *kern_base, int y, bool want, f2 (&kk2)[5]) -> unsigned {
         if (dbg & 128) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) kk2[k] = f2{(k == 0) ? 1.0f : 0.001f, 0.001f};
@@ -208,7 +239,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             // 6 (1,-1), 7 (-1,1), 8 (-1,-1)
             const int k = (dy == 0) ? (dx == 0 ? 0 : dx == 1 ? 3 : 4) : (dy == 1) ? (dx == 0 ? 1 : dx == 1 ? 5 : 6)
                                                                                   : (dx == 0 ? 2 : dx == 1 ? 7 : 8);
-            const float kv_ = c2_ld_f32(kr, cx4[dx + 1], pofs + rowoff[dy + 1]);
+            const float kv_ = c2_ld_f32<decltype(pol)::value>(kr, cx4[dx + 1], pofs + rowoff[dy + 1]);
             if (k & 1)
                 kk2[k / 2].y = kv_;
             else
@@ -220,7 +251,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
     };
 
     // f64 coefficients: the same walk with 8-byte loads, nine scalars in the reference's term order
-    auto load_kd = [&](const void *kern_base, int y, bool want, double (&kk)[9]) -> unsigned {
+    auto load_kd = [&](auto pol, const void *kern_base, int y, bool want, double (&kk)[9]) -> unsigned {
         unsigned rowoff[3];
         bool rok[3];
 #pragma unroll
@@ -237,7 +268,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             const int dy = p / 3 - 1, dx = p % 3 - 1;
             const int k = (dy == 0) ? (dx == 0 ? 0 : dx == 1 ? 3 : 4) : (dy == 1) ? (dx == 0 ? 1 : dx == 1 ? 5 : 6)
                                                                                   : (dx == 0 ? 2 : dx == 1 ? 7 : 8);
-            kk[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(kr, cx4[dx + 1] * 2u, pofs + rowoff[dy + 1], 0));
+            kk[k] = c2_ld_f64<decltype(pol)::value>(kr, cx4[dx + 1] * 2u, pofs + rowoff[dy + 1]);
             pofs += pl4 * 2u;
         }
         const unsigned um = (want && y >= ay0 && y < ay1) ? rowbits : 0u;
@@ -280,10 +311,10 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                      o1 = yl * (row4 >> 2) + (unsigned)g0 * npix;
 #pragma unroll
             for (int g = g0; g < g1; ++g) {
-                rr.S[g] = c2_ld_u16(rs, cc2, o2);
-                rr.q[g] = c2_ld_u8(rq, cc1, o1);
-                rr.dk[g] = c2_ld_f32(rd, cc4, o4);
-                rr.bs[g] = c2_ld_f32(rb, cc4, o4);
+                rr.S[g] = c2_ld_u16<C2_NT_G>(rs, cc2, o2);
+                rr.q[g] = c2_ld_u8<C2_NT_G>(rq, cc1, o1);
+                rr.dk[g] = c2_ld_f32<C2_NT_G>(rd, cc4, o4);
+                rr.bs[g] = c2_ld_f32<C2_NT_G>(rb, cc4, o4);
                 o4 += pl4;
                 o2 += pl4 >> 1;
                 o1 += npix;
@@ -300,17 +331,17 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
 #pragma unroll
             for (int i = i0; i < i1; ++i) {
                 if (i < NP)
-                    rr.cf[i] = c2_ld_f32(rp, cc4, o4);
+                    rr.cf[i] = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
                 else if (i == NP)
-                    rr.smin = c2_ld_f32(rp, cc4, o4);
+                    rr.smin = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
                 else if (i == NP + 1)
-                    rr.smax = c2_ld_f32(rp, cc4, o4);
+                    rr.smax = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
                 else if (i == NP + 2)
-                    rr.sref = c2_ld_f32(rp, cc4, o4);
+                    rr.sref = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
                 else if (i == NP + 3)
-                    rr.dq = c2_ld_u32(rp, cc4, o4);
+                    rr.dq = c2_ld_u32<C2_NT_C>(rp, cc4, o4);
                 else
-                    rr.gain = c2_ld_f32(rp, cc4, o4);
+                    rr.gain = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
                 o4 += pl4;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -499,9 +530,9 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             kC[4].y = 0.0f;
             unsigned vC;
             if constexpr (K64)
-                vC = load_kd(ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kCd);
+                vC = load_kd(C2Keep{}, ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kCd);
             else
-                vC = load_k(ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
+                vC = load_k(C2Keep{}, ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
             CH_T(2)
             C2_SYNC();
             CH_T(3)
@@ -587,19 +618,19 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             // ---- S1: read noise of the pixel (used by the fit), then the second IPC iterate of row r
             const __amdgpu_buffer_rsrc_t rpl = c2_rsrc(kf->a.planes);
             const unsigned t_row = rc_ * row4;  // byte offset of row r in an f32 plane (uniform)
-            const float e_read = c2_ld_f32(rpl, cc4, (unsigned)(NP + 5) * pl4 + t_row);
+            const float e_read = c2_ld_f32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 5) * pl4 + t_row);
             const float e_gain = gain_next;
             // calibration planes of the tail (finish) of the same pixel, consumed after the barrier
             const size_t t_row4 = (size_t)t_row;
             const size_t pe_row = (size_t)(rc_ * (unsigned)nx);   // element offset of row r
-            const float e_dark = c2_ld_f32(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_row);
-            const uint32_t e_ff = c2_ld_u32(rpl, cc4, (unsigned)(NP + 8) * pl4 + t_row);
-            const uint32_t e_pdq = c2_ld_u32(c2_rsrc(kf->a.pdq), cc4, t_row);
+            const float e_dark = c2_ld_f32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_row);
+            const uint32_t e_ff = c2_ld_u32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 8) * pl4 + t_row);
+            const uint32_t e_pdq = c2_ld_u32<C2_NT_F>(c2_rsrc(kf->a.pdq), cc4, t_row);
             // flat / dark_dq == null: read the first slab plane instead (value unused), keeps the loads in one block
-            const float e_flat_raw = c2_ld_f32(c2_rsrc(kf->a.flat ? (const void *)kf->a.flat : (const void *)kf->a.planes), cc4, t_row);
+            const float e_flat_raw = c2_ld_f32<C2_NT_F>(c2_rsrc(kf->a.flat ? (const void *)kf->a.flat : (const void *)kf->a.planes), cc4, t_row);
             const float e_flat = kf->a.flat ? e_flat_raw : 1.0f;
             const uint32_t e_ddq_raw =
-                c2_ld_u32(c2_rsrc(kf->a.dark_dq ? (const void *)kf->a.dark_dq : (const void *)kf->a.planes), cc4, t_row);
+                c2_ld_u32<C2_NT_F>(c2_rsrc(kf->a.dark_dq ? (const void *)kf->a.dark_dq : (const void *)kf->a.planes), cc4, t_row);
             const uint32_t e_ddq = kf->a.dark_dq ? e_ddq_raw : 0u;
             float d[G];
             f2 dpair[GP];
@@ -721,10 +752,10 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             const bool next_on = (r + 1 >= R0) && (r + 1 < R1) && col >= 2 && col < C2_COLS - 2;
             unsigned vN;
             if constexpr (K64)
-                vN = load_kd(kg->a.kern, r + 1, next_on, kNd);
+                vN = load_kd(C2Last{}, kg->a.kern, r + 1, next_on, kNd);
             else
-                vN = load_k(kg->a.kern, r + 1, next_on, kN);
-            gain_next = c2_ld_f32(c2_rsrc(kg->a.planes), cc4, (unsigned)(NP + 4) * pl4 + (unsigned)min(max(r + 1, 0), ny - 1) * row4);
+                vN = load_k(C2Last{}, kg->a.kern, r + 1, next_on, kN);
+            gain_next = c2_ld_f32<C2_NT_F>(c2_rsrc(kg->a.planes), cc4, (unsigned)(NP + 4) * pl4 + (unsigned)min(max(r + 1, 0), ny - 1) * row4);
             CH_T(4)
             C2_DRAIN()
             CH_T(5)
