@@ -10,10 +10,13 @@ What runs where
     or ``.npz`` mirrors -- see ``calio``);
   * steps whose source is NOT in the reference tree are restated from their call sites and documented
     behaviour (parity unpinned): dq-init (:118, mask -> pixeldq, zero groupdq), saturation flagging
-    (:148-185, see ``flag_saturation``), and the L2 tree layout of ``romanisim.image.make_asdf`` (:653-662).
-  * not done here (outside the hot path): sky estimate / SKYORDER subtraction, WCS->gwcs and the
-    pixel-area map (pass ``AREAFACTOR``: file with an (N,N) f64 array, else 1), dark decay, WFI18 transient,
-    romancal likelihood ramp fit, FITS output.  Asking for one of those raises NotImplementedError.
+    (:148-185, on the device: ``rip_ramp_desc::flag_saturation``; its numpy restatement is ``oracle/saturation.py``), and
+    the L2 tree layout of ``romanisim.image.make_asdf`` (:653-662);
+  * the post-path reductions (:632-651, 697-712: median gain, sky mode, SKYORDER model, SLICEOUT) -> ``utils/sky.py``,
+    ``utils/maskhandling.py`` (HIP kernels);
+  * not done here (outside the hot path): WCS->gwcs and the pixel-area map (pass ``AREAFACTOR``: file with
+    an (N,N) f64 array, else 1), dark decay, WFI18 transient, romancal likelihood ramp fit, FITS output.  Asking for one
+    of those raises NotImplementedError.
 """
 
 import sys
@@ -49,45 +52,6 @@ def initializationstep(config, caldir, mylog):
     if config.get("EXCLUDE_FIRST", True):
         groupdq[0] |= np.uint8(group.DO_NOT_USE)
     return {"data": data, "amp33": amp33, "groupdq": groupdq, "pixeldq": pixeldq, "meta": l1meta}, meta
-
-
-def flag_saturation(ramp, sat_threshold, backup=1, skip_firstn=1, n_pix_grow_sat=1, sat_dq=None):
-    """Saturation flags (restatement of the call at gen_cal_image.py:172-185; stcal's source is not available:
-    PARITY UNPINNED).  A resultant of group g >= skip_firstn is SATURATED where data >= threshold; the flag is
-    grown by ``n_pix_grow_sat`` pixels (3x3 box for 1), is sticky for all later groups, and is also set on the
-    ``backup`` preceding groups (but never on the first ``skip_firstn`` ones).  Pixels whose threshold is NaN or
-    flagged NO_SAT_CHECK are not checked.  pixeldq receives SATURATED where any group is flagged."""
-    data, gdq, pdq = ramp["data"], ramp["groupdq"], ramp["pixeldq"]
-    G = data.shape[0]
-    thr = np.array(sat_threshold, dtype=np.float32)
-    nocheck = ~np.isfinite(thr)
-    if sat_dq is not None:
-        nocheck |= (np.asarray(sat_dq) & np.uint32(pixel.NO_SAT_CHECK)) != 0
-    sat = np.zeros(data.shape, dtype=bool)
-    for g in range(skip_firstn, G):
-        s = (data[g] >= thr) & ~nocheck
-        for _ in range(n_pix_grow_sat):
-            grown = s.copy()
-            grown[1:, :] |= s[:-1, :]
-            grown[:-1, :] |= s[1:, :]
-            s = grown.copy()
-            s[:, 1:] |= grown[:, :-1]
-            s[:, :-1] |= grown[:, 1:]
-        sat[g] = s
-    for g in range(skip_firstn + 1, G):
-        sat[g] |= sat[g - 1]
-    for _ in range(int(backup)):
-        for g in range(skip_firstn, G - 1):
-            sat[g] |= sat[g + 1]
-    gdq |= np.where(sat, np.uint8(group.SATURATED), np.uint8(0))
-    pdq |= np.where(sat.any(axis=0), np.uint32(pixel.SATURATED), np.uint32(0))
-
-
-def saturation_check(ramp, caldir, mylog, backup=1, skip_firstn=1):
-    with calio.open_tree(caldir["saturation"]) as f:
-        r = f["roman"]
-        flag_saturation(ramp, np.asarray(r["data"]), backup=backup, skip_firstn=skip_firstn, n_pix_grow_sat=1,
-                        sat_dq=np.asarray(r["dq"]) if "dq" in r else None)
 
 
 def load_caldir_arrays(caldir):
@@ -131,12 +95,11 @@ def calibrateimage(config, verbose=True, calibrator=None):
 
     cb = calibrator or pipeline.Calibrator()
     slot = _caldir_slot(cb, caldir)
-    # saturation flagging: on the device, inside the calibrate call (config SATURATION_ON_HOST = true keeps the numpy
-    # restatement above)
-    sat_on_device = "saturation" in caldir and not config.get("SATURATION_ON_HOST", False)
-    if not sat_on_device:
-        saturation_check(ramp, caldir, mylog, backup=backup)
-    mylog.append("Saturation check " + ("on the device\n" if sat_on_device else "complete\n"))
+    # saturation flagging (gen_cal_image.py:148-185): on the device, inside the calibrate call
+    if "saturation" not in caldir:
+        raise KeyError("saturation")  # the reference opens caldir["saturation"] unconditionally (:174)
+    sat_on_device = True
+    mylog.append("Saturation check on the device\n")
     exclude_first = config.get("EXCLUDE_FIRST", True)
     area = None
     if "AREAFACTOR" in config:

@@ -5,6 +5,7 @@ import pytest
 from conftest import assert_same_bits, gpu_context
 
 import oracle
+from oracle import saturation
 from romanimpreprocess_amd import pipeline, synth
 
 pytestmark = pytest.mark.gpu
@@ -169,7 +170,7 @@ def test_calibrateimage_files_end_to_end(tmp_path):
     r0 = {"data": ramp["data"], "amp33": ramp["amp33"], "groupdq": np.zeros(ramp["data"].shape, np.uint8),
           "pixeldq": cal["mask"]["dq"].copy(), "read_pattern": rp, "frame_time": synth.FRAME_TIME}
     r0["groupdq"][0] |= 1
-    gen_cal_image.flag_saturation(r0, cal["saturation"]["data"], backup=1, skip_firstn=1, sat_dq=cal["saturation"]["dq"])
+    saturation.flag_saturation(r0, cal["saturation"]["data"], backup=1, skip_firstn=1, sat_dq=cal["saturation"]["dq"])
     ref = oracle.calibrate_arrays(r0, cal, jump_pars=config["JUMP_DETECT_PARS"])
     act = (slice(4, -4), slice(4, -4))
     assert_same_bits(out["roman"]["dq"], ref["pixeldq"][act], "L2 dq")
@@ -281,10 +282,9 @@ def test_fused_forms_agree_across_seams(kdt):
 
 def test_saturation_flagging_on_device_matches_host_restatement():
     """dq-init + saturation flagging inside rip_calibrate against the numpy restatement
-    L1_to_L2.gen_cal_image.flag_saturation (parity unpinned: stcal's source is not in the reference tree): identical
+    oracle.saturation.flag_saturation (parity unpinned: stcal's source is not in the reference tree): identical
     flags, hence identical chain outputs.  Thresholds lowered so that many pixels saturate at different groups; some
     pixels are NO_SAT_CHECK / NaN-threshold."""
-    from romanimpreprocess_amd.L1_to_L2 import gen_cal_image as gci
     from romanimpreprocess_amd.dqflags import pixel
 
     rp = synth.READ_PATTERN_8
@@ -303,7 +303,7 @@ def test_saturation_flagging_on_device_matches_host_restatement():
     for backup in (1, 2, 0):
         # host restatement
         h = {"data": ramp["data"], "groupdq": np.zeros(ramp["data"].shape, np.uint8), "pixeldq": mask.copy()}
-        gci.flag_saturation(h, thr, backup=backup, skip_firstn=1, n_pix_grow_sat=1, sat_dq=sdq)
+        saturation.flag_saturation(h, thr, backup=backup, skip_firstn=1, n_pix_grow_sat=1, sat_dq=sdq)
         assert 50 < np.count_nonzero(h["groupdq"][-1] & 2) < 0.5 * ny * nx
         cb = pipeline.Calibrator(ctx=gpu_context())
         cb.load_caldir(6, cal)

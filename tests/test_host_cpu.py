@@ -124,7 +124,7 @@ def test_asdf_and_npz_round_trip(tmp_path):
 
 
 def test_flag_saturation_semantics():
-    from romanimpreprocess_amd.L1_to_L2.gen_cal_image import flag_saturation
+    from oracle.saturation import flag_saturation
     G, n = 6, 9
     data = np.zeros((G, n, n), np.float32)
     data[3:, 4, 4] = 100.0       # saturates from group 3 on
