@@ -20,6 +20,8 @@ def scatter_items(items, device="cpu"):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return list(items)
     rank, world = dist.get_rank(), dist.get_world_size()
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     n = torch.tensor([len(items) if rank == 0 else 0], dtype=torch.int64, device=device)
     dist.broadcast(n, src=0)
     buf = (torch.tensor(list(items), dtype=torch.int32, device=device) if rank == 0
@@ -32,6 +34,17 @@ def _world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def _all_to_all(recv, send, out_split, in_split):
+    """``all_to_all_single`` on 1-D tensors.  RCCL moves device tensors directly (xGMI); the gloo backend (CPU tests,
+    rehearsals of several ranks on one GPU) only takes host tensors, so device tensors are staged through the host."""
+    if dist.get_backend() == "gloo" and send.is_cuda:
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r, send.cpu(), out_split, in_split)
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv, send, out_split, in_split)
 
 
 def row_bounds(ny, world):
@@ -56,7 +69,7 @@ def seeds_to_rows(stack, nseeds):
     in_split = [counts[rank] * (b[q + 1] - b[q]) * nx for q in range(world)]
     out_split = [counts[s] * nrows * nx for s in range(world)]
     recv = torch.empty(sum(out_split), dtype=stack.dtype, device=stack.device)
-    dist.all_to_all_single(recv, send, out_split, in_split)
+    _all_to_all(recv, send, out_split, in_split)
     del send
     out = torch.empty((nseeds, nrows, nx), dtype=stack.dtype, device=stack.device)
     off = 0
@@ -76,7 +89,7 @@ def gather_rows(planes, ny):
     in_split = [planes.numel()] + [0] * (world - 1)
     out_split = [P * (b[s + 1] - b[s]) * nx if rank == 0 else 0 for s in range(world)]
     recv = torch.empty(sum(out_split), dtype=planes.dtype, device=planes.device)
-    dist.all_to_all_single(recv, planes.reshape(-1).contiguous(), out_split, in_split)
+    _all_to_all(recv, planes.reshape(-1).contiguous(), out_split, in_split)
     if rank != 0:
         return None
     out = torch.empty((P, ny, nx), dtype=planes.dtype, device=planes.device)
