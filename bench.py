@@ -61,6 +61,44 @@ def cpu_baseline(cal, ramp, target_s=7.0):
                       f"({frac:.4f} ramp) through the numpy oracle, {dt:.1f} s, single thread"}
 
 
+def _replica_worker(args):
+    """One process of the replica run: its own strip of a seeded synthetic ramp through the numpy oracle."""
+    rows, groups, seed, p_order, ipc64, barrier = args
+    import numpy as _np
+
+    import oracle
+    from romanimpreprocess_amd import synth
+
+    rp = synth.READ_PATTERN_8 if groups == 8 else synth.READ_PATTERN_16
+    cal = synth.make_caldir(rows + 8, 4096, read_pattern=rp, p_order=p_order, seed=1000 + seed,
+                            ipc_dtype=_np.float64 if ipc64 else _np.float32)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=seed)
+    barrier.wait()
+    t0 = time.perf_counter()
+    oracle.calibrate_arrays(ramp, cal)
+    return time.perf_counter() - t0
+
+
+def cpu_replicas(rows, groups, p_order, ipc64, max_procs=16):
+    """The same oracle as independent single-thread processes, one strip each, started together: ramps/s of C host cores
+    (numpy's elementwise work does not thread, so this is what the host can do with the reference's kind of code)."""
+    import multiprocessing as mp
+
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = max(1, min(max_procs, ncpu))
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as man:
+        barrier = man.Barrier(procs)
+        with ctx.Pool(procs) as pool:
+            t0 = time.perf_counter()
+            dts = pool.map(_replica_worker, [(rows, groups, 100 + i, p_order, ipc64, barrier) for i in range(procs)])
+            wall = time.perf_counter() - t0
+    frac = procs * (rows + 8) / 4096.0
+    return {"value": frac / max(dts), "unit": "ramps/s", "cores": procs,
+            "sample": f"{procs} processes x {rows + 8} rows of 4096 ({frac:.3f} ramp in all), slowest {max(dts):.1f} s "
+                      f"(wall incl. generating the strips {wall:.1f} s)"}
+
+
 def _cpu_strip(cal, ramp, rows):
     import oracle
 
@@ -227,6 +265,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cal, ramp)
+            if N == 4096:
+                out["cpu_baseline"]["replicas"] = cpu_replicas(248, G, p_order, args.ipc_dtype == "f64")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
