@@ -175,6 +175,15 @@ int rip_plan_destroy(rip_ctx *ctx, int plan_id);
 int rip_calibrate(rip_ctx *ctx, int sca_slot, int plan_id, unsigned stages, const rip_ramp_desc *in,
                   const rip_outputs *out);
 
+/* A batch of n ramps in HOST memory through the same chain, pipelined over PCIe: upload of ramp i+1, chain of ramp i and
+   download of ramp i-1 overlap (three streams, two sets of device buffers); results equal those of n single calls.  What a
+   batch driver (runs/summer2025run/OpenUniverse_to_L1L2.py:123-137: every SCA of an exposure) hands its arrays to.  All
+   ramps share the CALDIR slot, the plan, the group count and the data dtype; location must be RIP_HOST in every
+   descriptor; the stage mask must include the ramp fit; outputs::cube is not available here.  Page-locked arrays
+   (rip_host_alloc) make the copies run at PCIe rate in both directions at once.  Returns when everything has arrived. */
+int rip_calibrate_batch(rip_ctx *ctx, int sca_slot, int plan_id, unsigned stages, int n, const rip_ramp_desc *in,
+                        const rip_outputs *out);
+
 /* ---- stage-level entry points (host arrays; for function-level drop-in and parity tests) ----- */
 
 /* reference_subtraction.ref_subtraction_row(image, use_ref_channel=True, slope) followed by

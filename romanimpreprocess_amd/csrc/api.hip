@@ -120,6 +120,7 @@ int rip_ctx_create(int device_id, rip_ctx **out) {
         return rip_fail(nullptr, RIP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) ctx->stream2 = nullptr;
+    if (hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess) ctx->stream3 = nullptr;
     for (int i = 0; i < 2 && ctx->stream2; ++i)
         if (hipEventCreateWithFlags(&ctx->ev_tab[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming) != hipSuccess) {
@@ -142,6 +143,12 @@ void rip_ctx_destroy(rip_ctx *ctx) {
         }
     for (int i = 0; i < 10; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    for (void *p : ctx->batch_buf)
+        if (p) (void)hipFree(p);
+    if (ctx->stream3) {
+        (void)hipStreamSynchronize(ctx->stream3);
+        (void)hipStreamDestroy(ctx->stream3);
+    }
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2);

@@ -132,6 +132,10 @@ struct rip_ctx {
     std::vector<hipEvent_t> prof_events;  // 6 per rip_calibrate call
     void *ws[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t ws_bytes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // rip_calibrate_batch (batch.hip): download stream and the two sets of device buffers, kept between calls
+    hipStream_t stream3 = nullptr;
+    void *batch_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t batch_bytes[4] = {0, 0, 0, 0};
 };
 
 // ---------------------------------------------------------------- host helpers

@@ -122,6 +122,72 @@ class Calibrator:
         res["K"], res["meta"] = meta["K"], meta
         return res
 
+    # ---- a batch of ramps in host memory, pipelined over PCIe --------------------------------
+    def calibrate_many(self, slot, ramps, exclude_first=True, ramp_opt_pars=None, jump_pars=None, want_groupdq=False,
+                       flag_saturation=False, saturation_backup=1, saturation_skip_firstn=1, out=None):
+        """Run the whole chain on a list of ramps (dicts as for ``calibrate``; same read pattern, frame time and data
+        dtype) with ``rip_calibrate_batch``: upload, chain and download of consecutive ramps overlap.  ``out``: optional
+        list of dicts of preallocated result arrays (see ``calibrate``).  Returns the list of result dicts.  Page-locked
+        arrays (``pinned_empty``) on both sides give the full PCIe rate."""
+        ramps = list(ramps)
+        if not ramps:
+            return []
+        ny, nx = self.shapes[slot]
+        pid, meta = self.plan_for(ramps[0]["read_pattern"], ramps[0]["frame_time"], exclude_first, ramp_opt_pars, jump_pars)
+        n = len(ramps)
+        descs, outs, results, keep = (_native.RampDesc * n)(), (_native.Outputs * n)(), [], []
+        for i, ramp in enumerate(ramps):
+            if list(map(list, ramp["read_pattern"])) != list(map(list, ramps[0]["read_pattern"])):
+                raise ValueError(f"ramp {i}: read pattern differs from ramp 0")
+            data = np.ascontiguousarray(ramp["data"])
+            if data.dtype not in (np.uint16, np.float32):
+                data = data.astype(np.float32)
+            G = data.shape[0]
+            if data.shape != (G, ny, nx):
+                raise ValueError(f"ramp {i}: shape {data.shape} does not match the CALDIR frame {(ny, nx)}")
+            gdq = None
+            if ramp.get("groupdq") is not None:
+                gdq = np.ascontiguousarray(ramp["groupdq"], dtype=np.uint8)
+                if exclude_first and not np.all(gdq[0] & np.uint8(1)):
+                    gdq = gdq.copy()
+                    gdq[0] |= np.uint8(1)  # gen_cal_image.py:142-143
+            elif not flag_saturation:
+                raise ValueError(f"ramp {i}: groupdq is required unless flag_saturation is set")
+            pdq = np.ascontiguousarray(ramp["pixeldq"], dtype=np.uint32)
+            amp33 = None if ramp.get("amp33") is None else np.ascontiguousarray(ramp["amp33"], dtype=np.uint16)
+            keep.append((data, gdq, pdq, amp33))
+            rd = descs[i]
+            rd.location, rd.ngrp = _native.RIP_HOST, G
+            rd.data, rd.data_dtype = data.ctypes.data, _native.dtype_code(data)
+            rd.amp33 = None if amp33 is None else amp33.ctypes.data
+            rd.groupdq, rd.pixeldq = (None if gdq is None else gdq.ctypes.data), pdq.ctypes.data
+            rd.flag_saturation = 1 if flag_saturation else 0
+            rd.sat_backup, rd.sat_skip_firstn = int(saturation_backup), int(saturation_skip_firstn)
+            given = None if out is None else out[i]
+
+            def result(name, shape, dtype, given=given):
+                a = None if given is None else given.get(name)
+                if a is None:
+                    return np.empty(shape, dtype)
+                if a.shape != shape or a.dtype != dtype or not a.flags.c_contiguous:
+                    raise ValueError(f"out[{i}][{name!r}] must be a C-contiguous {np.dtype(dtype).name} array of shape {shape}")
+                return a
+
+            res = {"slope": result("slope", (ny, nx), np.float32), "err_read": result("err_read", (ny, nx), np.float32),
+                   "err_poisson": result("err_poisson", (ny, nx), np.float32), "pixeldq": result("pixeldq", (ny, nx), np.uint32)}
+            od = outs[i]
+            od.location = _native.RIP_HOST
+            od.slope, od.err_read = res["slope"].ctypes.data, res["err_read"].ctypes.data
+            od.err_poisson, od.pixeldq = res["err_poisson"].ctypes.data, res["pixeldq"].ctypes.data
+            if want_groupdq:
+                res["groupdq"] = result("groupdq", (G, ny, nx), np.uint8)
+                od.groupdq = res["groupdq"].ctypes.data
+            res["K"], res["meta"] = meta["K"], meta
+            results.append(res)
+        self.ctx.check(self.ctx.lib.rip_calibrate_batch(self.ctx.h, int(slot), int(pid), int(STAGE_ALL), n, descs, outs))
+        del keep
+        return results
+
     # ---- device pointers in, device pointers out (asynchronous) ---------------------------
     def calibrate_device(self, slot, plan_id, ngrp, data_ptr, data_is_u16, amp33_ptr, groupdq_ptr, pixeldq_ptr,
                          slope_ptr, err_read_ptr, err_poisson_ptr, pixeldq_out_ptr, groupdq_out_ptr=None,

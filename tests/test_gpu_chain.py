@@ -415,3 +415,30 @@ def test_unusual_group_counts_vs_oracle(name, rp, exclude_first):
     for k in ("slope", "err_read", "err_poisson"):
         assert_same_bits(got[k], ref[k], k, zero_sign_ok=True)
     cb.ctx.drop_caldir(8)
+
+
+@pytest.mark.parametrize("flag_sat", [False, True])
+def test_batch_of_host_ramps_equals_single_calls(flag_sat):
+    """rip_calibrate_batch (upload / chain / download of consecutive ramps overlapped) against one call per ramp."""
+    rp = synth.READ_PATTERN_8
+    ny, nx = 72, 256
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=41, bias_amplitude=2.0)
+    cb = pipeline.Calibrator(ctx=gpu_context())
+    cb.load_caldir(2, cal)
+    ramps = []
+    for i in range(5):
+        r = synth.make_ramp(cal, read_pattern=rp, seed=50 + i, cr_frac=0.02)
+        if flag_sat:
+            r["groupdq"] = None
+            r["pixeldq"] = cal["mask"]["dq"].copy()
+        ramps.append(r)
+    singles = [cb.calibrate(2, r, flag_saturation=flag_sat) for r in ramps]
+    pinned_out = [{k: cb.pinned_empty((ny, nx), np.float32) for k in ("slope", "err_read", "err_poisson")} for _ in ramps]
+    many = cb.calibrate_many(2, ramps, want_groupdq=True, flag_saturation=flag_sat, out=pinned_out)
+    assert len(many) == len(ramps)
+    for i, (a, b) in enumerate(zip(many, singles)):
+        assert a["slope"] is pinned_out[i]["slope"]
+        for k in ("slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
+            assert_same_bits(a[k], b[k], f"ramp {i}: {k}")
+    assert cb.calibrate_many(2, []) == []
+    cb.ctx.drop_caldir(2)

@@ -42,3 +42,15 @@ for want_gdq in (True, False):
         ts.append(time.perf_counter() - t0)
     print(f"calibrate(page-locked arrays, want_groupdq={want_gdq}): best {min(ts)*1e3:.1f} ms, median {sorted(ts)[len(ts)//2]*1e3:.1f} ms  -> {1/min(ts):.1f} ramps/s")
 assert np.array_equal(res2["slope"], res["slope"], equal_nan=True) and np.array_equal(res2["pixeldq"], res["pixeldq"])
+
+# a batch of page-locked ramps through rip_calibrate_batch (upload / chain / download overlapped)
+nb_ = 8
+outs = [out] + [{k: cb.pinned_empty(v.shape, v.dtype) for k, v in out.items()} for _ in range(nb_ - 1)]
+for want_gdq in (True, False):
+    ts = []
+    for i in range(3):
+        t0 = time.perf_counter()
+        many = cb.calibrate_many(0, [ramp_p] * nb_, want_groupdq=want_gdq, out=outs)
+        ts.append((time.perf_counter() - t0) / nb_)
+    print(f"calibrate_many({nb_} page-locked ramps, want_groupdq={want_gdq}): best {min(ts)*1e3:.1f} ms per ramp -> {1/min(ts):.1f} ramps/s")
+assert np.array_equal(many[-1]["slope"], res["slope"], equal_nan=True) and np.array_equal(many[3]["pixeldq"], res["pixeldq"])
