@@ -256,6 +256,15 @@ int rip_stage_legendre2d(rip_ctx *ctx, float *arr, int ny, int nx, int order, co
 int rip_stage_invlinearity(rip_ctx *ctx, const void *slin, int dtype, int ny, int nx, int nplanes, const float *coefs,
                            const float *smin, const float *smax, void *S, uint8_t *exflag);
 
+/* ---- noise layers ---------------------------------------------------- */
+/* gen_noise_image.make_noise_cube, read-noise injection (gen_noise_image.py:120-134): per group k and active pixel
+   data' = u16(rint(clip(f32(data) + f32(f64(normal) * (f64(read) / sqrt(f64(N_k)))), 0, 65535))); border pixels unchanged.
+   cube, out (ngrp,ny,nx) u16; read_noise (ny,nx) f32; nreads[ngrp]; normals (ngrp,ny-2nb,nx-2nb) f32 standard normal
+   deviates from the caller, or NULL: drawn on the device from a counter-based generator keyed by (seed, layer, group,
+   pixel).  Host arrays.  Exact given the normals. */
+int rip_stage_noise_inject(rip_ctx *ctx, const uint16_t *cube, int ngrp, int ny, int nx, int nb, const float *read_noise,
+                           const int32_t *nreads, const float *normals, uint64_t seed, uint32_t layer, uint16_t *out);
+
 /* ---- statistics over many noise realisations of one ramp -- DEVICE pointers, asynchronous ------- */
 /* Replaces the per-pixel arithmetic of validation_tests/many_realizations.py:57-106 on stacks (nseeds, rows, nx) that stay
    in HBM (256 realisations of a 4096 x 4096 SCA: 56 GB).  All results are exact (f32 operations in the reference's order,

@@ -67,10 +67,12 @@ def load_caldir_arrays(caldir):
 
 def _caldir_slot(cb, caldir):
     key = (id(cb.ctx), tuple(sorted((k, str(v)) for k, v in caldir.items() if isinstance(v, str))))
-    if key in _cal_cache:
-        return _cal_cache[key]
-    slot = len(_cal_cache) % 32
-    cb.load_caldir(slot, load_caldir_arrays(caldir))
+    slot = _cal_cache.get(key)
+    if slot is not None and cb.slot_owner(slot) == key:   # still ours (an explicit load_caldir may have reused the slot)
+        return slot
+    if slot is None:
+        slot = 31 - len(_cal_cache) % 24   # from the top: low slot numbers are left to explicit load_caldir calls
+    cb.load_caldir(slot, load_caldir_arrays(caldir), owner=key)
     _cal_cache[key] = slot
     return slot
 

@@ -1,0 +1,147 @@
+"""Noise layers -- same entry points and configuration surface as the reference's ``L1_to_L2/gen_noise_image.py``
+(``make_noise_cube`` :60, ``generate_all_noise`` :334, CLI :392-400); SURVEY.md 8f row 3.
+
+A layer re-runs the whole L1 -> L2 chain on a noise-injected copy of the Level-1 cube and keeps the difference of the
+two slope images.  What runs where
+  * both chain runs: ``calibrateimage`` of this package (HIP kernels);
+  * the injection of white read noise into the cube (``:120-134``): ``rip_stage_noise_inject`` (HIP kernel; exact given the
+    normal deviates);
+  * clipping (``z``) and sky-mode removal (``S``): ``utils/sky.py`` (HIP kernels).
+Random numbers.  The reference draws from ``galsim`` generators, which are not available offline and whose streams cannot be
+reproduced; here ``rng`` may be ``None`` / an integer seed (deviates drawn ON THE DEVICE from a counter-based generator:
+reproducible, no host random numbers) or a ``numpy.random.Generator`` (deviates drawn on the host in the reference's order
+and handed to the kernel).  Layers are therefore statistically, not bit-wise, comparable with the reference's.
+Not built: the correlated part of a read-noise layer (``sim_to_isim.fill_in_refdata_and_1f``: fresh reference pixels,
+reference output and 1/f noise -- the reference pixels of the input are kept), the resampled-Poisson layers (``P..r``) and the
+pseudo-Poisson layers (``O``); asking for them raises NotImplementedError.
+"""
+
+import re
+import sys
+from copy import deepcopy
+
+import numpy as np
+
+from .. import _native, calio, pars
+from ..utils import sky
+from .gen_cal_image import calibrateimage
+
+
+def _get_subscript(arr, ch):
+    """The subscript of directive ``ch``: what follows it up to the next capital letter
+    (``_get_subscript('RS2Pg4', 'S') -> '2'``, ``('RS2Pg4', 'P') -> 'g4'``; gen_noise_image.py:32-57)."""
+    return re.split(r"(?=[A-Z])", arr.split(ch)[-1])[0]
+
+
+def inject_read_noise(data, read_noise, read_pattern, nb=pars.nborder, normals=None, seed=0, layer=0, ctx=None):
+    """White read noise into a u16 cube (gen_noise_image.py:120-134).  ``normals`` (ngrp, ny-2nb, nx-2nb) f32 or None
+    (drawn on the device from ``seed``, ``layer``)."""
+    ctx = ctx or _native.default_context()
+    data = np.ascontiguousarray(data)
+    if data.dtype != np.uint16:
+        raise TypeError(f"the Level-1 cube is {data.dtype}, expected uint16")
+    G, ny, nx = data.shape
+    read = np.ascontiguousarray(read_noise, dtype=np.float32)
+    nreads = np.array([len(g) for g in read_pattern], dtype=np.int32)
+    if normals is not None:
+        normals = np.ascontiguousarray(normals, dtype=np.float32)
+        if normals.shape != (G, ny - 2 * nb, nx - 2 * nb):
+            raise ValueError(f"normals have shape {normals.shape}")
+    out = np.empty_like(data)
+    ctx.check(ctx.lib.rip_stage_noise_inject(ctx.h, data.ctypes.data, G, ny, nx, nb, read.ctypes.data, nreads.ctypes.data,
+                                             None if normals is None else normals.ctypes.data, int(seed) & (2**64 - 1),
+                                             int(layer), out.ctypes.data))
+    return out
+
+
+def make_noise_cube(config, rng=None):
+    """The noise realisations listed in ``config["NOISE"]["LAYER"]``: array (N_noise, ny_active, nx_active) f32."""
+    layers = config["NOISE"]["LAYER"]
+    host_rng = rng if isinstance(rng, np.random.Generator) else None
+    seed = config["NOISE"].get("SEED", 0) if (rng is None or host_rng is not None) else int(rng)
+    nb = pars.nborder
+    noiseimage = None
+    for i_noise, cmd in enumerate(layers):
+        with calio.open_tree(config["IN"]) as f_in:
+            mytree = deepcopy(calio._materialise(f_in if isinstance(f_in, dict) else dict(f_in)))
+        with calio.open_tree(config["OUT"]) as f_orig:
+            diff = np.zeros_like(np.asarray(f_orig["roman"]["data"]))
+        if noiseimage is None:
+            noiseimage = np.zeros((len(layers),) + diff.shape, dtype=np.float32)
+        read_pattern = mytree["roman"]["meta"]["exposure"]["read_pattern"]
+
+        if "R" in cmd:
+            noiseflags = _get_subscript(cmd, "R")
+            origfile = config["OUT"]
+            if "a" not in noiseflags:  # start from the dark instead of the data
+                with calio.open_tree(config["CALDIR"]["dark"]) as fb:
+                    dark = np.asarray(fb["roman"]["data"])
+                    de = dark.shape[0] - np.shape(mytree["roman"]["data"])[0]
+                    if de not in [0, 1]:
+                        raise ValueError("Dark date cube has the wrong shape.")
+                    mytree["roman"]["data"] = dark.astype(mytree["roman"]["data"].dtype)[de:, :, :]
+                calio.write_asdf(config["NOISE"]["TEMP"], mytree)
+                config3 = deepcopy(config)
+                config3["IN"] = config["NOISE"]["TEMP"]
+                config3["OUT"] = config["NOISE"]["TEMP"][:-5] + "_refL2.asdf"
+                calibrateimage(config3)
+                origfile = config3["OUT"]
+            with calio.open_tree(config["CALDIR"]["read"]) as fr:
+                read = np.asarray(fr["roman"]["data"], dtype=np.float32)
+            data = np.ascontiguousarray(mytree["roman"]["data"])
+            normals = None
+            if host_rng is not None:  # one draw per group, in the reference's order
+                na = (data.shape[1] - 2 * nb, data.shape[2] - 2 * nb)
+                normals = np.stack([host_rng.standard_normal(na, dtype=np.float32) for _ in range(data.shape[0])])
+            mytree["roman"]["data"] = inject_read_noise(data, read, read_pattern, nb=nb, normals=normals, seed=seed,
+                                                        layer=i_noise)
+            # (the reference regenerates reference pixels, reference output and 1/f noise here: not built)
+            calio.write_asdf(config["NOISE"]["TEMP"], mytree)
+            config2 = deepcopy(config)
+            config2["IN"] = config["NOISE"]["TEMP"]
+            config2["OUT"] = config["NOISE"]["TEMP"][:-5] + "_L2.asdf"
+            calibrateimage(config2)
+            with calio.open_tree(config2["OUT"]) as f_out, calio.open_tree(origfile) as f_orig:
+                diff = np.asarray(f_out["roman"]["data"]) - np.asarray(f_orig["roman"]["data"])
+            if "z" in noiseflags:
+                zclip = float(_get_subscript(noiseflags.upper(), "Z"))
+                p25, med, p75 = sky.nanpercentiles(diff, [25.0, 50.0, 75.0])
+                iqr = p75 - p25
+                print("***", noiseflags, zclip, iqr, med)
+                diff = np.clip(diff, med - zclip * iqr / 1.34896, med + zclip * iqr / 1.34896)
+        if "O" in cmd:
+            raise NotImplementedError("pseudo-Poisson layers ('O': GalPoisson sampler) are not built")
+        if "P" in cmd and "r" in _get_subscript(cmd, "P"):
+            raise NotImplementedError("resampled-Poisson layers ('P..r') are not built")
+        if "S" in cmd:
+            sky_order = int("0" + _get_subscript(cmd, "S"))
+            diff = diff - sky.medfit(diff, order=sky_order)[1]
+        noiseimage[i_noise, :, :] = diff
+    return noiseimage
+
+
+def generate_all_noise(config):
+    """Driver (gen_noise_image.py:334-389): ``config["NOISE"]`` holds LAYER (list of directives), TEMP (scratch file), SEED
+    and OUT; the configuration must have been run through ``calibrateimage`` already."""
+    noiseimage = make_noise_cube(config, None)
+    print(np.shape(noiseimage))
+    print("percentiles:")
+    for q in [5, 25, 50, 75, 95]:
+        print(q, np.percentile(noiseimage, q, axis=(1, 2)))
+    if "NOISE_PRECISION" in config:
+        if config["NOISE_PRECISION"] == 16:
+            noiseimage = noiseimage.astype(np.float16)
+        if config["NOISE_PRECISION"] not in [16, 32]:
+            raise ValueError("Unsupported noise precision.")
+    calio.write_asdf(config["NOISE"]["OUT"], {"config": config, "noise": noiseimage})
+    if config.get("FITSOUT", False):
+        raise NotImplementedError("FITS output needs astropy")
+
+
+if __name__ == "__main__":
+    import yaml
+
+    with open(sys.argv[1]) as f:
+        cfg = yaml.safe_load(f)
+    calibrateimage(cfg | {"SLICEOUT": True})
+    generate_all_noise(cfg)

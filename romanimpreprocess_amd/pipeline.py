@@ -17,15 +17,21 @@ from ._native import (STAGE_ALL, STAGE_BIAS, STAGE_DARK, STAGE_FLAT, STAGE_IPC, 
 class Calibrator:
     def __init__(self, device=None, ctx=None):
         self.ctx = ctx if ctx is not None else _native.default_context(device)
-        self.shapes = {}
-        self._plans = {}
+        # CALDIR slots and plans belong to the context: every Calibrator on it sees them
+        self.shapes = self.ctx.__dict__.setdefault("_caldir_shapes", {})
+        self._plans = self.ctx.__dict__.setdefault("_plan_cache", {})
 
     # ---- CALDIR ---------------------------------------------------------------------------
-    def load_caldir(self, slot, cal, nborder=pars.nborder):
-        """Upload one SCA's calibration arrays (dict of dicts, ``roman`` branch layout) into ``slot``."""
+    def load_caldir(self, slot, cal, nborder=pars.nborder, owner=None):
+        """Upload one SCA's calibration arrays (dict of dicts, ``roman`` branch layout) into ``slot``.  ``owner``: tag kept
+        with the slot (``slot_owner``) so that a cache of file-based CALDIR sets can tell when its slot was reused."""
         rslope = planmod.refout_slope(cal["read"])
         self.shapes[slot] = self.ctx.upload_caldir(slot, cal, nborder=nborder, refout_slope=rslope)
+        self.ctx.__dict__.setdefault("_caldir_owner", {})[slot] = owner
         return self.shapes[slot]
+
+    def slot_owner(self, slot):
+        return self.ctx.__dict__.get("_caldir_owner", {}).get(slot)
 
     # ---- plans ----------------------------------------------------------------------------
     def plan_for(self, read_pattern, frame_time, exclude_first=True, ramp_opt_pars=None, jump_pars=None):

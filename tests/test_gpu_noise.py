@@ -1,0 +1,124 @@
+"""Noise layers: read-noise injection kernel and the gen_noise_image driver on the GPU chain."""
+
+import numpy as np
+import pytest
+from conftest import assert_same_bits, gpu_context
+
+from romanimpreprocess_amd import calio, pipeline, synth
+from romanimpreprocess_amd.L1_to_L2 import gen_cal_image, gen_noise_image
+
+pytestmark = pytest.mark.gpu
+
+
+def numpy_injection(data, read, read_pattern, normals, nb=4):
+    """gen_noise_image.py:120-134 as written there (numpy 2 promotion rules)."""
+    out = data.copy()
+    for k in range(len(read_pattern)):
+        resultants = out[k, nb:-nb, nb:-nb].astype(np.float32)
+        im = normals[k].copy()
+        im *= read[nb:-nb, nb:-nb] / np.sqrt(len(read_pattern[k]))
+        resultants += im
+        out[k, nb:-nb, nb:-nb] = np.round(np.clip(resultants, 0, 2**16 - 1)).astype(out.dtype)
+    return out
+
+
+def test_get_subscript():
+    assert gen_noise_image._get_subscript("RS2Pg4", "S") == "2"
+    assert gen_noise_image._get_subscript("RS2Pg4", "P") == "g4"
+    assert gen_noise_image._get_subscript("Raz3.5S1", "R") == "az3.5"
+
+
+def test_injection_is_exact_given_the_normals():
+    rng = np.random.default_rng(7)
+    rp = synth.READ_PATTERN_8
+    G, ny, nx = len(rp), 40, 200
+    data = rng.integers(0, 65536, size=(G, ny, nx), dtype=np.uint16)
+    data[:, 10, 10:14] = [0, 1, 65534, 65535]                 # clipping at both ends
+    read = (6 + 5 * rng.random((ny, nx))).astype(np.float32)
+    normals = rng.standard_normal((G, ny - 8, nx - 8)).astype(np.float32)
+    normals[:, 3, 3] = np.float32(0.5) / (read[7, 7] / np.sqrt(1.0)).astype(np.float32)   # a tie for round-half-even in group 0
+    got = gen_noise_image.inject_read_noise(data, read, rp, normals=normals, ctx=gpu_context())
+    assert_same_bits(got, numpy_injection(data, read, rp, normals), "injected cube")
+    assert np.array_equal(got[:, :4], data[:, :4]) and np.array_equal(got[:, :, -4:], data[:, :, -4:])
+
+
+def test_device_deviates_are_standard_normal_and_reproducible():
+    rp = synth.READ_PATTERN_8
+    G, ny, nx = len(rp), 264, 520
+    data = np.full((G, ny, nx), 30000, np.uint16)
+    read = np.full((ny, nx), 64.0, np.float32)                 # large sigma: rounding to integers does not matter
+    a = gen_noise_image.inject_read_noise(data, read, rp, seed=5, layer=0, ctx=gpu_context())
+    b = gen_noise_image.inject_read_noise(data, read, rp, seed=5, layer=0, ctx=gpu_context())
+    c = gen_noise_image.inject_read_noise(data, read, rp, seed=5, layer=1, ctx=gpu_context())
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    act = (slice(None), slice(4, -4), slice(4, -4))
+    for k in range(G):
+        z = (a[act][k].astype(np.float64) - 30000.0) / (64.0 / np.sqrt(len(rp[k])))
+        n = z.size
+        assert abs(z.mean()) < 5 / np.sqrt(n) + 0.02 and abs(z.std() - 1.0) < 0.02
+        assert abs(np.mean(z**3)) < 0.05 and abs(np.mean(z**4) - 3.0) < 0.1
+    # groups, layers and neighbouring pixels are uncorrelated
+    z0 = a[act][0].astype(np.float64) - 30000.0
+    z1 = a[act][1].astype(np.float64) - 30000.0
+    zc = c[act][0].astype(np.float64) - 30000.0
+    for u, v in ((z0, z1), (z0, zc), (z0[:, 1:], z0[:, :-1]), (z0[1:], z0[:-1])):
+        assert abs(np.corrcoef(u.ravel(), v.ravel())[0, 1]) < 0.01
+
+
+def _write_inputs(tmp_path, rp, ny, nx):
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=3, seed=31, bias_amplitude=1.0)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=32, cr_frac=0.0)
+    caldir = {}
+    names = {"dark": "dark", "read": "read", "gain": "gain", "linearitylegendre": "linearitylegendre", "ipc4d": "ipc4d",
+             "flat": "pflat", "biascorr": "biascorr", "mask": "mask", "saturation": "saturation"}
+    for key, fname in names.items():
+        path = tmp_path / f"roman_wfi_{fname}_TEST_SCA04.asdf"
+        calio.write_asdf(str(path), {"roman": cal[key]})
+        caldir[key] = str(path)
+    l1 = {"roman": {"data": ramp["data"], "amp33": ramp["amp33"],
+                    "meta": {"exposure": {"frame_time": synth.FRAME_TIME, "read_pattern": rp},
+                             "instrument": {"detector": "WFI04"}}}}
+    calio.write_asdf(str(tmp_path / "l1.asdf"), l1)
+    config = {"IN": str(tmp_path / "l1.asdf"), "OUT": str(tmp_path / "l2.asdf"), "CALDIR": caldir, "SLICEOUT": True,
+              "NOISE": {"LAYER": ["Ra", "R", "RaS2", "Raz2", "Ccomment"], "TEMP": str(tmp_path / "tmp.asdf"), "SEED": 11,
+                        "OUT": str(tmp_path / "noise.asdf")}, "NOISE_PRECISION": 32}
+    return cal, ramp, config
+
+
+def test_noise_layers_end_to_end(tmp_path):
+    """calibrateimage, then generate_all_noise: every layer is the difference of two chain runs; its scatter is the read
+    noise of the slope, the sky-mode layer has no low-order content, the clipped layer is bounded."""
+    rp = synth.READ_PATTERN_8
+    cal, ramp, config = _write_inputs(tmp_path, rp, 72, 256)
+    cb = pipeline.Calibrator(ctx=gpu_context())
+    gen_cal_image.calibrateimage(config, verbose=False, calibrator=cb)
+    gen_noise_image.generate_all_noise(config)
+    out = calio.read_asdf(config["NOISE"]["OUT"])
+    noise = np.asarray(out["noise"])
+    l2 = calio.read_asdf(config["OUT"])
+    assert noise.shape == (5,) + np.asarray(l2["roman"]["data"]).shape and noise.dtype == np.float32
+    good = np.asarray(l2["roman"]["dq"]) == 0
+    err_read = np.sqrt(np.asarray(l2["roman"]["var_rnoise"]))[good]
+    for i in (0, 1, 2):
+        ratio = np.std(noise[i][good]) / np.sqrt(np.mean(err_read**2))
+        assert 0.8 < ratio < 1.25, (i, ratio)          # an extra read-noise realisation: scatter = the read-noise error
+        assert abs(np.mean(noise[i][good])) < 5 * np.std(noise[i][good]) / np.sqrt(good.sum()) + 1e-3
+    assert not np.array_equal(noise[0], noise[1])
+    # 'S2': the quadratic sky model of the layer is gone
+    from romanimpreprocess_amd.utils import sky
+    coef, _ = sky.medfit(noise[2], order=2, ctx=gpu_context())
+    coef0, _ = sky.medfit(noise[0], order=2, ctx=gpu_context())
+    assert np.max(np.abs(coef)) < 0.2 * np.max(np.abs(coef0)) + 1e-4
+    # 'z2': clipped at 2 sigma-equivalents of the interquartile range
+    p25, med, p75 = np.percentile(noise[3], [25, 50, 75])
+    assert noise[3].max() - noise[3].min() < 2 * 2.2 * (p75 - p25) / 1.34896
+    assert np.count_nonzero(noise[4]) == 0               # a comment-only layer
+    # same seed, same layers
+    again = gen_noise_image.make_noise_cube(config)
+    assert_same_bits(again, noise, "layers from the same seed")
+    # host deviates in the reference's order give different, equally valid layers
+    other = gen_noise_image.make_noise_cube(dict(config, NOISE=dict(config["NOISE"], LAYER=["Ra"])), np.random.default_rng(3))
+    assert 0.8 < np.std(other[0][good]) / np.sqrt(np.mean(err_read**2)) < 1.25
+    for bad in ("Pr", "O"):
+        with pytest.raises(NotImplementedError):
+            gen_noise_image.make_noise_cube(dict(config, NOISE=dict(config["NOISE"], LAYER=[bad])))
