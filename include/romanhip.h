@@ -265,6 +265,19 @@ int rip_stage_invlinearity(rip_ctx *ctx, const void *slin, int dtype, int ny, in
 int rip_stage_noise_inject(rip_ctx *ctx, const uint16_t *cube, int ngrp, int ny, int nx, int nb, const float *read_noise,
                            const int32_t *nreads, const float *normals, uint64_t seed, uint32_t layer, uint16_t *out);
 
+/* gen_noise_image.make_noise_cube, resampled Poisson layer 'P..r' (gen_noise_image.py:262-331) on n pixels: electrons per frame
+   e = clip(skylevel * gain * frame_time, 0); for each read a Poisson deviate of mean e, re-centred, in DN, accumulated into the
+   change of every resultant (group j = reads group_first[j] .. + group_count[j] - 1), then diff += sum_j w[endslice][j] *
+   delta[j] with the weight vector of the ramp's end slice (weights (ngrp,ngrp) f32 row-major, has_weights[es] = 0 where the
+   reference has no vector; endslice (n) i8 already mapped as the reference does, <= 0 -> ngrp - 1).  samples (nsamp,n) f64
+   Poisson deviates from the caller, or NULL: drawn on the device (inversion / PTRS on Philox uniforms keyed by seed, layer,
+   read, pixel).  gain (n) f32 or f64, already clipped to [1e-4, 1e4].  Up to 16 groups.  Host arrays; diff in/out.
+   Exact given the deviates. */
+int rip_stage_poisson_resample(rip_ctx *ctx, const float *skylevel, const void *gain, int gain_dtype, size_t n,
+                               double frame_time, int ngrp, const int32_t *group_first, const int32_t *group_count,
+                               const float *weights, const uint8_t *has_weights, const int8_t *endslice,
+                               const double *samples, int nsamp, uint64_t seed, uint32_t layer, float *diff);
+
 /* ---- statistics over many noise realisations of one ramp -- DEVICE pointers, asynchronous ------- */
 /* Replaces the per-pixel arithmetic of validation_tests/many_realizations.py:57-106 on stacks (nseeds, rows, nx) that stay
    in HBM (256 realisations of a 4096 x 4096 SCA: 56 GB).  All results are exact (f32 operations in the reference's order,

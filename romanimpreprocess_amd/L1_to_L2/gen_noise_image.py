@@ -6,14 +6,17 @@ two slope images.  What runs where
   * both chain runs: ``calibrateimage`` of this package (HIP kernels);
   * the injection of white read noise into the cube (``:120-134``): ``rip_stage_noise_inject`` (HIP kernel; exact given the
     normal deviates);
-  * clipping (``z``) and sky-mode removal (``S``): ``utils/sky.py`` (HIP kernels).
+  * clipping (``z``) and sky-mode removal (``S``): ``utils/sky.py`` (HIP kernels);
 Random numbers.  The reference draws from ``galsim`` generators, which are not available offline and whose streams cannot be
 reproduced; here ``rng`` may be ``None`` / an integer seed (deviates drawn ON THE DEVICE from a counter-based generator:
 reproducible, no host random numbers) or a ``numpy.random.Generator`` (deviates drawn on the host in the reference's order
 and handed to the kernel).  Layers are therefore statistically, not bit-wise, comparable with the reference's.
+  * resampled Poisson layers (``P..r``, ``:262-331``): ``rip_stage_poisson_resample`` (HIP kernel: deviates, their
+    accumulation into the resultants and the ramp-fit weights of every pixel's end slice in one pass; exact given the
+    deviates).
 Not built: the correlated part of a read-noise layer (``sim_to_isim.fill_in_refdata_and_1f``: fresh reference pixels,
-reference output and 1/f noise -- the reference pixels of the input are kept), the resampled-Poisson layers (``P..r``) and the
-pseudo-Poisson layers (``O``); asking for them raises NotImplementedError.
+reference output and 1/f noise -- the reference pixels of the input are kept) and the pseudo-Poisson layers (``O``, the
+GalPoisson sampler); asking for ``O`` raises NotImplementedError.
 """
 
 import re
@@ -52,6 +55,59 @@ def inject_read_noise(data, read_noise, read_pattern, nb=pars.nborder, normals=N
                                              None if normals is None else normals.ctypes.data, int(seed) & (2**64 - 1),
                                              int(layer), out.ctypes.data))
     return out
+
+
+def ramp_weight_vectors(processinfo, ngrp):
+    """The weights the ramp fit applied to a pixel as a function of its end slice (gen_noise_image.py:236-252): the stored
+    optimal weights for a full ramp, the two-point weights for one truncated at ``iend``.  Returns (w (ngrp,ngrp) f32,
+    has (ngrp,) u8, endslice i8 with non-positive entries mapped to ngrp - 1)."""
+    meta = processinfo["meta"]
+    w = np.zeros((ngrp, ngrp), dtype=np.float32)
+    has = np.zeros(ngrp, dtype=np.uint8)
+    w[-1] = np.asarray(processinfo["weights"], dtype=np.float32)
+    has[-1] = 1
+    start = 1 if processinfo["exclude_first"] else 0
+    for iend in range(start + 2, ngrp):
+        Kt = np.zeros(ngrp, dtype=np.float32)
+        Kt[iend - 1] = 1.0 / (meta["tbar"][iend - 1] - meta["tbar"][start])
+        Kt[start] = -Kt[iend - 1]
+        w[iend - 1] = Kt
+        has[iend - 1] = 1
+    es = np.asarray(processinfo["endslice"])
+    endslice = np.where(es > 0, es, ngrp - 1).astype(np.int8)
+    return w, has, endslice
+
+
+def poisson_resample(diff, skylevel, gain, frame_time, read_pattern, weights, has_weights, endslice, samples=None, seed=0,
+                     layer=0, ctx=None):
+    """Adds a resampled-Poisson realisation to ``diff`` (f32, in place; gen_noise_image.py:262-331).  ``gain`` already
+    clipped; ``samples`` (nsamp, ny, nx) f64 Poisson deviates of mean clip(skylevel*gain*frame_time, 0) or None (device)."""
+    ctx = ctx or _native.default_context()
+    if not (isinstance(diff, np.ndarray) and diff.dtype == np.float32 and diff.flags.c_contiguous):
+        raise TypeError("diff must be a C-contiguous float32 array (updated in place)")
+    ngrp = len(read_pattern)
+    first = np.array([g[0] for g in read_pattern], dtype=np.int32)
+    count = np.array([len(g) for g in read_pattern], dtype=np.int32)
+    for g in read_pattern:
+        if list(g) != list(range(g[0], g[0] + len(g))):
+            raise ValueError("groups must hold consecutive reads")
+    nsamp = int(read_pattern[-1][-1]) + 1
+    sky_ = np.ascontiguousarray(skylevel, dtype=np.float32)
+    g_ = np.ascontiguousarray(gain)
+    if g_.dtype not in (np.float32, np.float64):
+        g_ = g_.astype(np.float64)
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    hw = np.ascontiguousarray(has_weights, dtype=np.uint8)
+    es = np.ascontiguousarray(endslice, dtype=np.int8)
+    if samples is not None:
+        samples = np.ascontiguousarray(samples, dtype=np.float64)
+        if samples.shape != (nsamp,) + diff.shape:
+            raise ValueError(f"samples have shape {samples.shape}, expected {(nsamp,) + diff.shape}")
+    ctx.check(ctx.lib.rip_stage_poisson_resample(
+        ctx.h, sky_.ctypes.data, g_.ctypes.data, _native.dtype_code(g_), diff.size, float(frame_time), ngrp, first.ctypes.data,
+        count.ctypes.data, w.ctypes.data, hw.ctypes.data, es.ctypes.data, None if samples is None else samples.ctypes.data,
+        nsamp, int(seed) & (2**64 - 1), int(layer), diff.ctypes.data))
+    return diff
 
 
 def make_noise_cube(config, rng=None):
@@ -111,8 +167,32 @@ def make_noise_cube(config, rng=None):
                 diff = np.clip(diff, med - zclip * iqr / 1.34896, med + zclip * iqr / 1.34896)
         if "O" in cmd:
             raise NotImplementedError("pseudo-Poisson layers ('O': GalPoisson sampler) are not built")
-        if "P" in cmd and "r" in _get_subscript(cmd, "P"):
-            raise NotImplementedError("resampled-Poisson layers ('P..r') are not built")
+        if "P" in cmd:
+            noiseflags = _get_subscript(cmd, "P")
+            with calio.open_tree(config["OUT"]) as f_L2:
+                withsky = np.asarray(f_L2["roman"]["data_withsky"], dtype=np.float32)
+                pinfo = calio._materialise(f_L2["processinfo"])
+                t_fr = mytree["roman"]["meta"]["exposure"]["frame_time"]
+            if "b" in noiseflags:  # background only: the low-order sky model
+                sky_order = int("0" + _get_subscript(noiseflags.upper(), "B"))
+                skylevel = sky.medfit(withsky, order=sky_order)[1]
+            else:
+                skylevel = withsky.copy()
+            if "r" in noiseflags:
+                with calio.open_tree(config["CALDIR"]["gain"]) as g_:
+                    gain = np.clip(np.asarray(g_["roman"]["data"]), 1e-4, 1e4)
+                d = (gain.shape[-1] - skylevel.shape[-1]) // 2
+                if d > 0:
+                    gain = gain[d:-d, d:-d]
+                w, has, endslice = ramp_weight_vectors(pinfo, len(read_pattern))
+                samples = None
+                if host_rng is not None:
+                    e = np.clip(skylevel * gain * t_fr, 0.0, None)
+                    samples = np.stack([host_rng.poisson(e.astype(np.float64)).astype(np.float64)
+                                        for _ in range(int(read_pattern[-1][-1]) + 1)])
+                diff = np.ascontiguousarray(diff, dtype=np.float32)
+                poisson_resample(diff, skylevel, np.ascontiguousarray(gain), t_fr, read_pattern, w, has, endslice, samples=samples,
+                                 seed=seed, layer=1000 + i_noise)
         if "S" in cmd:
             sky_order = int("0" + _get_subscript(cmd, "S"))
             diff = diff - sky.medfit(diff, order=sky_order)[1]

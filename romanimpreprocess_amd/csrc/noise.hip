@@ -7,6 +7,7 @@
 // Box-Muller, keyed by seed, layer, group and pixel), so that a layer is reproducible and needs no host random numbers.
 // Border pixels (reference pixels) pass through unchanged.  Host arrays in and out.  Exact given the normals.
 #include "rip_common.h"
+#include <cstring>
 
 namespace {
 
@@ -103,6 +104,180 @@ extern "C" int rip_stage_noise_inject(rip_ctx *ctx, const uint16_t *cube, int ng
     NZ_HIP(hipMemcpyAsync(out, d_out, (size_t)ngrp * npix * 2, hipMemcpyDeviceToHost, ctx->stream));
     NZ_HIP(hipStreamSynchronize(ctx->stream));
 #undef NZ_HIP
+    done();
+    return RIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ resampled Poisson ('P..r')
+// gen_noise_image.py:262-331: per active pixel, with e = clip(skylevel * gain * t_frame, 0) electrons per frame,
+//     for isamp = 0 .. lastsamp:  s = Poisson(e) - e ;  s /= gain ;  cur (f32) = f32(f64(cur) + s)            (f64 sample)
+//                                 for every group j holding read isamp:  delta[j] (f32) += cur / N_j
+//     diff (f32) += sum_j w[endslice][j] * delta[j]        one f32 product and one f32 addition per j, j ascending
+// where w[es] is the weight vector the ramp fit used for a ramp ending at group es (processinfo weights for the full ramp,
+// the two-point weights for truncated ones) and endslice comes from the L2 file (SLICEOUT).  The Poisson deviates come from
+// the caller (samples (nsamp, n) f64, the reference order) or, samples == NULL, from the device generator: inversion by
+// sequential search below a mean of 10, Hoermann's transformed rejection (PTRS) above, uniforms from Philox keyed by (seed,
+// layer, read, pixel, attempt).  Everything but the deviates is exact.
+namespace {
+
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t a, uint32_t b, uint32_t c_, uint32_t d, int which) {
+    uint32_t c[4] = {a, b, c_, d};
+    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return ((float)(c[which] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+__device__ double device_poisson(double lam, uint64_t seed, uint32_t layer, uint32_t isamp, uint32_t pix) {
+    if (!(lam > 0.0)) return 0.0;
+    if (lam < 10.0) {   // inversion: sequential search of the cumulative distribution with one uniform (two words: 48 bits)
+        uint32_t c[4] = {pix, isamp, layer, 0x706f6973u};
+        philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const double u = ((double)(((uint64_t)c[0] << 16) | (c[1] >> 16)) + 0.5) * (1.0 / 281474976710656.0);
+        double p = exp(-lam), cdf = p;
+        int k = 0;
+        while (u > cdf && k < 200) {
+            ++k;
+            p *= lam / k;
+            cdf += p;
+        }
+        return (double)k;
+    }
+    // PTRS (W. Hoermann, "The transformed rejection method for generating Poisson random variables", 1993)
+    const double slam = sqrt(lam), loglam = log(lam);
+    const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b, inv_alpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+        uint32_t c[4] = {pix, isamp, layer ^ (attempt << 16), 0x70747273u};
+        philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const double u = ((double)c[0] + 0.5) * (1.0 / 4294967296.0) - 0.5;
+        const double v = ((double)c[1] + 0.5) * (1.0 / 4294967296.0);
+        const double us = 0.5 - fabs(u);
+        const double k = floor((2.0 * a / us + b) * u + lam + 0.43);
+        if (us >= 0.07 && v <= vr) return k;
+        if (k < 0.0 || (us < 0.013 && v > us)) continue;
+        if (log(v) + log(inv_alpha) - log(a / (us * us) + b) <= -lam + k * loglam - lgamma(k + 1.0)) return k;
+    }
+    return floor(lam + 0.5);   // not reached in practice
+}
+
+struct ResampleArgs {
+    const float *sky;        // (n) skylevel, DN/s
+    const void *gain;        // (n) clipped gain, f32 or f64
+    int gain_f64;
+    double t_frame;
+    const int8_t *endslice;  // (n), already mapped: <= 0 -> ngrp - 1
+    const double *samples;   // (nsamp, n) or null
+    float *diff;             // (n) in/out
+    size_t n;
+    int ngrp, nsamp;
+    uint64_t seed;
+    uint32_t layer;
+};
+struct ResampleTables {
+    float w[RIP_MAX_GROUPS > 16 ? 16 : RIP_MAX_GROUPS][16];   // w[es][j]; rows without a weight vector are flagged in has
+    int has[16];
+    int first[16], count[16];   // reads of group j: first .. first + count - 1 (contiguous, as in every MA table)
+};
+
+template <typename GT>
+__global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a, ResampleTables t) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const GT g = reinterpret_cast<const GT *>(a.gain)[i];
+    // e = skylevel * gain * t_frame in the promoted type, clipped at zero
+    GT e = (GT)a.sky[i] * g;
+    e = (GT)(e * (GT)a.t_frame);
+    if (e < (GT)0) e = (GT)0;
+    float cur = 0.0f;
+    float delta[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) delta[j] = 0.0f;
+    for (int s = 0; s < a.nsamp; ++s) {
+        const double k = a.samples ? a.samples[(size_t)s * a.n + i] : device_poisson((double)e, a.seed, a.layer, (uint32_t)s, (uint32_t)i);
+        double smp = k - (double)e;
+        smp = smp / (double)g;
+        cur = (float)((double)cur + smp);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < a.ngrp && s >= t.first[j] && s < t.first[j] + t.count[j]) delta[j] = __fadd_rn(delta[j], cur / (float)t.count[j]);
+    }
+    const int es = a.endslice[i];
+    float d = __fadd_rn(a.diff[i], 0.0f);   // the reference adds 0.0 for every other end slice (-0 becomes +0)
+    if (es >= 0 && es < a.ngrp && t.has[es]) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < a.ngrp) d = __fadd_rn(d, __fmul_rn(t.w[es][j], delta[j]));
+    }
+    a.diff[i] = d;
+}
+
+}   // namespace
+
+extern "C" int rip_stage_poisson_resample(rip_ctx *ctx, const float *skylevel, const void *gain, int gain_dtype, size_t n,
+                                          double frame_time, int ngrp, const int32_t *group_first, const int32_t *group_count,
+                                          const float *weights, const uint8_t *has_weights, const int8_t *endslice,
+                                          const double *samples, int nsamp, uint64_t seed, uint32_t layer, float *diff) {
+    if (!skylevel || !gain || !group_first || !group_count || !weights || !has_weights || !endslice || !diff || ngrp < 1 || ngrp > 16 ||
+        nsamp < 1 || n < 1 || (gain_dtype != RIP_F32 && gain_dtype != RIP_F64))
+        return rip_fail(ctx, RIP_EINVAL, "poisson_resample: bad arguments (up to 16 groups)");
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    ResampleTables t;
+    memset(&t, 0, sizeof t);
+    for (int j = 0; j < ngrp; ++j) {
+        t.first[j] = group_first[j];
+        t.count[j] = group_count[j];
+        if (group_count[j] < 1) return rip_fail(ctx, RIP_EINVAL, "poisson_resample: group %d has no reads", j);
+        t.has[j] = has_weights[j] ? 1 : 0;
+        for (int k = 0; k < ngrp; ++k) t.w[j][k] = weights[j * ngrp + k];
+    }
+    const size_t gs = gain_dtype == RIP_F64 ? 8 : 4;
+    void *d_sky = nullptr, *d_gain = nullptr, *d_end = nullptr, *d_smp = nullptr, *d_diff = nullptr;
+    int rc = RIP_OK;
+    auto done = [&]() {
+        for (void *p : {d_sky, d_gain, d_end, d_smp, d_diff})
+            if (p) (void)hipFree(p);
+    };
+#define PR_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            rc = rip_fail(ctx, RIP_EHIP, "%s: %s", #call, hipGetErrorString(e_));      \
+            done();                                                                    \
+            return rc;                                                                 \
+        }                                                                              \
+    } while (0)
+    PR_HIP(hipMalloc(&d_sky, n * 4));
+    PR_HIP(hipMalloc(&d_gain, n * gs));
+    PR_HIP(hipMalloc(&d_end, n));
+    PR_HIP(hipMalloc(&d_diff, n * 4));
+    PR_HIP(hipMemcpyAsync(d_sky, skylevel, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PR_HIP(hipMemcpyAsync(d_gain, gain, n * gs, hipMemcpyHostToDevice, ctx->stream));
+    PR_HIP(hipMemcpyAsync(d_end, endslice, n, hipMemcpyHostToDevice, ctx->stream));
+    PR_HIP(hipMemcpyAsync(d_diff, diff, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (samples) {
+        PR_HIP(hipMalloc(&d_smp, (size_t)nsamp * n * 8));
+        PR_HIP(hipMemcpyAsync(d_smp, samples, (size_t)nsamp * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ResampleArgs a;
+    a.sky = (const float *)d_sky;
+    a.gain = d_gain;
+    a.gain_f64 = gain_dtype == RIP_F64;
+    a.t_frame = frame_time;
+    a.endslice = (const int8_t *)d_end;
+    a.samples = (const double *)d_smp;
+    a.diff = (float *)d_diff;
+    a.n = n;
+    a.ngrp = ngrp;
+    a.nsamp = nsamp;
+    a.seed = seed;
+    a.layer = layer;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (gain_dtype == RIP_F64)
+        hipLaunchKernelGGL(resample_kernel<double>, grid, dim3(256), 0, ctx->stream, a, t);
+    else
+        hipLaunchKernelGGL(resample_kernel<float>, grid, dim3(256), 0, ctx->stream, a, t);
+    PR_HIP(hipGetLastError());
+    PR_HIP(hipMemcpyAsync(diff, d_diff, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PR_HIP(hipStreamSynchronize(ctx->stream));
+#undef PR_HIP
     done();
     return RIP_OK;
 }

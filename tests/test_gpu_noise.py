@@ -80,7 +80,7 @@ def _write_inputs(tmp_path, rp, ny, nx):
                              "instrument": {"detector": "WFI04"}}}}
     calio.write_asdf(str(tmp_path / "l1.asdf"), l1)
     config = {"IN": str(tmp_path / "l1.asdf"), "OUT": str(tmp_path / "l2.asdf"), "CALDIR": caldir, "SLICEOUT": True,
-              "NOISE": {"LAYER": ["Ra", "R", "RaS2", "Raz2", "Ccomment"], "TEMP": str(tmp_path / "tmp.asdf"), "SEED": 11,
+              "NOISE": {"LAYER": ["Ra", "R", "RaS2", "Raz2", "Ccomment", "Pr", "Pb2r"], "TEMP": str(tmp_path / "tmp.asdf"), "SEED": 11,
                         "OUT": str(tmp_path / "noise.asdf")}, "NOISE_PRECISION": 32}
     return cal, ramp, config
 
@@ -96,7 +96,7 @@ def test_noise_layers_end_to_end(tmp_path):
     out = calio.read_asdf(config["NOISE"]["OUT"])
     noise = np.asarray(out["noise"])
     l2 = calio.read_asdf(config["OUT"])
-    assert noise.shape == (5,) + np.asarray(l2["roman"]["data"]).shape and noise.dtype == np.float32
+    assert noise.shape == (7,) + np.asarray(l2["roman"]["data"]).shape and noise.dtype == np.float32
     good = np.asarray(l2["roman"]["dq"]) == 0
     err_read = np.sqrt(np.asarray(l2["roman"]["var_rnoise"]))[good]
     for i in (0, 1, 2):
@@ -119,6 +119,80 @@ def test_noise_layers_end_to_end(tmp_path):
     # host deviates in the reference's order give different, equally valid layers
     other = gen_noise_image.make_noise_cube(dict(config, NOISE=dict(config["NOISE"], LAYER=["Ra"])), np.random.default_rng(3))
     assert 0.8 < np.std(other[0][good]) / np.sqrt(np.mean(err_read**2)) < 1.25
-    for bad in ("Pr", "O"):
-        with pytest.raises(NotImplementedError):
-            gen_noise_image.make_noise_cube(dict(config, NOISE=dict(config["NOISE"], LAYER=[bad])))
+    # resampled Poisson layers: scatter = the Poisson error of the slope (unsaturated, jump-free pixels: full-ramp weights)
+    err_p = np.sqrt(np.asarray(l2["roman"]["var_poisson"]))[good]
+    for i in (5, 6):
+        ratio = np.std(noise[i][good]) / np.sqrt(np.mean(err_p**2))
+        assert 0.7 < ratio < 1.4, (i, ratio)
+    with pytest.raises(NotImplementedError):
+        gen_noise_image.make_noise_cube(dict(config, NOISE=dict(config["NOISE"], LAYER=["O"])))
+
+
+def numpy_resample(diff, skylevel, gain, t_fr, read_pattern, weightvecs, endslice, samples):
+    """gen_noise_image.py:285-331 as written there, with the Poisson deviates handed in."""
+    ngrp = len(read_pattern)
+    n = skylevel.shape
+    lastsamp = read_pattern[-1][-1]
+    e_per_slice = skylevel * gain * t_fr
+    delta_resultants = np.zeros((ngrp,) + n, dtype=np.float32)
+    e_per_slice = np.clip(e_per_slice, 0.0, None)
+    current_sample = np.zeros(np.shape(e_per_slice), dtype=np.float32)
+    for isamp in range(lastsamp + 1):
+        sample = samples[isamp].copy()
+        sample -= e_per_slice
+        sample /= gain
+        current_sample += sample
+        for j in range(ngrp):
+            if isamp in read_pattern[j]:
+                delta_resultants[j, :, :] += current_sample / len(read_pattern[j])
+    for es in range(ngrp):
+        if isinstance(weightvecs[es], np.ndarray):
+            for j in range(len(weightvecs[es])):
+                diff[:, :] += np.where(endslice == es, weightvecs[es][j] * delta_resultants[j, :, :], 0.0)
+    return diff
+
+
+@pytest.mark.parametrize("gdt", [np.float32, np.float64])
+def test_poisson_resampling_is_exact_given_the_deviates(gdt):
+    rng = np.random.default_rng(17)
+    rp = synth.READ_PATTERN_8
+    ngrp, ny, nx = len(rp), 30, 70
+    sky_ = (0.4 + 3.0 * rng.random((ny, nx)) ** 4).astype(np.float32)
+    sky_[3, 3] = -0.2                                       # negative sky: clipped to zero electrons
+    sky_[4, 4] = 4000.0
+    gain = np.clip((1.5 + 0.1 * rng.standard_normal((ny, nx))).astype(gdt), 1e-4, 1e4)
+    t_fr = 3.04
+    tbar = [t_fr * np.mean(g) for g in rp]
+    pinfo = {"meta": {"tbar": tbar}, "weights": rng.standard_normal(ngrp).astype(np.float32), "exclude_first": True,
+             "endslice": rng.integers(-1, ngrp, size=(ny, nx)).astype(np.int8)}
+    w, has, endslice = gen_noise_image.ramp_weight_vectors(pinfo, ngrp)
+    assert has.tolist() == [0, 0, 1, 1, 1, 1, 1, 1] and endslice.min() >= 1
+    weightvecs = [w[i].copy() if has[i] else "" for i in range(ngrp)]
+    e = np.clip(sky_ * gain * t_fr, 0.0, None)
+    samples = np.stack([rng.poisson(e.astype(np.float64)).astype(np.float64) for _ in range(rp[-1][-1] + 1)])
+    start = (0.01 * rng.standard_normal((ny, nx))).astype(np.float32)
+    start[0, 0] = -0.0
+    want = numpy_resample(start.copy(), sky_, gain, t_fr, rp, weightvecs, endslice, samples)
+    got = gen_noise_image.poisson_resample(start.copy(), sky_, gain, t_fr, rp, w, has, endslice, samples=samples, ctx=gpu_context())
+    assert_same_bits(got, want, "resampled Poisson layer")
+
+
+def test_device_poisson_deviates():
+    """Mean and variance of the device generator across the inversion / PTRS switch: a single read group, weight 1, so
+    that the layer IS the re-centred deviate in DN."""
+    rp = [[0]]
+    n = 400_000
+    for lam in (0.05, 0.7, 3.0, 9.5, 10.5, 40.0, 900.0, 20000.0):
+        sky_ = np.full((1, n), lam, np.float32)
+        gain = np.ones((1, n), np.float32)
+        diff = np.zeros((1, n), np.float32)
+        gen_noise_image.poisson_resample(diff, sky_, gain, 1.0, rp, np.ones((1, 1), np.float32), np.ones(1, np.uint8),
+                                         np.zeros((1, n), np.int8), seed=3, layer=int(lam * 10), ctx=gpu_context())
+        k = diff.astype(np.float64) + lam
+        assert np.all(np.abs(k - np.round(k)) < 1e-2 * max(1.0, lam / 1000)) and k.min() >= -1e-3
+        se = np.sqrt(lam / n)
+        assert abs(k.mean() - lam) < 5 * se, (lam, k.mean())
+        assert abs(k.var() - lam) < 5 * lam * np.sqrt(2.0 / n + 1.0 / (lam * n)), (lam, k.var())
+        if lam < 5:
+            p0 = np.mean(np.round(k) == 0)
+            assert abs(p0 - np.exp(-lam)) < 5 * np.sqrt(np.exp(-lam) / n) + 1e-4
