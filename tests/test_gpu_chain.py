@@ -316,13 +316,15 @@ def test_saturation_flagging_on_device_matches_host_restatement():
         cb.ctx.drop_caldir(6)
 
 
-def test_full_frame_4096x4096x8_vs_oracle_and_between_forms():
-    """BASELINE config 2 at its full size (the bench workload): the numpy oracle on the whole frame (about a minute of CPU)
-    against the wave-specialised kernel, bit for bit with LAPACK's channel lines handed in; then the three device forms
-    (specialised, general fused, stage kernels) against each other with the lines fitted on the device."""
+@pytest.mark.parametrize("kdt", [np.float32, np.float64])
+def test_full_frame_4096x4096x8_vs_oracle_and_between_forms(kdt):
+    """BASELINE config 2 at its full size (the bench workload; also with the f64 ipc4d of production CALDIR sets): the numpy
+    oracle on the whole frame (about a minute of CPU) against the wave-specialised kernel, bit for bit with LAPACK's channel
+    lines handed in; then the three device forms (specialised, general fused, stage kernels) against each other with the
+    lines fitted on the device."""
     rp = synth.READ_PATTERN_8
     n = 4096
-    cal, ramp = synth.make_tiled_inputs(n, n, read_pattern=rp, p_order=8, seed=1, strip_rows=128)
+    cal, ramp = synth.make_tiled_inputs(n, n, read_pattern=rp, p_order=8, seed=1, strip_rows=128, ipc_dtype=kdt)
     ref = oracle.calibrate_arrays(ramp, cal)
     ctx = gpu_context()
     cb = pipeline.Calibrator(ctx=ctx)
