@@ -24,7 +24,7 @@ import sys
 import numpy as np
 
 from .. import calio, pars, pipeline, plan as planmod
-from ..dqflags import group, pixel
+from ..dqflags import group
 from ..utils import maskhandling, processlog, sky
 
 _cal_cache = {}  # (ctx id, tuple of CALDIR paths) -> slot

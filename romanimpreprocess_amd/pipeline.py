@@ -5,7 +5,6 @@ plans; ``calibrate`` runs the chain of ``calibrateimage`` (``gen_cal_image.py:53
 arrays (host) or on device pointers (e.g. torch tensors' ``data_ptr()``), through ``rip_calibrate``.
 """
 
-import ctypes as C
 
 import numpy as np
 
