@@ -265,6 +265,15 @@ int rip_stage_invlinearity(rip_ctx *ctx, const void *slin, int dtype, int ny, in
 int rip_stage_noise_inject(rip_ctx *ctx, const uint16_t *cube, int ngrp, int ny, int nx, int nb, const float *read_noise,
                            const int32_t *nreads, const float *normals, uint64_t seed, uint32_t layer, uint16_t *out);
 
+/* sim_to_isim.noise_1f_frame (sim_to_isim.py:265-303): nframes frames of rows x width samples of 1/f noise (unit variance per
+   logarithmic frequency range), the generator behind the correlated part of a read-noise layer (:376-399).  For each frame
+   L = 2*rows*width complex samples (n_k + i n_{L+k}) |k|^-1/2 are Fourier transformed in f64 (hipFFT), the real part of the
+   first L/2 outputs / sqrt(2) minus its mean is the frame, cast to f32.  normals (nframes, 2L) f64 standard normal deviates
+   from the caller, or NULL: drawn on the device (seed, stream_id).  out (nframes, rows, width) f32.  Host arrays.  Agrees
+   with the reference's numpy FFT to rounding (~1e-12 relative before the cast), not bit for bit. */
+int rip_stage_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, const double *normals, uint64_t seed,
+                       uint32_t stream_id, float *out);
+
 /* gen_noise_image.make_noise_cube, resampled Poisson layer 'P..r' (gen_noise_image.py:262-331) on n pixels: electrons per frame
    e = clip(skylevel * gain * frame_time, 0); for each read a Poisson deviate of mean e, re-centred, in DN, accumulated into the
    change of every resultant (group j = reads group_first[j] .. + group_count[j] - 1), then diff += sum_j w[endslice][j] *

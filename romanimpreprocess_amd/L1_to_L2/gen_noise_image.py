@@ -14,9 +14,11 @@ and handed to the kernel).  Layers are therefore statistically, not bit-wise, co
   * resampled Poisson layers (``P..r``, ``:262-331``): ``rip_stage_poisson_resample`` (HIP kernel: deviates, their
     accumulation into the resultants and the ramp-fit weights of every pixel's end slice in one pass; exact given the
     deviates).
-Not built: the correlated part of a read-noise layer (``sim_to_isim.fill_in_refdata_and_1f``: fresh reference pixels,
-reference output and 1/f noise -- the reference pixels of the input are kept) and the pseudo-Poisson layers (``O``, the
-GalPoisson sampler); asking for ``O`` raises NotImplementedError.
+  * the correlated part of a read-noise layer (``sim_to_isim.fill_in_refdata_and_1f`` :306-402: fresh reference pixels,
+    reference output, 1/f noise): the 1/f frames -- 34 Fourier transforms of 2^20 points per group -- are made by
+    ``rip_stage_noise_1f`` (hipFFT, device deviates); the white deviates and the assembly follow the reference's lines in
+    numpy on the host (``NOISE: {CORRELATED: false}`` switches the step off).
+Not built: the pseudo-Poisson layers (``O``, the GalPoisson sampler); asking for them raises NotImplementedError.
 """
 
 import re
@@ -55,6 +57,66 @@ def inject_read_noise(data, read_noise, read_pattern, nb=pars.nborder, normals=N
                                              None if normals is None else normals.ctypes.data, int(seed) & (2**64 - 1),
                                              int(layer), out.ctypes.data))
     return out
+
+
+def noise_1f_frames(nframes, rows=pars.nside, width=pars.channelwidth, normals=None, seed=0, stream=0, ctx=None):
+    """``nframes`` frames (rows, width) f32 of 1/f noise (``sim_to_isim.noise_1f_frame`` :265-303) on the GPU (hipFFT).
+    ``normals`` (nframes, 4*rows*width) f64 standard normal deviates or None (drawn on the device)."""
+    ctx = ctx or _native.default_context()
+    if normals is not None:
+        normals = np.ascontiguousarray(normals, dtype=np.float64)
+        if normals.shape != (nframes, 4 * rows * width):
+            raise ValueError(f"normals have shape {normals.shape}, expected {(nframes, 4 * rows * width)}")
+    out = np.empty((nframes, rows, width), np.float32)
+    ctx.check(ctx.lib.rip_stage_noise_1f(ctx.h, rows, width, nframes, None if normals is None else normals.ctypes.data,
+                                         int(seed) & (2**64 - 1), int(stream) & 0xFFFFFFFF, out.ctypes.data))
+    return out
+
+
+def fill_in_refdata_and_1f(im, caldir, rng, tij, fill_in_banding=True, amp33=None, seed=0, stream=0, ctx=None):
+    """Reference pixels, reference output and correlated noise of a Level-1 cube, in place (``sim_to_isim.py:306-402``):
+    the border becomes dark + read noise + reset noise, every science channel and the reference output receive 1/f noise
+    (one common frame per group plus one per channel), the cube is rounded back to its integer type.  ``rng``: a
+    ``numpy.random.Generator`` for the white deviates; the 1/f frames -- 34 Fourier transforms of 2^20 points per group,
+    the expensive part -- are made on the GPU with device deviates (``seed``, ``stream``)."""
+    ngrp, ny, nx = np.shape(im)
+    nborder = pars.nborder
+    cw = pars.channelwidth
+    noise = rng.standard_normal((ngrp + 1, ny, nx), dtype=np.float32)
+    with calio.open_tree(caldir["read"]) as f:
+        noise[:-1, :, :] *= np.asarray(f["roman"]["data"])[None, :, :]
+        noise[-1, :, :] *= np.asarray(f["roman"]["resetnoise"])
+        u_pink = float(f["roman"]["anc"]["U_PINK"])
+        c_pink = float(f["roman"]["anc"]["C_PINK"])
+        amp33info = {"valid": False}
+        if amp33 is not None and "amp33" in f["roman"]:
+            amp33info = calio._materialise(f["roman"]["amp33"])
+    for j in range(len(tij)):
+        noise[j, :, :] /= len(tij[j]) ** 0.5
+    noise[:-1, :, :] += noise[-1, :, :][None, :, :]
+    with calio.open_tree(caldir["dark"]) as f:
+        dark = np.asarray(f["roman"]["data"])
+        de = dark.shape[0] - ngrp
+        noise[:-1, :, :] += dark[de:, :, :]
+    act = (slice(None), slice(nborder, ny - nborder), slice(nborder, nx - nborder))
+    noise[:-1][act] = im[act].astype(noise.dtype)
+    if fill_in_banding:
+        nch = nx // cw
+        per_group = 1 + nch + (1 if amp33info.get("valid") else 0)
+        for j in range(len(tij)):
+            frames = noise_1f_frames(per_group, rows=ny, width=cw, seed=seed, stream=stream + j * per_group, ctx=ctx)
+            common_noise = frames[0] * c_pink
+            for ch in range(nch):
+                pinknoise = frames[1 + ch] * u_pink + common_noise
+                if ch % 2 == 1:
+                    pinknoise = pinknoise[:, ::-1]
+                noise[j, :, cw * ch:cw * (ch + 1)] += (pinknoise / len(tij[j]) ** 0.5).astype(noise.dtype)
+            if amp33info.get("valid"):
+                whitenoise = rng.standard_normal((ny, cw), dtype=np.float32)
+                whitenoise *= amp33info["std"]
+                pinknoise = amp33info["RU_PINK"] * frames[1 + nch] + amp33info["M_PINK"] * common_noise
+                amp33[j, :, :] = (amp33info["med"] + (whitenoise + pinknoise) / len(tij[j]) ** 0.5).astype(amp33.dtype)
+    im[:, :, :] = np.clip(np.round(noise[:-1, :, :]), 0, 2**16 - 1).astype(im.dtype)
 
 
 def ramp_weight_vectors(processinfo, ngrp):
@@ -151,7 +213,18 @@ def make_noise_cube(config, rng=None):
                 normals = np.stack([host_rng.standard_normal(na, dtype=np.float32) for _ in range(data.shape[0])])
             mytree["roman"]["data"] = inject_read_noise(data, read, read_pattern, nb=nb, normals=normals, seed=seed,
                                                         layer=i_noise)
-            # (the reference regenerates reference pixels, reference output and 1/f noise here: not built)
+            # correlated noise: fresh reference pixels, reference output and 1/f noise (sim_to_isim.fill_in_refdata_and_1f)
+            if config["NOISE"].get("CORRELATED", True):
+                cube = np.ascontiguousarray(mytree["roman"]["data"])
+                a33 = mytree["roman"].get("amp33")
+                if a33 is not None:
+                    a33 = np.ascontiguousarray(a33)
+                fill_in_refdata_and_1f(cube, config["CALDIR"], host_rng if host_rng is not None else
+                                       np.random.default_rng([int(seed) & 0xFFFFFFFF, i_noise]), read_pattern, amp33=a33,
+                                       seed=seed, stream=100000 * (i_noise + 1))
+                mytree["roman"]["data"] = cube
+                if a33 is not None:
+                    mytree["roman"]["amp33"] = a33
             calio.write_asdf(config["NOISE"]["TEMP"], mytree)
             config2 = deepcopy(config)
             config2["IN"] = config["NOISE"]["TEMP"]

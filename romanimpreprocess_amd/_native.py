@@ -100,6 +100,7 @@ SYMBOLS = {
     "rip_stage_legendre2d": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _I, _VP]),
     "rip_stage_invlinearity": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "rip_stage_noise_inject": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, C.c_uint64, C.c_uint32, _VP]),
+    "rip_stage_noise_1f": (_I, [_VP, _I, _I, _I, _VP, C.c_uint64, C.c_uint32, _VP]),
     "rip_stage_poisson_resample": (_I, [_VP, _VP, _VP, _I, C.c_size_t, C.c_double, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I,
                                         C.c_uint64, C.c_uint32, _VP]),
     "rip_stats_l1_diff": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),

@@ -1,0 +1,155 @@
+// 1/f noise frames: sim_to_isim.noise_1f_frame (sim_to_isim.py:265-303), the generator behind the
+// correlated part of a read-noise layer (fill_in_refdata_and_1f :376-399: one common and 32 per-channel frames plus one for
+// the reference output, per group).  One frame of rows x width samples:
+//     L = 2*rows*width ;  z_k = (n_k + i n_{L+k}) * a_k ,  a_k = |k|^-1/2 for the signed frequency index k (a_0 = 0)
+//     block = Re(FFT(z))[0 : L/2] / sqrt(2) ;  block -= mean(block) ;  reshaped (rows, width), cast to f32
+// in f64 as the reference (complex128 FFT of 2^20 points for the 4096 x 128 frame; hipFFT Z2Z, batched).  The 2L standard
+// normal deviates per frame come from the caller or, normals == NULL, from the device (Philox + Box-Muller).  The FFT is not
+// the reference's pocketfft: results agree to rounding (~1e-12 relative), not bit for bit.
+#include <hipfft/hipfft.h>
+
+#include <algorithm>
+
+#include "rip_common.h"
+
+namespace {
+
+__device__ __forceinline__ void philox10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (uint32_t)p1;
+        c[3] = (uint32_t)p0;
+        c[0] = n0;
+        c[2] = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// z[f*L + k] from the deviates of frame f (or from the device generator)
+__global__ __launch_bounds__(256) void pink_fill_kernel(const double *__restrict__ normals, hipfftDoubleComplex *__restrict__ z, size_t L,
+                                                        int nframes, uint64_t seed, uint32_t stream_id) {
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    if (k >= L) return;
+    double a, b;
+    if (normals) {
+        a = normals[(size_t)f * 2 * L + k];
+        b = normals[(size_t)f * 2 * L + L + k];
+    } else {
+        uint32_t c[4] = {(uint32_t)k, (uint32_t)(k >> 32) ^ (uint32_t)f, stream_id, 0x70696e6bu};
+        philox10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const double u1 = ((double)(((uint64_t)c[0] << 21) | (c[1] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);   // 53 bits, (0, 1)
+        const double u2 = ((double)(((uint64_t)c[2] << 21) | (c[3] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+        const double r = sqrt(-2.0 * log(u1));
+        a = r * cospi(2.0 * u2);
+        b = r * sinpi(2.0 * u2);
+    }
+    // signed frequency index as the reference builds it: linspace(0, 1 - 1/L, L), upper half minus one, times L
+    const double step = (1.0 - 1.0 / (double)L) / (double)(L - 1);
+    double freq = (double)k * step;
+    if (k >= L / 2) freq -= 1.0;
+    double amp = pow(1.0e-99 + fabs(freq * (double)L), -0.5);
+    if (k == 0) amp = 0.0;
+    hipfftDoubleComplex v;
+    v.x = a * amp;
+    v.y = b * amp;
+    z[(size_t)f * L + k] = v;
+}
+
+// sum of Re(Z)[0 : L/2] / sqrt(2) per frame (f64, two-level)
+__global__ __launch_bounds__(256) void pink_sum_kernel(const hipfftDoubleComplex *__restrict__ z, size_t L, double *__restrict__ sums) {
+    __shared__ double sh[256];
+    const int f = blockIdx.y;
+    const size_t half = L / 2;
+    double acc = 0.0;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < half; k += (size_t)gridDim.x * 256) acc += z[(size_t)f * L + k].x / sqrt(2.0);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(&sums[f], sh[0]);
+}
+
+__global__ __launch_bounds__(256) void pink_out_kernel(const hipfftDoubleComplex *__restrict__ z, size_t L, const double *__restrict__ sums,
+                                                       float *__restrict__ out) {
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    const size_t half = L / 2;
+    if (k >= half) return;
+    const double mean = sums[f] / (double)half;
+    out[(size_t)f * half + k] = (float)(z[(size_t)f * L + k].x / sqrt(2.0) - mean);
+}
+
+}   // namespace
+
+extern "C" int rip_stage_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, const double *normals, uint64_t seed,
+                                  uint32_t stream_id, float *out) {
+    if (rows < 1 || width < 1 || nframes < 1 || !out) return rip_fail(ctx, RIP_EINVAL, "noise_1f: bad arguments");
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t L = (size_t)2 * rows * width, half = L / 2;
+    hipfftDoubleComplex *z = nullptr;
+    double *d_n = nullptr, *d_s = nullptr;
+    float *d_o = nullptr;
+    hipfftHandle plan = 0;
+    bool have_plan = false;
+    int rc = RIP_OK;
+    auto done = [&]() {
+        if (have_plan) (void)hipfftDestroy(plan);
+        for (void *p : {(void *)z, (void *)d_n, (void *)d_s, (void *)d_o})
+            if (p) (void)hipFree(p);
+    };
+#define PK_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            rc = rip_fail(ctx, RIP_EHIP, "%s: %s", #call, hipGetErrorString(e_));      \
+            done();                                                                    \
+            return rc;                                                                 \
+        }                                                                              \
+    } while (0)
+    // frames are transformed in chunks so that the complex buffer stays below ~1 GB
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nframes, ((size_t)1 << 30) / (L * sizeof(hipfftDoubleComplex))));
+    PK_HIP(hipMalloc((void **)&z, (size_t)chunk * L * sizeof(hipfftDoubleComplex)));
+    PK_HIP(hipMalloc((void **)&d_s, (size_t)chunk * sizeof(double)));
+    PK_HIP(hipMalloc((void **)&d_o, (size_t)chunk * half * sizeof(float)));
+    if (normals) PK_HIP(hipMalloc((void **)&d_n, (size_t)chunk * 2 * L * sizeof(double)));
+    int n1 = (int)L;
+    if (hipfftPlanMany(&plan, 1, &n1, nullptr, 1, n1, nullptr, 1, n1, HIPFFT_Z2Z, chunk) != HIPFFT_SUCCESS) {
+        rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftPlanMany(%zu points x %d) failed", L, chunk);
+        done();
+        return rc;
+    }
+    have_plan = true;
+    if (hipfftSetStream(plan, ctx->stream) != HIPFFT_SUCCESS) {
+        rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftSetStream failed");
+        done();
+        return rc;
+    }
+    for (int f0 = 0; f0 < nframes; f0 += chunk) {
+        const int nf = std::min(chunk, nframes - f0);
+        if (normals)
+            PK_HIP(hipMemcpyAsync(d_n, normals + (size_t)f0 * 2 * L, (size_t)nf * 2 * L * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(pink_fill_kernel, dim3((unsigned)((L + 255) / 256), nf), dim3(256), 0, ctx->stream, (const double *)d_n, z, L,
+                           nf, seed, stream_id + (uint32_t)f0);
+        if (nf < chunk) PK_HIP(hipMemsetAsync(z + (size_t)nf * L, 0, (size_t)(chunk - nf) * L * sizeof(hipfftDoubleComplex), ctx->stream));
+        if (hipfftExecZ2Z(plan, z, z, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
+            rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftExecZ2Z failed");
+            done();
+            return rc;
+        }
+        PK_HIP(hipMemsetAsync(d_s, 0, (size_t)chunk * sizeof(double), ctx->stream));
+        hipLaunchKernelGGL(pink_sum_kernel, dim3(256, nf), dim3(256), 0, ctx->stream, z, L, d_s);
+        hipLaunchKernelGGL(pink_out_kernel, dim3((unsigned)((half + 255) / 256), nf), dim3(256), 0, ctx->stream, z, L, (const double *)d_s, d_o);
+        PK_HIP(hipGetLastError());
+        PK_HIP(hipMemcpyAsync(out + (size_t)f0 * half, d_o, (size_t)nf * half * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        PK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+#undef PK_HIP
+    done();
+    return RIP_OK;
+}
