@@ -4,22 +4,11 @@ import numpy as np
 import pytest
 from conftest import assert_same_bits, gpu_context
 
+from oracle import noise as onoise
 from romanimpreprocess_amd import calio, pipeline, synth
 from romanimpreprocess_amd.L1_to_L2 import gen_cal_image, gen_noise_image
 
 pytestmark = pytest.mark.gpu
-
-
-def numpy_injection(data, read, read_pattern, normals, nb=4):
-    """gen_noise_image.py:120-134 as written there (numpy 2 promotion rules)."""
-    out = data.copy()
-    for k in range(len(read_pattern)):
-        resultants = out[k, nb:-nb, nb:-nb].astype(np.float32)
-        im = normals[k].copy()
-        im *= read[nb:-nb, nb:-nb] / np.sqrt(len(read_pattern[k]))
-        resultants += im
-        out[k, nb:-nb, nb:-nb] = np.round(np.clip(resultants, 0, 2**16 - 1)).astype(out.dtype)
-    return out
 
 
 def test_get_subscript():
@@ -38,7 +27,7 @@ def test_injection_is_exact_given_the_normals():
     normals = rng.standard_normal((G, ny - 8, nx - 8)).astype(np.float32)
     normals[:, 3, 3] = np.float32(0.5) / (read[7, 7] / np.sqrt(1.0)).astype(np.float32)   # a tie for round-half-even in group 0
     got = gen_noise_image.inject_read_noise(data, read, rp, normals=normals, ctx=gpu_context())
-    assert_same_bits(got, numpy_injection(data, read, rp, normals), "injected cube")
+    assert_same_bits(got, onoise.inject_read_noise(data, read, rp, normals), "injected cube")
     assert np.array_equal(got[:, :4], data[:, :4]) and np.array_equal(got[:, :, -4:], data[:, :, -4:])
 
 
@@ -129,30 +118,6 @@ def test_noise_layers_end_to_end(tmp_path):
         gen_noise_image.make_noise_cube(dict(config, NOISE=dict(config["NOISE"], LAYER=["O"])))
 
 
-def numpy_resample(diff, skylevel, gain, t_fr, read_pattern, weightvecs, endslice, samples):
-    """gen_noise_image.py:285-331 as written there, with the Poisson deviates handed in."""
-    ngrp = len(read_pattern)
-    n = skylevel.shape
-    lastsamp = read_pattern[-1][-1]
-    e_per_slice = skylevel * gain * t_fr
-    delta_resultants = np.zeros((ngrp,) + n, dtype=np.float32)
-    e_per_slice = np.clip(e_per_slice, 0.0, None)
-    current_sample = np.zeros(np.shape(e_per_slice), dtype=np.float32)
-    for isamp in range(lastsamp + 1):
-        sample = samples[isamp].copy()
-        sample -= e_per_slice
-        sample /= gain
-        current_sample += sample
-        for j in range(ngrp):
-            if isamp in read_pattern[j]:
-                delta_resultants[j, :, :] += current_sample / len(read_pattern[j])
-    for es in range(ngrp):
-        if isinstance(weightvecs[es], np.ndarray):
-            for j in range(len(weightvecs[es])):
-                diff[:, :] += np.where(endslice == es, weightvecs[es][j] * delta_resultants[j, :, :], 0.0)
-    return diff
-
-
 @pytest.mark.parametrize("gdt", [np.float32, np.float64])
 def test_poisson_resampling_is_exact_given_the_deviates(gdt):
     rng = np.random.default_rng(17)
@@ -168,12 +133,11 @@ def test_poisson_resampling_is_exact_given_the_deviates(gdt):
              "endslice": rng.integers(-1, ngrp, size=(ny, nx)).astype(np.int8)}
     w, has, endslice = gen_noise_image.ramp_weight_vectors(pinfo, ngrp)
     assert has.tolist() == [0, 0, 1, 1, 1, 1, 1, 1] and endslice.min() >= 1
-    weightvecs = [w[i].copy() if has[i] else "" for i in range(ngrp)]
     e = np.clip(sky_ * gain * t_fr, 0.0, None)
     samples = np.stack([rng.poisson(e.astype(np.float64)).astype(np.float64) for _ in range(rp[-1][-1] + 1)])
     start = (0.01 * rng.standard_normal((ny, nx))).astype(np.float32)
     start[0, 0] = -0.0
-    want = numpy_resample(start.copy(), sky_, gain, t_fr, rp, weightvecs, endslice, samples)
+    want = onoise.poisson_resample(start.copy(), sky_, gain, t_fr, rp, w, has, endslice, samples)
     got = gen_noise_image.poisson_resample(start.copy(), sky_, gain, t_fr, rp, w, has, endslice, samples=samples, ctx=gpu_context())
     assert_same_bits(got, want, "resampled Poisson layer")
 
@@ -199,29 +163,13 @@ def test_device_poisson_deviates():
             assert abs(p0 - np.exp(-lam)) < 5 * np.sqrt(np.exp(-lam) / n) + 1e-4
 
 
-def numpy_1f_frame(this_array, rows, width):
-    """sim_to_isim.noise_1f_frame (:265-303) with the deviates handed in."""
-    len_ = 2 * rows * width
-    freq = np.linspace(0, 1 - 1.0 / len_, len_)
-    freq[len_ // 2:] -= 1.0
-    amp = (1.0e-99 + np.abs(freq * len_)) ** (-0.5)
-    amp[0] = 0.0
-    ftsignal = np.zeros((len_,), dtype=np.complex128)
-    ftsignal[:] = this_array[:len_]
-    ftsignal[:] += 1j * this_array[len_:]
-    ftsignal *= amp
-    block = np.fft.fft(ftsignal).real[: len_ // 2] / np.sqrt(2.0)
-    block -= np.mean(block)
-    return block.reshape((rows, width)).astype(np.float32)
-
-
 @pytest.mark.parametrize("rows,width", [(64, 128), (4096, 128)])
 def test_1f_frames_against_numpy_fft(rows, width):
     rng = np.random.default_rng(23)
     normals = rng.standard_normal((3, 4 * rows * width))
     got = gen_noise_image.noise_1f_frames(3, rows=rows, width=width, normals=normals, ctx=gpu_context())
     for f in range(3):
-        want = numpy_1f_frame(normals[f], rows, width)
+        want = onoise.noise_1f_frame(normals[f], rows, width)
         # another FFT than numpy's pocketfft: equal to rounding (the f32 cast hides almost all of it)
         np.testing.assert_allclose(got[f], want, rtol=0, atol=2e-6 * np.abs(want).max())
         assert np.mean(got[f] != want) < 0.01
@@ -230,7 +178,7 @@ def test_1f_frames_against_numpy_fft(rows, width):
     assert dev.shape == (4, rows, width) and not np.array_equal(dev[0], dev[1])
     again = gen_noise_image.noise_1f_frames(4, rows=rows, width=width, seed=9, stream=5, ctx=gpu_context())
     assert np.array_equal(dev, again)
-    ref = np.stack([numpy_1f_frame(rng.standard_normal(4 * rows * width), rows, width) for _ in range(4)])
+    ref = np.stack([onoise.noise_1f_frame(rng.standard_normal(4 * rows * width), rows, width) for _ in range(4)])
 
     def octave_power(x):
         p = np.abs(np.fft.rfft(x.reshape(x.shape[0], -1).astype(np.float64), axis=1)) ** 2
