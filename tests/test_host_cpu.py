@@ -102,6 +102,9 @@ def test_asdf_and_npz_round_trip(tmp_path):
                       "k64": np.linspace(0, 1, 5)}}
     p = tmp_path / "x.asdf"
     calio.write_asdf(str(p), tree)
+    with_md5 = tmp_path / "x_md5.asdf"
+    calio.write_asdf(str(with_md5), tree, checksum=True)   # same file but for the optional block checksums
+    assert p.stat().st_size == with_md5.stat().st_size and p.read_bytes() != with_md5.read_bytes()
     back = calio.read_asdf(str(p))
     r = back["roman"]
     assert_same_bits(r["data"], tree["roman"]["data"], "data")
