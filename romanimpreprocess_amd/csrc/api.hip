@@ -190,6 +190,10 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value) {
         ctx->use_chain2 = value != 0;
         return RIP_OK;
     }
+    if (name && strcmp(name, "chain3") == 0) {
+        ctx->use_chain3 = value != 0;
+        return RIP_OK;
+    }
     if (name && strcmp(name, "overlap") == 0) {
         ctx->use_overlap = value != 0 && ctx->stream2 != nullptr;
         return RIP_OK;
@@ -769,7 +773,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     // stage-by-stage kernels
     ctx->last_form = 0;
     const bool fused = ctx->use_fused && do_ref && do_bias && do_lin && do_ipc && do_fit && in->data_dtype == RIP_U16 &&
-                       rip_chain_supported(c.lin_nplanes, G, c.ipc_dtype, c.gain_dtype);
+                       rip_chain_supported(ctx, c.lin_nplanes, G, c.ipc_dtype, c.gain_dtype);
     if (fused) {
         // ---- one kernel: refpix apply + bias + linearity + IPC + ramp fit + finish (chain.hip)
         ChainArgs ca;
@@ -893,6 +897,13 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     }
     mark();
     }  // unfused
+    // the main-stream kernels of this call are the last readers of the tables / flag copies of parity `par`: the
+    // pre-pass of call n+2 (same parity, second stream) waits for this event before it overwrites them
+    if (overlap) {
+        RIP_HIP(ctx, hipEventRecord(ctx->ev_done[par], ctx->stream));
+        ctx->ev_done_valid[par] = true;
+        ctx->parity ^= 1;
+    }
     // ---- results back
     if (host) {
         if (do_fit) {

@@ -6,14 +6,35 @@ int rip_launch_chain_np9(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, 
 int rip_launch_chain_np11(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int k_dtype);
 
 // f32 gain; 4 / 9 / 11 Legendre planes (P_ORDER 3 / 8 / 10); 6, 8 or 16 groups; LDS budget (see chain_kernel.h)
-bool rip_chain_supported(int nplanes, int G, int k_dtype, int gain_dtype) {
+bool rip_chain_supported(const rip_ctx *ctx, int nplanes, int G, int k_dtype, int gain_dtype) {
     if (gain_dtype != RIP_F32) return false;
     if (nplanes != 4 && nplanes != 9 && nplanes != 11) return false;
-    if (G != 6 && G != 8 && !(G == 16 && k_dtype == RIP_F32)) return false;
+    if (G != 6 && G != 8 && G != 16) return false;
+    if (G == 16 && k_dtype == RIP_F64 && !ctx->use_chain3) return false;  // that combination: wave-private kernel only
     return true;
 }
 
+#define C3_DECL(np)                                                                        \
+    int rip_launch_chain3_np##np(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a);   \
+    int rip_launch_chain3_k64_np##np(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a);
+C3_DECL(4)
+C3_DECL(9)
+C3_DECL(11)
+#undef C3_DECL
+
 int rip_launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int nplanes, int k_dtype) {
+    // wave-private kernel (chain3_kernel.h) first; 1 = no instantiation for this plan
+    if (ctx->use_chain3 && (nplanes == 4 || nplanes == 9 || nplanes == 11)) {
+        const bool k64 = k_dtype == RIP_F64;
+        int rc = 1;
+        if (nplanes == 4) rc = k64 ? rip_launch_chain3_k64_np4(ctx, plan, a) : rip_launch_chain3_np4(ctx, plan, a);
+        if (nplanes == 9) rc = k64 ? rip_launch_chain3_k64_np9(ctx, plan, a) : rip_launch_chain3_np9(ctx, plan, a);
+        if (nplanes == 11) rc = k64 ? rip_launch_chain3_k64_np11(ctx, plan, a) : rip_launch_chain3_np11(ctx, plan, a);
+        if (rc != 1) {
+            ctx->last_form = 3;
+            return rc;
+        }
+    }
     switch (nplanes) {
         case 4:
             return rip_launch_chain_np4(ctx, plan, a, k_dtype);

@@ -1,0 +1,10 @@
+// Wave-private fused kernel (chain3_kernel.h), f64 ipc4d coefficients (the reference's production writer), 9 Legendre planes.
+#include "chain3_kernel.h"
+
+// returns the launch status, or 1 when no instantiation fits (the caller falls back to the other fused kernels)
+int rip_launch_chain3_k64_np9(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
+    if (a.ngrp == 8) return launch_chain3<9, 8, double>(ctx, plan, a);
+    if (a.ngrp == 6) return launch_chain3<9, 6, double>(ctx, plan, a);
+    if (a.ngrp == 16) return launch_chain3<9, 16, double>(ctx, plan, a);
+    return 1;
+}

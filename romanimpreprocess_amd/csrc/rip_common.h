@@ -119,7 +119,8 @@ struct rip_ctx {
     int parity = 0;
     bool use_overlap = true;
     bool use_chain2 = true;  // wave-specialised fused kernel where it applies
-    int last_form = 0;       // diagnostic: how the last rip_calibrate ran (0 stage kernels, 1 general fused, 2 specialised)
+    bool use_chain3 = true;  // wave-private fused kernel (chain3_kernel.h) where it applies; takes precedence
+    int last_form = 0;       // diagnostic: how the last rip_calibrate ran (0 stage kernels, 1 general fused, 2 wave-specialised, 3 wave-private)
     std::string err;
     std::vector<RipCal> cals;
     std::vector<RipPlan *> plans;
@@ -219,7 +220,7 @@ struct ChainArgs {
     int dbg;           // timing experiments only (rip_set_option "chain_dbg"): skips phases, results invalid
     int ny, nx, nb, ngrp;
 };
-bool rip_chain_supported(int nplanes, int G, int k_dtype, int gain_dtype);
+bool rip_chain_supported(const rip_ctx *ctx, int nplanes, int G, int k_dtype, int gain_dtype);
 int rip_launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int nplanes, int k_dtype);
 
 // ipc.hip

@@ -294,14 +294,15 @@ def _tile_active_rows(strip, nya, axis):
 
 
 def make_tiled_inputs(ny=pars.nside, nx=pars.nside, read_pattern=None, p_order=8, seed=1, strip_rows=256,
-                      gain_dtype=np.float32, ipc_dtype=np.float32, cr_frac=1e-3, nb=pars.nborder):
+                      gain_dtype=np.float32, ipc_dtype=np.float32, cr_frac=1e-3, nb=pars.nborder, ramp_seed=None):
     """(cal, ramp) at full frame size, synthesised on a (strip_rows + 2*nb)-row strip and repeated down the
-    frame (seconds instead of minutes on the host; same per-pixel statistics, same dtypes and shapes)."""
+    frame (seconds instead of minutes on the host; same per-pixel statistics, same dtypes and shapes).
+    ``ramp_seed``: seed of the ramp alone (several ramps on one calibration set)."""
     rp = READ_PATTERN_8 if read_pattern is None else read_pattern
     sy = min(strip_rows + 2 * nb, ny)
     cal_s = make_caldir(sy, nx, read_pattern=rp, p_order=p_order, seed=1000 + seed, gain_dtype=gain_dtype,
                         ipc_dtype=ipc_dtype, nb=nb)
-    ramp_s = make_ramp(cal_s, read_pattern=rp, seed=seed, cr_frac=cr_frac, nb=nb)
+    ramp_s = make_ramp(cal_s, read_pattern=rp, seed=seed if ramp_seed is None else ramp_seed, cr_frac=cr_frac, nb=nb)
     if sy == ny:
         return cal_s, ramp_s
     nya = ny - 2 * nb

@@ -2,6 +2,7 @@
 
 import numpy as np
 import pytest
+import torch  # before libromanhip is loaded: torch brings its own copy of the HIP runtime, and the first one loaded must be the one both use
 from conftest import assert_same_bits, gpu_context
 
 import oracle
@@ -202,8 +203,20 @@ def test_calibrateimage_files_end_to_end(tmp_path):
         gen_cal_image.calibrateimage(dict(config, romancal_ramp_fit=True), verbose=False)
 
 
-# ---- the wave-specialised fused kernel (chain2_kernel.h): every instantiation the dispatcher can pick, and the seams
-# between its column strips / row ranges
+# ---- the specialised fused kernels (wave-private chain3_kernel.h, wave-specialised chain2_kernel.h): every instantiation the
+# dispatcher can pick, and the seams between their column strips / row ranges
+
+
+def _set_form(ctx, form):
+    """3: wave-private fused kernel, 2: wave-specialised, 1: general fused, 0: stage kernels"""
+    ctx.set_option("fused", 1 if form else 0)
+    ctx.set_option("chain3", 1 if form == 3 else 0)
+    ctx.set_option("chain2", 1 if form >= 2 else 0)
+
+
+def _default_form(ctx):
+    _set_form(ctx, 3)
+
 
 SPECIALISED = [
     # name, (ny, nx), read pattern, p_order (NP = p + 1 planes), exclude_first, ipc4d dtype
@@ -219,15 +232,20 @@ SPECIALISED = [
     ("g8_np11_start0_k64", (40, 256), synth.READ_PATTERN_8, 10, False, np.float64),
     ("g6_np4_start1_k64", (48, 128), synth.READ_PATTERN_6, 3, True, np.float64),
     ("g6_np9_start0_k64", (40, 256), synth.READ_PATTERN_6, 8, False, np.float64),
+    # f64 ipc4d x 16 groups: wave-private kernel only
+    ("g16_np9_start1_k64", (40, 256), synth.READ_PATTERN_16, 8, True, np.float64),
+    ("g16_np11_start0_k64", (32, 256), synth.READ_PATTERN_16, 10, False, np.float64),
 ]
 
 
+@pytest.mark.parametrize("form", [3, 2])
 @pytest.mark.parametrize("name,shape,rp,p,exclude_first,kdt", SPECIALISED)
-def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first, kdt):
+def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first, kdt, form):
     ny, nx = shape
+    if form == 2 and len(rp) == 16 and kdt is np.float64:
+        pytest.skip("not instantiated for the wave-specialised kernel")
     ctx = gpu_context()
-    ctx.set_option("fused", 1)
-    ctx.set_option("chain2", 1)
+    _set_form(ctx, form)
     cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=p, seed=91, bias_amplitude=2.0, bad_lin_frac=0.01,
                             ipc_dtype=kdt)
     # degenerate gains: the waves holding them leave the shared-reciprocal division for the division operator
@@ -241,7 +259,8 @@ def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first, kdt):
     cb.load_caldir(4, cal)
     lines = _oracle_lines(ref, len(rp), nx // 128)
     got = cb.calibrate(4, ramp, exclude_first=exclude_first, want_cube=True, channel_lines=lines)
-    assert ctx.last_chain_form() == 2, "the wave-specialised kernel did not run"
+    assert ctx.last_chain_form() == form, "the requested fused kernel did not run"
+    _default_form(ctx)
     assert_same_bits(got["cube"], ref["data"], "corrected cube", zero_sign_ok=True)
     assert_same_bits(got["groupdq"], ref["groupdq"], "groupdq")
     assert_same_bits(got["pixeldq"], ref["pixeldq"], "pixeldq")
@@ -253,8 +272,9 @@ def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first, kdt):
 
 @pytest.mark.parametrize("kdt", [np.float32, np.float64])
 def test_fused_forms_agree_across_seams(kdt):
-    """A frame wider than several 252-column strips and taller than several row ranges: the wave-specialised kernel, the
-    general fused kernel and the stage kernels must give identical bits (halo columns, range boundaries, frame edges)."""
+    """A frame wider than several column strips and taller than several row ranges: the wave-private kernel, the
+    wave-specialised kernel, the general fused kernel and the stage kernels must give identical bits (halo columns, range
+    boundaries, frame edges)."""
     rp = synth.READ_PATTERN_8
     ny, nx = 1160, 896
     cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=31, bias_amplitude=2.0, bad_lin_frac=0.005,
@@ -265,17 +285,15 @@ def test_fused_forms_agree_across_seams(kdt):
     cb.load_caldir(5, cal)
     outs = []
     try:
-        for fused, chain2 in ((1, 1), (1, 0), (0, 0)):
-            ctx.set_option("fused", fused)
-            ctx.set_option("chain2", chain2)
+        for form in (3, 2, 1, 0):
+            _set_form(ctx, form)
             outs.append(cb.calibrate(5, ramp, want_cube=True))
-            assert ctx.last_chain_form() == {(1, 1): 2, (1, 0): 1, (0, 0): 0}[(fused, chain2)]
+            assert ctx.last_chain_form() == form
     finally:
-        ctx.set_option("fused", 1)
-        ctx.set_option("chain2", 1)
-    for other, label in ((outs[1], "general fused"), (outs[2], "stage kernels")):
+        _default_form(ctx)
+    for other, label in ((outs[1], "wave-specialised"), (outs[2], "general fused"), (outs[3], "stage kernels")):
         for k in ("cube", "slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
-            assert_same_bits(outs[0][k], other[k], f"{k}: specialised vs {label}")
+            assert_same_bits(outs[0][k], other[k], f"{k}: wave-private vs {label}")
     assert np.count_nonzero(outs[0]["pixeldq"] & 4) > 1000 and np.count_nonzero(outs[0]["pixeldq"] & 2) > 100
     cb.ctx.drop_caldir(5)
 
@@ -330,10 +348,9 @@ def test_full_frame_4096x4096x8_vs_oracle_and_between_forms(kdt):
     cb = pipeline.Calibrator(ctx=ctx)
     cb.load_caldir(6, cal)
     try:
-        ctx.set_option("fused", 1)
-        ctx.set_option("chain2", 1)
+        _default_form(ctx)
         got = cb.calibrate(6, ramp, channel_lines=_oracle_lines(ref, len(rp), n // 128))
-        assert ctx.last_chain_form() == 2
+        assert ctx.last_chain_form() == 3
         assert_same_bits(got["groupdq"], ref["groupdq"], "groupdq")
         assert_same_bits(got["pixeldq"], ref["pixeldq"], "pixeldq")
         for k in ("slope", "err_read", "err_poisson"):
@@ -342,19 +359,17 @@ def test_full_frame_4096x4096x8_vs_oracle_and_between_forms(kdt):
         assert frac_good > 0.9 and np.count_nonzero(got["pixeldq"] & 4) > 10000
         del ref
         outs = []
-        for fused, chain2 in ((1, 1), (1, 0), (0, 0)):
-            ctx.set_option("fused", fused)
-            ctx.set_option("chain2", chain2)
+        for form in (3, 2, 1, 0):
+            _set_form(ctx, form)
             outs.append(cb.calibrate(6, ramp))
-        for other, label in ((outs[1], "general fused"), (outs[2], "stage kernels")):
+        for other, label in ((outs[1], "wave-specialised"), (outs[2], "general fused"), (outs[3], "stage kernels")):
             for k in ("slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
-                assert_same_bits(outs[0][k], other[k], f"{k}: specialised vs {label}")
+                assert_same_bits(outs[0][k], other[k], f"{k}: wave-private vs {label}")
         # device-fitted lines against LAPACK's: flags identical, slopes within the north-star tolerance
         assert_same_bits(outs[0]["pixeldq"], got["pixeldq"], "pixeldq (device lines)")
         np.testing.assert_allclose(outs[0]["slope"], got["slope"], rtol=1e-5, atol=1e-7)
     finally:
-        ctx.set_option("fused", 1)
-        ctx.set_option("chain2", 1)
+        _default_form(ctx)
         cb.ctx.drop_caldir(6)
 
 
@@ -406,8 +421,7 @@ def test_unusual_group_counts_vs_oracle(name, rp, exclude_first):
     ramp = synth.make_ramp(cal, read_pattern=rp, seed=62, cr_frac=0.03)
     ref = oracle.calibrate_arrays(ramp, cal, exclude_first=exclude_first)
     ctx = gpu_context()
-    ctx.set_option("fused", 1)
-    ctx.set_option("chain2", 1)
+    _default_form(ctx)
     cb = pipeline.Calibrator(ctx=ctx)
     cb.load_caldir(8, cal)
     got = cb.calibrate(8, ramp, exclude_first=exclude_first, want_cube=True, channel_lines=_oracle_lines(ref, len(rp), nx // 128))
@@ -444,3 +458,63 @@ def test_batch_of_host_ramps_equals_single_calls(flag_sat):
             assert_same_bits(a[k], b[k], f"ramp {i}: {k}")
     assert cb.calibrate_many(2, []) == []
     cb.ctx.drop_caldir(2)
+
+
+@pytest.mark.parametrize("flag_sat", [False, True])
+def test_back_to_back_device_calls_without_sync(flag_sat):
+    """Different device-resident ramps issued back to back with no synchronisation in between (the reference-pixel pre-pass and
+    the saturation pass of call n+1 run ahead on the second stream while the chain of call n is still reading ITS tables and
+    flag copies: they are double-buffered by call parity, api.hip): results must equal those of synchronised single calls."""
+    dev = torch.device("cuda", 0)
+    rp = synth.READ_PATTERN_8
+    ny, nx = 1024, 1024
+    cal, _ = synth.make_tiled_inputs(ny, nx, read_pattern=rp, p_order=8, seed=3, strip_rows=64)
+    cal = dict(cal)
+    thr = np.full((ny, nx), 50000.0, np.float32)
+    cal["saturation"] = {"data": thr, "dq": np.zeros((ny, nx), np.uint32)}
+    ctx = gpu_context()
+    _default_form(ctx)
+    cb = pipeline.Calibrator(ctx=ctx)
+    cb.load_caldir(9, cal)
+    pid, _meta = cb.plan_for(rp, synth.FRAME_TIME)
+
+    def to_dev(a):
+        a = np.ascontiguousarray(a)
+        view = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32}.get(a.dtype)
+        return torch.from_numpy(a.view(view) if view else a).to(dev)
+
+    n = 5
+    ramps = []
+    for i in range(n):
+        _, r = synth.make_tiled_inputs(ny, nx, read_pattern=rp, p_order=8, seed=3, strip_rows=64, ramp_seed=100 + i)
+        g = r["groupdq"].copy()
+        g[0] |= 1
+        # distinct reference-output levels: the row corrections of consecutive ramps differ by much more than rounding
+        a33 = (r["amp33"].astype(np.int32) + 40 * i * (np.arange(ny)[None, :, None] % 7)).astype(np.uint16)
+        ramps.append([to_dev(r["data"]), to_dev(a33), None if flag_sat else to_dev(g), to_dev(r["pixeldq"])])
+    outs = [[torch.empty((ny, nx), dtype=torch.float32, device=dev) for _ in range(3)] +
+            [torch.empty((ny, nx), dtype=torch.int32, device=dev), torch.empty((8, ny, nx), dtype=torch.uint8, device=dev)]
+            for _ in range(2 * n)]
+    torch.cuda.synchronize()
+
+    def call(i, o):
+        t = ramps[i]
+        cb.calibrate_device(9, pid, 8, t[0].data_ptr(), True, t[1].data_ptr(), None if t[2] is None else t[2].data_ptr(),
+                            t[3].data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(),
+                            flag_saturation=flag_sat)
+
+    try:
+        for i in range(n):          # reference: one call at a time
+            call(i, outs[i])
+            cb.synchronize()
+        for rep in range(3):        # asynchronous: all calls queued, one synchronisation at the end
+            for i in range(n):
+                call(i, outs[n + i])
+            cb.synchronize()
+            for i in range(n):
+                for k, name in enumerate(("slope", "err_read", "err_poisson", "pixeldq", "groupdq")):
+                    assert torch.equal(outs[i][k], outs[n + i][k]), f"ramp {i} {name}: queued call differs (repeat {rep})"
+        # the ramps do differ from one another (otherwise the test could not see a stale table)
+        assert not torch.equal(outs[0][0], outs[1][0])
+    finally:
+        cb.ctx.drop_caldir(9)
