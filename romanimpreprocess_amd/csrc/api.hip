@@ -700,13 +700,13 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     // overlaps the previous ramp's main kernel; the tables are double-buffered by call parity:
     //   stream2: wait(main kernels of call n-2 done) -> pre-pass -> ev_tab[p]
     //   stream : wait(ev_tab[p]) -> main kernels -> ev_done[p]
-    const size_t tab_bytes = ((size_t)G * ny * 8 + (size_t)G * nch * 16 + 255) / 256 * 256;
+    const size_t tab_bytes = ((size_t)2 * G * ny * 8 + (size_t)G * nch * 16 + 255) / 256 * 256;  // rowcorr, its transpose, lines
     char *ws3 = (do_ref || (do_fit && (stages & RIP_STAGE_FLAT) && c.has_flat && d_area))
                     ? (char *)rip_ws(ctx, 3, 2 * tab_bytes + npix * 4 + 512)
                     : nullptr;
     const int par = ctx->parity;
     const bool overlap = do_ref && !host && ctx->use_overlap;
-    double *rowcorr = nullptr, *lines = nullptr;
+    double *rowcorr = nullptr, *rowcorr_t = nullptr, *lines = nullptr;
     // dq-init + saturation flagging into workspace copies of the flag arrays (the caller's inputs stay untouched), double
     // buffered by call parity like the reference-pixel tables because the pass may run ahead on the second stream
     auto sat_pass = [&]() -> int {
@@ -728,9 +728,10 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         if (!ws3) return RIP_ENOMEM;
         if (c.has_amp33 && !d_a33) return rip_fail(ctx, RIP_EINVAL, "calibrate: the read file has amp33 but the ramp has none");
         rowcorr = (double *)(ws3 + (size_t)par * tab_bytes);
-        lines = rowcorr + (size_t)G * ny;
+        rowcorr_t = rowcorr + (size_t)G * ny;
+        lines = rowcorr_t + (size_t)G * ny;
         RefpixArgs ra{d_data, in->data_dtype, c.dark_data, c.has_amp33 ? d_a33 : nullptr, c.amp33_med, c.refout_slope,
-                      d_lines_ovr, rowcorr, lines, ny, nx, G};
+                      d_lines_ovr, rowcorr, rowcorr_t, lines, ny, nx, G};
         hipStream_t main_stream = ctx->stream;
         if (overlap) {
             if (ctx->ev_done_valid[par]) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_done[par], 0));
@@ -784,6 +785,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         ca.pdq = d_pdq;
         ca.dark_data = c.dark_data;
         ca.rowcorr = rowcorr;
+        ca.rowcorr_t = rowcorr_t;
         ca.lines = lines;
         ca.bias = c.bias + (size_t)(c.ngrp_bias - G) * npix;
         ca.planes = c.slab;

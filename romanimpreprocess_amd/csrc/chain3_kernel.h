@@ -15,13 +15,18 @@
 //   * Per step (new raw row yi): A = reference-pixel apply + bias + Legendre linearity of row yi -> x = gain * phi;
 //     C = first Neumann iterate of row yi-1; O2 = second iterate of row r = yi-2 / gain -> the pixel's ramp in registers;
 //     F/T = ramp fit with jump detection, saturated refits, flag propagation, finish, stores of pixel (r, c).
-//     The raw loads of row yi+1 and the coefficients of the next step are issued between O2 and F.
+//     The raw loads of row yi+1 are issued right after A (their registers are free then), the coefficients of the next
+//     step after O2.  The channel lines and the dense fit table are staged in LDS once per workgroup, the row
+//     corrections of the next row come with one wide scalar load a step ahead: no serialised scalar-memory round trips
+//     inside the row loop besides the kernel arguments.
 //   * The arithmetic of every phase is that of chain2_kernel.h / chain_kernel.h (validated bit for bit against the oracle);
 //     only the data movement differs.
 //
 // A workgroup is C3_NW waves on adjacent strips (same rows): they touch neighbouring cache lines at about the same time.
 // The grid is exactly resident; the row ranges are equal.
 #pragma once
+#include <algorithm>
+
 #include "chain2_kernel.h"
 
 #ifndef C3_NW
@@ -30,6 +35,11 @@
 #ifndef C3_WPS   // waves per SIMD the 8-group f32 instantiation is compiled for (register budget 512 / C3_WPS)
 #define C3_WPS 3
 #endif
+#ifndef C3_NBATCH   // groups the forward operator evaluates in lockstep (2 or 4)
+#define C3_NBATCH 2
+#endif
+// groups whose raw values are prefetched one step ahead (the rest are requested at the top of their own step)
+#define C3_GEARLY (G / 2)
 #define C3_OUTW 60
 #define C3_THREADS (64 * C3_NW)
 // One s_barrier per row step keeps the waves of a workgroup within a row of each other: neighbouring strips share cache lines
@@ -70,27 +80,66 @@ struct C3KSet {
     T m[3], z[3], p[3];
 };
 
-// forward IPC operator at the destination lane from the three source rows held by the lane and its neighbours.
+// forward IPC operator at the destination lane from the three source rows held by the lane and its neighbours, for NB
+// groups in lockstep: the NB products of a term are formed first, then the NB accumulating adds (a DPP operand may not be
+// read within two wait states of the instruction that wrote it; NB independent chains also hide the add latency).
 // Term order and edge rule of ipc_linearity.py:69-94; bit k of `valid` = term k exists (ALL: every term does).
-template <typename T, bool ALL>
-__device__ __forceinline__ T c3_fwd(T vm, T v0, T vp, const C3KSet<T> &k, unsigned valid) {
-    T acc = v0 * k.z[1];
-#define C3_TERM(kk, expr)                                  \
-    {                                                      \
-        const T t_ = (expr);                               \
-        acc = (ALL || ((valid >> kk) & 1u)) ? acc + t_ : acc; \
+template <typename T, bool ALL, int NB>
+__device__ __forceinline__ void c3_fwd(const T (&vm)[NB], const T (&v0)[NB], const T (&vp)[NB], const C3KSet<T> &k,
+                                       unsigned valid, T (&acc)[NB]) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = v0[b] * k.z[1];
+#define C3_TERM(kk, src, coef, SHIFT)                                                   \
+    {                                                                                   \
+        T t_[NB];                                                                       \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b) t_[b] = src[b] * (coef);         \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                \
+            const T s_ = SHIFT(t_[b]);                                                  \
+            acc[b] = (ALL || ((valid >> kk) & 1u)) ? acc[b] + s_ : acc[b];              \
+        }                                                                               \
     }
-    C3_TERM(1, vm * k.m[1])
-    C3_TERM(2, vp * k.p[1])
-    C3_TERM(3, c3_shr(v0 * k.z[2]))
-    C3_TERM(4, c3_shl(v0 * k.z[0]))
-    C3_TERM(5, c3_shr(vm * k.m[2]))
-    C3_TERM(6, c3_shl(vm * k.m[0]))
-    C3_TERM(7, c3_shr(vp * k.p[2]))
-    C3_TERM(8, c3_shl(vp * k.p[0]))
+#define C3_ID(x) (x)
+    C3_TERM(1, vm, k.m[1], C3_ID)
+    C3_TERM(2, vp, k.p[1], C3_ID)
+    C3_TERM(3, v0, k.z[2], c3_shr)
+    C3_TERM(4, v0, k.z[0], c3_shl)
+    C3_TERM(5, vm, k.m[2], c3_shr)
+    C3_TERM(6, vm, k.m[0], c3_shl)
+    C3_TERM(7, vp, k.p[2], c3_shr)
+    C3_TERM(8, vp, k.p[0], c3_shl)
+#undef C3_ID
 #undef C3_TERM
-    return acc;
 }
+
+template <int N>
+struct C3Int {
+    static constexpr int value = N;
+};
+
+// the dense fit table of the plan, staged in LDS by the kernel (device_rampfit.h: fit_full_pk_a_t)
+#define C3_MAXG 16  // the kernel is instantiated for at most 16 groups
+struct __attribute__((aligned(16))) C3FitTab {
+    float k2[C3_MAXG];
+    RipDensePair pairs[C3_MAXG];
+    float amin;
+    uint32_t valid;
+    float pad_[2];
+};
+template <int G>
+struct C3DenseLds {
+    const C3FitTab *t;
+    float k2v[G];  // the slope weights: loop-invariant scalars, read once before the row loop
+    __device__ __forceinline__ float k2(int i) const { return k2v[i]; }
+    __device__ __forceinline__ uint32_t valid() const { return t->valid; }
+    __device__ __forceinline__ float amin() const { return t->amin; }
+    __device__ __forceinline__ void pair(RipDensePair &r, int ps) const {
+        typedef float f4_ __attribute__((ext_vector_type(4)));
+        const f4_ *p = reinterpret_cast<const f4_ *>(&t->pairs[ps]);  // 32 B, 16-byte aligned in C3FitTab
+        const f4_ a = p[0], b = p[1];
+        r.inv_dt[0] = a[0], r.inv_dt[1] = a[1], r.A[0] = a[2], r.A[1] = a[3];
+        r.B[0] = b[0], r.B[1] = b[1], r.k1[0] = b[2], r.k1[1] = b[3];
+    }
+};
 
 template <int NP, int G, int START, typename KT, int WPS>
 __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
@@ -103,13 +152,25 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     constexpr bool K64 = sizeof(KT) == 8;
     using T = KT;                                    // dtype of the Neumann iterates (numpy promotion f32 * KT)
     constexpr int NCH = (C3_NW * C3_OUTW + 4 + 126) / 128 + 1;  // channels a workgroup's columns can touch
-    __shared__ double LN[NCH * G * 2];               // channel lines (m, c) of those channels, read-only after the fill
     constexpr int GQ = (G + 3) / 4;                  // 16-byte units of four f32 values per pixel
+    constexpr int XQ = GQ;                           // x-ring units per row
+    constexpr int WQ = 1 + (QW > 2 ? 1 : 0);         // units of a row's small words {gain, lin dq, groupdq bytes}
     constexpr int OQ = K64 ? G / 2 : GQ;             // 16-byte units of the first iterate (two doubles or four floats)
     typedef float c3_f4 __attribute__((ext_vector_type(4)));
     typedef double c3_d2 __attribute__((ext_vector_type(2)));
-    __shared__ c3_f4 XR[C3_NW][2][GQ][64];           // x = gain * phi of the two previous rows, slot = row & 1
-    __shared__ c3_f4 OR_[C3_NW][2][OQ][64];          // first iterate of the two previous rows (c3_d2 view for f64 ipc4d)
+    // LDS (dynamic; chain3_lds_bytes):  XR  [C3_NW][3][XQ][64] x 16 B   x = gain * phi of rows yi-2, yi-1, yi, slot = row mod 3
+    //                                   WR  [C3_NW][2][WQ][64] x 16 B   gain, linearity dq and packed groupdq bytes of rows yi-2 / yi (the
+    //                                                                   slot is read, then rewritten), yi-1; slot = row & 1
+    //                                   OR_ [C3_NW][2][OQ][64] x 16 B   first iterate of the two previous rows
+    //                                   FT  C3FitTab                    dense fit table of the plan
+    //                                   LN  [NCH][G][2] f64             channel lines (m, c) of the workgroup's channels
+    // the last two are read-only after the fill (one barrier), the rings are private to their wave
+    extern __shared__ __align__(16) unsigned char c3_lds[];
+    c3_f4 *const XR = reinterpret_cast<c3_f4 *>(c3_lds);
+    c3_f4 *const OR_ = XR + C3_NW * 3 * XQ * 64;
+    c3_f4 *const WR = OR_ + C3_NW * 2 * OQ * 64;
+    C3FitTab *const FT = reinterpret_cast<C3FitTab *>(WR + C3_NW * 2 * WQ * 64);
+    double *const LN = reinterpret_cast<double *>(FT + 1);
 
     const RIP_K C2KernArgs *kargs = (const RIP_K C2KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const int tid = threadIdx.x;
@@ -141,7 +202,20 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     const int ch0 = max(wgx * C3_NW * C3_OUTW - 2, 0) / RIP_CW;
     for (int i = tid; i < NCH * G * 2; i += C3_THREADS) {
         const int ch = i / (G * 2), g = (i / 2) % G, w = i & 1;
-        LN[i] = (ch0 + ch < nch && a.lines) ? a.lines[(g * nch + ch0 + ch) * 2 + w] : 0.0;
+        LN[i] = (ch0 + ch < nch) ? a.lines[(g * nch + ch0 + ch) * 2 + w] : 0.0;
+    }
+    for (int i = tid; i < (int)(sizeof(C3FitTab) / 4); i += C3_THREADS) {
+        uint32_t v = 0;
+        constexpr int o_pairs = C3_MAXG, o_amin = o_pairs + C3_MAXG * 8;
+        if (i < o_pairs)
+            v = __float_as_uint(a.dense->K2[i]);
+        else if (i < o_amin)
+            v = reinterpret_cast<const uint32_t *>(a.dense->pairs)[i - o_pairs];
+        else if (i == o_amin)
+            v = __float_as_uint(a.dense->amin);
+        else if (i == o_amin + 1)
+            v = a.dense->valid;
+        reinterpret_cast<uint32_t *>(FT)[i] = v;
     }
     __syncthreads();
     if ((int)blockIdx.x >= nwgx * nranges || R0 >= ny || strip >= nstrips) return;
@@ -154,7 +228,7 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     const bool emit_lane = lane >= 2 && lane < 62 && col_ok;
     const bool edge_wave = (strip * C3_OUTW - 2 < 0) || (strip * C3_OUTW + 62 > nx);  // wave-uniform: some lane is off the frame
     const unsigned cc4 = (unsigned)cc * 4u, cc2 = (unsigned)cc * 2u, cc1 = (unsigned)cc;
-    const unsigned ccK = (unsigned)cc * (unsigned)sizeof(KT);
+    const unsigned ccK = K64 ? cc4 * 2u : cc4;
     unsigned colmask = 0;  // bit k: the source column of term k is in the active box (and so is c)
     {
 #pragma unroll
@@ -174,13 +248,14 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     };
 
     // ---- loaders (buffer loads: scalar base + plane/row scalar offset + loop-invariant per-lane column offset)
-    auto fetch_groups = [&](const RIP_K ChainArgs *ka, int y, RowRegs<NP, G> &rr) {
+    auto fetch_groups = [&](const RIP_K ChainArgs *ka, int y, RowRegs<NP, G> &rr, int g_lo, int g_hi) {
         const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
         const __amdgpu_buffer_rsrc_t rs = c2_rsrc(ka->data), rq = c2_rsrc(ka->gdq), rd = c2_rsrc(ka->dark_data),
                                      rb = c2_rsrc(ka->bias);
-        unsigned o4 = yl * row4, o2 = yl * (row4 >> 1), o1 = yl * (row4 >> 2);
+        unsigned o4 = yl * row4 + (unsigned)g_lo * pl4, o2 = yl * (row4 >> 1) + (unsigned)g_lo * (pl4 >> 1),
+                 o1 = yl * (row4 >> 2) + (unsigned)g_lo * npix;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
+        for (int g = g_lo; g < g_hi; ++g) {
             rr.S[g] = c2_ld_u16<0>(rs, cc2, o2);
             rr.q[g] = c2_ld_u8<0>(rq, cc1, o1);
             rr.dk[g] = c2_ld_f32<0>(rd, cc4, o4);
@@ -229,31 +304,33 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     const RipVariant v0 = rip_load_variant(vars, 0);
     const RipFitConst fc0 = rip_fit_const(h);
     constexpr int start = START;
+    C3DenseLds<G> dtab;
+    dtab.t = FT;
+#pragma unroll
+    for (int t = 0; t < G; ++t) dtab.k2v[t] = KLD(a.dense->K2[t]);
 
-    // ---- rolling state of the march.  Registers: the coefficient sets and the small per-row words; LDS (private to the
-    // wave): x of rows yi-2, yi-1 and the first iterate of rows yi-3, yi-2, slot = row & 1
-    uint32_t dq_m = 0, dq_0 = 0;           // linearity dq of rows yi-2, yi-1
-    uint32_t qw_m[QW], qw_0[QW];           // packed groupdq bytes of rows yi-2, yi-1
-    float gain_m = 1.0f, gain_0 = 1.0f;    // gain of rows yi-2, yi-1
+    // ---- rolling state of the march.  Registers: the two coefficient sets; LDS (private to the wave): x and the small
+    // per-row words of rows yi-2, yi-1, yi, the first iterate of rows yi-3, yi-2
     C3KSet<T> kO, kC;                      // coefficient sets of destination rows yi-2 (second iterate), yi-1 (first)
 #pragma unroll
-    for (int i = 0; i < QW; ++i) qw_m[i] = qw_0[i] = 0;
-#pragma unroll
     for (int j = 0; j < 3; ++j) kO.m[j] = kO.z[j] = kO.p[j] = kC.m[j] = kC.z[j] = kC.p[j] = (T)0;
-    c3_f4 *const xr = &XR[wv][0][0][lane];    // [slot * GQ * 64 + q * 64]
-    c3_f4 *const orr = &OR_[wv][0][0][lane];  // [slot * OQ * 64 + q * 64]
+    c3_f4 *const xr = XR + wv * 3 * XQ * 64 + lane;    // [slot * XQ * 64 + q * 64]
+    c3_f4 *const orr = OR_ + wv * 2 * OQ * 64 + lane;  // [slot * OQ * 64 + q * 64]
+    c3_f4 *const wr = WR + wv * 2 * WQ * 64 + lane;    // [slot * WQ * 64 + q * 64]
 #pragma unroll
-    for (int i = 0; i < 2 * GQ; ++i) xr[i * 64] = c3_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < 3 * XQ; ++i) xr[i * 64] = c3_f4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < 2 * OQ; ++i) orr[i * 64] = c3_f4{0.0f, 0.0f, 0.0f, 0.0f};
-    // ring access (G values of one row; compile-time unrolled)
-    auto ld_x = [&](int slot, float (&v)[G]) {
 #pragma unroll
-        for (int q = 0; q < GQ; ++q) {
-            const c3_f4 t = xr[(slot * GQ + q) * 64];
+    for (int i = 0; i < 2 * WQ; ++i) wr[i * 64] = c3_f4{1.0f, 0.0f, 0.0f, 0.0f};
+    // ring access, NB groups starting at group g0 (compile-time unrolled; NB * sizeof(value) is a multiple of 16 B except for
+    // the last unit of a 6-group ramp, which is padded)
+    auto ld_x = [&](int slot, int g0, auto &v, auto nb_tag) {
+        constexpr int NBB = decltype(nb_tag)::value;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * q + e < G) v[4 * q + e] = t[e];
+        for (int b = 0; b < NBB; ++b) {  // (one 16-byte read per unit: identical reads are merged)
+            const c3_f4 t = xr[(slot * XQ + (g0 + b) / 4) * 64];
+            v[b] = t[(g0 + b) & 3];
         }
     };
     auto st_x = [&](int slot, const float (&v)[G]) {
@@ -262,25 +339,38 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
             c3_f4 t;
 #pragma unroll
             for (int e = 0; e < 4; ++e) t[e] = (4 * q + e < G) ? v[4 * q + e] : 0.0f;
-            xr[(slot * GQ + q) * 64] = t;
+            xr[(slot * XQ + q) * 64] = t;
         }
     };
-    auto ld_o = [&](int slot, T (&v)[G]) {
+    // the row's small words: {gain, linearity dq, groupdq bytes of groups 0-3, 4-7} (+ {groups 8-11, 12-15, -, -})
+    auto st_w = [&](int slot, float gain, uint32_t dq, const uint32_t (&qw)[QW]) {
+        wr[slot * WQ * 64] = c3_f4{gain, __uint_as_float(dq), __uint_as_float(qw[0]), __uint_as_float(qw[1])};
+        if constexpr (QW > 2)
+            wr[(slot * WQ + 1) * 64] = c3_f4{__uint_as_float(qw[2]), __uint_as_float(QW > 3 ? qw[QW - 1] : 0u), 0.0f, 0.0f};
+    };
+    auto ld_w = [&](int slot, float &gain, uint32_t &dq, uint32_t (&qw)[QW]) {
+        const c3_f4 t = wr[slot * WQ * 64];
+        gain = t[0], dq = __float_as_uint(t[1]), qw[0] = __float_as_uint(t[2]), qw[1] = __float_as_uint(t[3]);
+        if constexpr (QW > 2) {
+            const c3_f4 u = wr[(slot * WQ + 1) * 64];
+            qw[2] = __float_as_uint(u[0]);
+            if constexpr (QW > 3) qw[QW - 1] = __float_as_uint(u[1]);
+        }
+    };
+    auto ld_o = [&](int slot, int g0, auto &v, auto nb_tag) {
+        constexpr int NBB = decltype(nb_tag)::value;
         if constexpr (K64) {
             const c3_d2 *od = reinterpret_cast<const c3_d2 *>(orr);
 #pragma unroll
-            for (int q = 0; q < OQ; ++q) {
-                const c3_d2 t = od[(slot * OQ + q) * 64];
-                v[2 * q] = t[0];
-                v[2 * q + 1] = t[1];
+            for (int b = 0; b < NBB; ++b) {
+                const c3_d2 t = od[(slot * OQ + (g0 + b) / 2) * 64];
+                v[b] = t[(g0 + b) & 1];
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < OQ; ++q) {
-                const c3_f4 t = orr[(slot * OQ + q) * 64];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * q + e < G) v[4 * q + e] = t[e];
+            for (int b = 0; b < NBB; ++b) {
+                const c3_f4 t = orr[(slot * OQ + (g0 + b) / 4) * 64];
+                v[b] = t[(g0 + b) & 3];
             }
         }
     };
@@ -299,39 +389,46 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
             }
         }
     };
+    // groups evaluated in lockstep by the forward operator: a multiple of the ring's 16-byte unit
+    constexpr int NB = (G % C3_NBATCH == 0) ? C3_NBATCH : 2;
+    static_assert(G % NB == 0, "batches");
+    using NbTag = C3Int<NB>;
 
     RowRegs<NP, G> rr;
     {
         const RIP_K ChainArgs *ka = &kargs->a;
         fetch_coefs(ka, R0 - 2, rr);
-        fetch_groups(ka, R0 - 2, rr);
+        fetch_groups(ka, R0 - 2, rr, 0, C3_GEARLY);
         fetch_kset(ka, R0 - 3, kC);  // set of the first step's C (destination row R0-3: not evaluated, loads stay in bounds)
     }
 
+    int sx = 0;  // x-ring slot of row yi-2
+    double rcn[G];  // row corrections of the row the next step ingests (wave-uniform: scalar registers)
+    {
+        const RIP_K double *rt = rip_k(a.rowcorr_t) + (size_t)min(max(R0 - 2, 0), ny - 1) * G;
+#pragma unroll
+        for (int g = 0; g < G; ++g) rcn[g] = rt[g];
+    }
+#ifdef CH_STAMP
+    unsigned long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tl_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int yi = R0 - 2; yi <= R1 + 1; ++yi) {
         const RIP_K C2KernArgs *kf = c2_args(kargs);
         const RIP_K ChainArgs *ka = &kf->a;
         const int yc = yi - 1, r = yi - 2;
         const bool do_c = (yc >= R0 - 1) && (yc <= R1);
         const bool do_e = (r >= R0) && (r < R1);
-        // ---- loads of the finish of pixel (r, c): consumed at the end of the step
         const unsigned rc_ = (unsigned)min(max(r, 0), ny - 1);
         const unsigned t_row = rc_ * row4;
-        const __amdgpu_buffer_rsrc_t rpl = c2_rsrc(ka->planes);
-        const float e_read = c2_ld_f32<0>(rpl, cc4, (unsigned)(NP + 5) * pl4 + t_row);
-        const float e_dark = c2_ld_f32<0>(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_row);
-        const uint32_t e_ff = c2_ld_u32<0>(rpl, cc4, (unsigned)(NP + 8) * pl4 + t_row);
-        const uint32_t e_pdq = c2_ld_u32<0>(c2_rsrc(ka->pdq), cc4, t_row);
-        const float e_flat_raw = c2_ld_f32<0>(c2_rsrc(ka->flat ? (const void *)ka->flat : (const void *)ka->planes), cc4, t_row);
-        const uint32_t e_ddq_raw =
-            c2_ld_u32<0>(c2_rsrc(ka->dark_dq ? (const void *)ka->dark_dq : (const void *)ka->planes), cc4, t_row);
-
-#ifdef C3_EXP_LATE_RAW
-        if (yi > R0 - 2) {
-            fetch_coefs(ka, yi, rr);
-            fetch_groups(ka, yi, rr);
-        }
+        // the raw values of the later groups of row yi: requested here, consumed in the second half of A (the first half
+        // covers part of their latency, the other waves of the SIMD the rest; prefetching them a step ahead like the others
+        // would hold 4 registers per group through C, O2 and the fit)
+        if (C3_GEARLY < G) fetch_groups(ka, yi, rr, C3_GEARLY, G);
+#ifdef CH_STAMP
+        if (a.dbg & 2048) __builtin_amdgcn_s_waitcnt(0);  // exposes what the step still waits for from the previous one
 #endif
+        CH_T(0)
         // =========================================================== A: refpix apply + bias + linearity of row yi
         float xn[G];
         uint32_t dq_n = 0, qw_n[QW];
@@ -340,9 +437,14 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
         for (int i = 0; i < QW; ++i) qw_n[i] = 0;
         const bool a_full = yi >= 0 && yi < ny;  // wave-uniform
         if (a_full) {
-            double rc[G];
+            double rc[G];  // row corrections of this row (scalars, loaded during the previous step)
 #pragma unroll
-            for (int g = 0; g < G; ++g) rc[g] = KLD(ka->rowcorr[g * ny + yi]);
+            for (int g = 0; g < G; ++g) rc[g] = rcn[g];
+            {   // ... and those of the next row: one wide scalar load, consumed a whole step later
+                const RIP_K double *rt = rip_k(ka->rowcorr_t) + (size_t)min(max(yi + 1, 0), ny - 1) * G;
+#pragma unroll
+                for (int g = 0; g < G; ++g) rcn[g] = rt[g];
+            }
             const bool act = col_act && yi >= ay0 && yi < ay1;
             uint32_t dq = rr.dq;
             const float smin = rr.smin;
@@ -485,109 +587,120 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
             for (int g = 0; g < G; ++g) xn[g] = 0.0f;
         }
 
+        CH_T(1)
+        // ---- read noise of pixel (r, c) for the fit, then the raw values of row yi+1 (this row's are consumed; they land while C,
+        // O2 and the fit run)
+        float e_read;
+        {
+            const RIP_K ChainArgs *kb = &c2_args(kargs)->a;
+            e_read = c2_ld_f32<0>(c2_rsrc(kb->planes), cc4, (unsigned)(NP + 5) * pl4 + t_row);
+            fetch_coefs(kb, yi + 1, rr);
+            fetch_groups(kb, yi + 1, rr, 0, C3_GEARLY);
+        }
         // =========================================================== C: first Neumann iterate of row yc
-        // slots: rows yi-2 and yi (same parity) share slot sA, rows yi-1 and yi-3 share slot sB
-        const int sA = yi & 1, sB = sA ^ 1;
-        float xm[G], x0[G];
-        ld_x(sA, xm);
-        ld_x(sB, x0);
+        // x slots rotate with the row (row mod 3); the first iterate has two (row & 1)
+        const int sxm = sx, sx0 = (sx == 2) ? 0 : sx + 1, sxn = (sx0 == 2) ? 0 : sx0 + 1;  // rows yi-2, yi-1, yi
+        sx = sx0;
+        const int sA = yi & 1, sB = sA ^ 1;  // first iterate: rows yi-2 (sA), yi-3 and yi-1 (sB)
+        st_x(sxn, xn);
+        float e_gain;
+        uint32_t lin_dq, qw[QW];
+        ld_w(yi & 1, e_gain, lin_dq, qw);  // row yi-2 ...
+        st_w(yi & 1, gain_n, dq_n, qw_n);  // ... whose slot row yi takes (one wave's LDS operations execute in order)
         T o1n[G];
         {
             const unsigned vC = lane_c & rowbits(yc);
             const bool all = __all(vC == 0x1ffu || vC == 0u);
-            if (do_c && all) {
+            if (do_c) {
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const T f = c3_fwd<T, true>((T)xm[g], (T)x0[g], (T)xn[g], kC, vC);
-                    o1n[g] = (T)(x0[g] + x0[g]) - f;
-                }
-            } else if (do_c) {
+                for (int g0 = 0; g0 < G; g0 += NB) {
+                    float bm[NB], b0[NB];
+                    ld_x(sxm, g0, bm, NbTag{});
+                    ld_x(sx0, g0, b0, NbTag{});
+                    T am[NB], a0[NB], ap[NB], f[NB];
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const T f = c3_fwd<T, false>((T)xm[g], (T)x0[g], (T)xn[g], kC, vC);
-                    o1n[g] = (T)(x0[g] + x0[g]) - f;
+                    for (int b = 0; b < NB; ++b) am[b] = (T)bm[b], a0[b] = (T)b0[b], ap[b] = (T)xn[g0 + b];
+                    if (all)
+                        c3_fwd<T, true, NB>(am, a0, ap, kC, vC, f);
+                    else
+                        c3_fwd<T, false, NB>(am, a0, ap, kC, vC, f);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) o1n[g0 + b] = (T)(b0[b] + b0[b]) - f[b];
                 }
             } else {
 #pragma unroll
                 for (int g = 0; g < G; ++g) o1n[g] = (T)0;
             }
         }
-        st_x(sA, xn);  // row yi takes the slot of row yi-2 (its values are in xm)
+        CH_T(2)
 
         // =========================================================== O2: second iterate of row r, division by the gain
         float d[G];
         f2 dpair[GP];
         const bool act = emit_lane && do_e && col_act && r >= ay0 && r < ay1;
-        const float e_gain = gain_m;
         {
-            T o1m[G], o10[G];
-            ld_o(sB, o1m);  // row yi-3
-            ld_o(sA, o10);  // row yi-2
             const unsigned vO = lane_o & rowbits(r);
             const bool all = __all(vO == 0x1ffu || !act);
-            if constexpr (K64) {
+            const bool fastdiv = __all(rcp_safe(e_gain) || !act);
+            const bool allact = __all(act || !emit_lane);  // interior wave: every lane that emits is active (the others are not read)
+            const float rgain = rip_rcp_mid(e_gain);
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const double f = all ? c3_fwd<double, true>(o1m[g], o10[g], o1n[g], kO, vO)
-                                         : c3_fwd<double, false>(o1m[g], o10[g], o1n[g], kO, vO);
-                    const double o2 = (o10[g] + (double)xm[g]) - f;
-                    d[g] = act ? (float)(o2 / (double)e_gain) : xm[g];
-                }
-            } else {
-                const bool fastdiv = __all(rcp_safe(e_gain) || !act);
-                const float rgain = rip_rcp_mid(e_gain);
-                float o2[G];
-                if (all) {
+            for (int g0 = 0; g0 < G; g0 += NB) {
+                float bx[NB];
+                T am[NB], a0[NB], ap[NB], f[NB], o2[NB];
+                ld_o(sB, g0, am, NbTag{});  // row yi-3
+                ld_o(sA, g0, a0, NbTag{});  // row yi-2
+                ld_x(sxm, g0, bx, NbTag{});
 #pragma unroll
-                    for (int g = 0; g < G; ++g) o2[g] = (o10[g] + xm[g]) - c3_fwd<float, true>(o1m[g], o10[g], o1n[g], kO, vO);
-                } else {
+                for (int b = 0; b < NB; ++b) ap[b] = o1n[g0 + b];
+                if (all)
+                    c3_fwd<T, true, NB>(am, a0, ap, kO, vO, f);
+                else
+                    c3_fwd<T, false, NB>(am, a0, ap, kO, vO, f);
 #pragma unroll
-                    for (int g = 0; g < G; ++g) o2[g] = (o10[g] + xm[g]) - c3_fwd<float, false>(o1m[g], o10[g], o1n[g], kO, vO);
-                }
-                if (fastdiv && __all(act || !emit_lane)) {  // interior wave: every lane that emits is active (the others are not read)
+                for (int b = 0; b < NB; ++b) o2[b] = (a0[b] + (T)bx[b]) - f[b];
+                if constexpr (K64) {
 #pragma unroll
-                    for (int p = 0; p < GP; ++p) {
-                        const f2 q = div_rcp2(f2{o2[2 * p], o2[2 * p + 1]}, e_gain, rgain);
-                        d[2 * p] = q.x;
-                        d[2 * p + 1] = q.y;
-                    }
+                    for (int b = 0; b < NB; ++b) d[g0 + b] = act ? (float)(o2[b] / (double)e_gain) : bx[b];
                 } else if (fastdiv) {
 #pragma unroll
-                    for (int p = 0; p < GP; ++p) {
-                        const f2 q = div_rcp2(f2{o2[2 * p], o2[2 * p + 1]}, e_gain, rgain);
-                        d[2 * p] = act ? q.x : xm[2 * p];
-                        d[2 * p + 1] = act ? q.y : xm[2 * p + 1];
+                    for (int b = 0; b < NB; b += 2) {
+                        const f2 q = div_rcp2(f2{o2[b], o2[b + 1]}, e_gain, rgain);
+                        d[g0 + b] = (allact || act) ? q.x : bx[b];
+                        d[g0 + b + 1] = (allact || act) ? q.y : bx[b + 1];
                     }
                 } else {
 #pragma unroll
-                    for (int g = 0; g < G; ++g) d[g] = act ? o2[g] / e_gain : xm[g];
+                    for (int b = 0; b < NB; ++b) d[g0 + b] = act ? o2[b] / e_gain : bx[b];
                 }
             }
 #pragma unroll
             for (int p = 0; p < GP; ++p) dpair[p] = f2{d[2 * p], d[2 * p + 1]};
             st_o(sB, o1n);  // row yi-1 takes the slot of row yi-3
         }
-        const uint32_t lin_dq = dq_m;
-        uint32_t qw[QW];
-#pragma unroll
-        for (int i = 0; i < QW; ++i) qw[i] = qw_m[i];
-
-        // ---- rotate the per-row words, then request the raw values of row yi+1 and the coefficient set of the next step's C
-        // (destination row yi); the set the second iterate just used is free
-        dq_m = dq_0, dq_0 = dq_n;
-#pragma unroll
-        for (int i = 0; i < QW; ++i) qw_m[i] = qw_0[i], qw_0[i] = qw_n[i];
-        gain_m = gain_0, gain_0 = gain_n;
+        CH_T(3)
+        // ---- request the coefficient set of the next step's C (destination row yi); the set
+        // the second iterate just used is free
         kO = kC;
         {
             const RIP_K ChainArgs *kb = &c2_args(kargs)->a;
             fetch_kset(kb, yi, kC);
-#ifndef C3_EXP_LATE_RAW
-            fetch_coefs(kb, yi + 1, rr);
-            fetch_groups(kb, yi + 1, rr);
-#endif
         }
+        // what the tail of pixel (r, c) reads: lands while the fit runs
+        float e_dark, e_flat_raw;
+        uint32_t e_ff, e_pdq, e_ddq_raw;
+        {
+            const RIP_K ChainArgs *kb = &c2_args(kargs)->a;
+            const __amdgpu_buffer_rsrc_t rpl = c2_rsrc(kb->planes);
+            e_dark = c2_ld_f32<0>(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_row);
+            e_ff = c2_ld_u32<0>(rpl, cc4, (unsigned)(NP + 8) * pl4 + t_row);
+            e_pdq = c2_ld_u32<0>(c2_rsrc(kb->pdq), cc4, t_row);
+            e_flat_raw = c2_ld_f32<0>(c2_rsrc(kb->flat ? (const void *)kb->flat : (const void *)kb->planes), cc4, t_row);
+            e_ddq_raw = c2_ld_u32<0>(c2_rsrc(kb->dark_dq ? (const void *)kb->dark_dq : (const void *)kb->planes), cc4, t_row);
+        }
+        CH_T(4)
         C3_SYNC();
+        CH_T(5)
 
         // =========================================================== F / T: ramp fit, flags, finish, stores of pixel (r, c)
         if (do_e && emit_lane) {
@@ -603,7 +716,8 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
             }
             RipFitState fs;
             const bool unsat = ((qw[(G - 1) / 4] >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
-            fit_full_pk_a<G, rip_full_valid<G, START>()>(dpair, fc0, v0, kg->a.dense, e_gain, e_read, unsat && act, kg->guard, fs);
+            fit_full_pk_a_t<G, rip_full_valid<G, START>(), C3DenseLds<G>>(dpair, fc0, v0, dtab, e_gain, e_read, unsat && act,
+                                                                                  kg->guard, fs);
             uint32_t qor = 0;
 #pragma unroll
             for (int i = 0; i < QW; ++i) qor |= qw[i];
@@ -665,7 +779,21 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
             *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_poisson) + t_row4 + w4) = ep;
             *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kg->a.pdq_out) + t_row4 + w4) = pdq;
         }
+        CH_T(6)
     }
+#ifdef CH_STAMP
+    if (lane == 0 && a.dbg_buf) {
+        unsigned long long *o = a.dbg_buf + (((size_t)blockIdx.x * C3_NW + wv) % 4096) * 9;
+        for (int i = 0; i < 9; ++i) o[i] += st_[i];
+    }
+#endif
+}
+
+static inline size_t chain3_lds_bytes(int G, size_t ksize) {
+    const size_t gq = (size_t)(G + 3) / 4, oq = ksize == 8 ? (size_t)G / 2 : gq;
+    const size_t nch = (C3_NW * C3_OUTW + 4 + 126) / 128 + 1;
+    const size_t wq = 1 + ((G + 3) / 4 > 2 ? 1 : 0);
+    return (size_t)C3_NW * (3 * gq + 2 * oq + 2 * wq) * 64 * 16 + sizeof(C3FitTab) + nch * G * 2 * 8;
 }
 
 // waves per SIMD the instantiation is compiled for (register budget 512 / WPS per lane)
@@ -684,8 +812,18 @@ static int launch_chain3_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
         RIP_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
         ncu = prop.multiProcessorCount;
     }
-    // exactly resident grid: a second round of workgroups would start only when the first ends (measured: +40 %)
-    const int wg_per_cu = (4 * WPS) / C3_NW;
+    // exactly resident grid: a second round of workgroups would start only when the first ends (measured: +40 %).
+    // Registers allow (4 * WPS) / C3_NW workgroups per CU; LDS may allow fewer (asked from the runtime).
+    const size_t lds = chain3_lds_bytes(G, sizeof(KT));
+    static int wg_per_cu = 0;
+    if (!wg_per_cu) {
+        if (lds > 48 * 1024)
+            RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chain3_kernel<NP, G, START, KT, WPS>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int nblk = 0;
+        RIP_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, chain3_kernel<NP, G, START, KT, WPS>, C3_THREADS, lds));
+        wg_per_cu = std::max(1, std::min(nblk, (4 * WPS) / C3_NW));
+    }
     const int nstrips = (a.nx + C3_OUTW - 1) / C3_OUTW;
     const int nwgx = (nstrips + C3_NW - 1) / C3_NW;
     int nranges = (int)(((long)ncu * wg_per_cu) / nwgx);
@@ -695,7 +833,7 @@ static int launch_chain3_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
     const int rows_per = (a.ny + nranges - 1) / nranges;
     nranges = (a.ny + rows_per - 1) / rows_per;
     const long grid = (long)nranges * nwgx;
-    hipLaunchKernelGGL((chain3_kernel<NP, G, START, KT, WPS>), dim3((unsigned)grid), dim3(C3_THREADS), 0, ctx->stream, a,
+    hipLaunchKernelGGL((chain3_kernel<NP, G, START, KT, WPS>), dim3((unsigned)grid), dim3(C3_THREADS), lds, ctx->stream, a,
                        reinterpret_cast<const RipPlanHeader *>(plan->dev), plan->d_variants, plan->d_k, plan->d_diffs,
                        rip_guard_band);
     RIP_HIP(ctx, hipGetLastError());

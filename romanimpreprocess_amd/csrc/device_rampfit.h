@@ -376,23 +376,33 @@ struct RipFitState {
     bool live;                 // wave-uniform: some lane of the wave keeps jump flags
 };
 
+// where the first half reads the dense per-plan table from: the device copy through scalar loads (RipDenseK), or a copy the
+// kernel staged in LDS (chain3_kernel.h: LDS reads return in order and need no scalar registers)
+struct RipDenseK {
+    const RipDense *dn;
+    __device__ __forceinline__ float k2(int t) const { return KLD(dn->K2[t]); }
+    __device__ __forceinline__ uint32_t valid() const { return KLD(dn->valid); }
+    __device__ __forceinline__ float amin() const { return KLD(dn->amin); }
+    __device__ __forceinline__ void pair(RipDensePair &r, int ps) const { rip_load_pair(r, dn, ps); }
+};
+
 // first half: slope, errors, threshold, approximate significance of every tested difference
 // VALID != 0: the tested differences are known at compile time (no plan-uniform branches: the eight difference
 // slots become one basic block the scheduler can interleave)
-template <int G, uint32_t VALID = 0u>
-__device__ __forceinline__ void fit_full_pk_a(const rf2 (&dA)[G / 2], const RipFitConst fc, const RipVariant v,
-                                              const RipDense *__restrict__ dn, float gain, float rn, bool flag,
-                                              double guard, RipFitState &st) {
+template <int G, uint32_t VALID, typename TAB>
+__device__ __forceinline__ void fit_full_pk_a_t(const rf2 (&dA)[G / 2], const RipFitConst fc, const RipVariant v,
+                                                const TAB tabsrc, float gain, float rn, bool flag, double guard,
+                                                RipFitState &st) {
     constexpr int GP = G / 2;
     constexpr int NS = 2 * GP;  // pair slots
     // scalar loads of the weights and of the first difference slot are issued before the slope arithmetic; slot
     // ps+1 is requested while slot ps is evaluated (scalar loads return out of order: every wait is lgkmcnt(0))
     float k2[G];
 #pragma unroll
-    for (int t = 0; t < G; ++t) k2[t] = KLD(dn->K2[t]);
-    const uint32_t valid = VALID ? VALID : KLD(dn->valid);
+    for (int t = 0; t < G; ++t) k2[t] = tabsrc.k2(t);
+    const uint32_t valid = VALID ? VALID : tabsrc.valid();
     RipDensePair tab[2];
-    rip_load_pair(tab[0], dn, 0);
+    tabsrc.pair(tab[0], 0);
     const float d1 = dA[0].y;
     const rf2 d11 = {d1, d1};
     float s = 0.0f;
@@ -443,7 +453,7 @@ __device__ __forceinline__ void fit_full_pk_a(const rf2 (&dA)[G / 2], const RipF
     const float s2 = st.s2;
     const float s8 = fabsf(s) * 8.1e-7f;
     const float thp = sth32 + band0, thm = sth32 - band0;
-    const float rsmax = __frsqrt_rn(KLD(dn->amin) * s2) * 1.000001f;
+    const float rsmax = __frsqrt_rn(tabsrc.amin() * s2) * 1.000001f;
     const bool pass = fmaf(s8, rsmax, band0) <= 0.5f * sth32;  // false for NaN, for amin == 0 and for sth32 <= 0
     const bool lane_exact = !(guard < 1e300) || !pass;
     uint32_t jfast = 0, unsure_mask = 0;
@@ -452,7 +462,7 @@ __device__ __forceinline__ void fit_full_pk_a(const rf2 (&dA)[G / 2], const RipF
     for (int p = 0; p < GP; ++p) dB[p] = rf2{dA[p].y, (p + 1 < GP) ? dA[p + 1].x : 0.0f};
 #pragma unroll
     for (int ps = 0; ps < NS; ++ps) {
-        if (ps + 1 < NS) rip_load_pair(tab[(ps + 1) & 1], dn, ps + 1);
+        if (ps + 1 < NS) tabsrc.pair(tab[(ps + 1) & 1], ps + 1);
         const int ip = ps / 2, di = (ps & 1) + 1;
         const uint32_t vbits = (valid >> (2 * ps)) & 3u;
         if (vbits == 0) continue;  // plan-uniform
@@ -482,6 +492,13 @@ __device__ __forceinline__ void fit_full_pk_a(const rf2 (&dA)[G / 2], const RipF
     }
     st.jfast = jfast;
     st.unsure = unsure_mask;
+}
+
+template <int G, uint32_t VALID = 0u>
+__device__ __forceinline__ void fit_full_pk_a(const rf2 (&dA)[G / 2], const RipFitConst fc, const RipVariant v,
+                                              const RipDense *__restrict__ dn, float gain, float rn, bool flag,
+                                              double guard, RipFitState &st) {
+    fit_full_pk_a_t<G, VALID, RipDenseK>(dA, fc, v, RipDenseK{dn}, gain, rn, flag, guard, st);
 }
 
 // second half: exact re-evaluation where the approximate significance was not decisive, jump mask

@@ -190,8 +190,8 @@ __global__ void sel_init_kernel(SelState *st, uint32_t *ghist, int ngrp, uint32_
 // ---- 3. per group: global median M, row medians, ctr, rowcorr ------------------------------------
 __global__ __launch_bounds__(1024) void rowcorr_kernel(const SelState *__restrict__ st, const float *__restrict__ lohi,
                                                        double slope, double *__restrict__ rowcorr,
-                                                       float *__restrict__ dbg_refmed, float *__restrict__ dbg_scal,
-                                                       int ny, int npow2) {
+                                                       double *__restrict__ rowcorr_t, float *__restrict__ dbg_refmed,
+                                                       float *__restrict__ dbg_scal, int ny, int npow2) {
     extern __shared__ float rm[];  // [npow2] sort buffer
     const int g = blockIdx.x;
     const float M = (key2f(st[g].prefix[0]) + key2f(st[g].prefix[1])) * 0.5f;  // np.median of the block
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(1024) void rowcorr_kernel(const SelState *__restric
     for (int r = threadIdx.x; r < ny; r += blockDim.x) {
         const float v = refmed(r);
         rowcorr[(size_t)g * ny + r] = slope * (double)(v - ctr);
+        if (rowcorr_t) rowcorr_t[(size_t)r * gridDim.x + g] = slope * (double)(v - ctr);  // [row][group]: one scalar load per row
         if (dbg_refmed) dbg_refmed[(size_t)g * ny + r] = v;
     }
     if (dbg_scal && threadIdx.x == 0) {
@@ -294,10 +295,11 @@ int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a) {
             RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rowcorr_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(rowcorr_kernel, dim3(G), dim3(1024), lds, ctx->stream, st, lohi, a.slope, a.rowcorr,
-                           (float *)nullptr, (float *)nullptr, ny, npow2);
+                           a.rowcorr_t, (float *)nullptr, (float *)nullptr, ny, npow2);
     } else {
         // no reference output in the read file: the row step is the identity
         RIP_HIP(ctx, hipMemsetAsync(a.rowcorr, 0, (size_t)G * ny * sizeof(double), ctx->stream));
+        if (a.rowcorr_t) RIP_HIP(ctx, hipMemsetAsync(a.rowcorr_t, 0, (size_t)G * ny * sizeof(double), ctx->stream));
     }
     if (a.data_dtype == RIP_U16)
         hipLaunchKernelGGL(chan_kernel<uint16_t>, dim3(nch, G), dim3(1024), 0, ctx->stream, (const uint16_t *)a.data,

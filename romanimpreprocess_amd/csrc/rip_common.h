@@ -203,6 +203,7 @@ struct ChainArgs {
     // reference-pixel tables (rowcorr null -> step skipped)
     const float *dark_data;
     const double *rowcorr, *lines;
+    const double *rowcorr_t;  // (ny, G) copy of rowcorr (wave-private kernel: one wide scalar load per row)
     const float *bias;  // embedded planes, already offset to the first group used; null -> skipped
     const float *planes;  // RipCal::slab
     int do_not_flag_first;
@@ -248,6 +249,7 @@ struct RefpixArgs {
     double slope;
     const double *lines_override;  // device (G, nch, 2) or nullptr
     double *rowcorr;  // out (G, ny)
+    double *rowcorr_t;  // out (ny, G): the same values, row-major (may be null)
     double *lines;    // out (G, nch, 2)
     int ny, nx, ngrp;
 };
