@@ -39,7 +39,9 @@
 #define C3_NBATCH 2
 #endif
 // groups whose raw values are prefetched one step ahead (the rest are requested at the top of their own step)
+#ifndef C3_GEARLY
 #define C3_GEARLY (G / 2)
+#endif
 #define C3_OUTW 60
 #define C3_THREADS (64 * C3_NW)
 // One s_barrier per row step keeps the waves of a workgroup within a row of each other: neighbouring strips share cache lines
@@ -597,6 +599,7 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
             fetch_coefs(kb, yi + 1, rr);
             fetch_groups(kb, yi + 1, rr, 0, C3_GEARLY);
         }
+        CH_T(2)
         // =========================================================== C: first Neumann iterate of row yc
         // x slots rotate with the row (row mod 3); the first iterate has two (row & 1)
         const int sxm = sx, sx0 = (sx == 2) ? 0 : sx + 1, sxn = (sx0 == 2) ? 0 : sx0 + 1;  // rows yi-2, yi-1, yi
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
                 for (int g = 0; g < G; ++g) o1n[g] = (T)0;
             }
         }
-        CH_T(2)
+        CH_T(3)
 
         // =========================================================== O2: second iterate of row r, division by the gain
         float d[G];
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
             for (int p = 0; p < GP; ++p) dpair[p] = f2{d[2 * p], d[2 * p + 1]};
             st_o(sB, o1n);  // row yi-1 takes the slot of row yi-3
         }
-        CH_T(3)
+        CH_T(4)
         // ---- request the coefficient set of the next step's C (destination row yi); the set
         // the second iterate just used is free
         kO = kC;
@@ -698,9 +701,9 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
             e_flat_raw = c2_ld_f32<0>(c2_rsrc(kb->flat ? (const void *)kb->flat : (const void *)kb->planes), cc4, t_row);
             e_ddq_raw = c2_ld_u32<0>(c2_rsrc(kb->dark_dq ? (const void *)kb->dark_dq : (const void *)kb->planes), cc4, t_row);
         }
-        CH_T(4)
-        C3_SYNC();
         CH_T(5)
+        C3_SYNC();
+        CH_T(6)
 
         // =========================================================== F / T: ramp fit, flags, finish, stores of pixel (r, c)
         if (do_e && emit_lane) {
@@ -731,6 +734,7 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
                 for (int g = 0; g < G; ++g) qe[g] = (qw[g / 4] >> (8 * (g & 3))) & 0xffu;
                 trunc_layers<G, G - 1>(d, qe, kg->h, kg->vars, kg->kvals, kg->diffs, e_gain, e_read, act, kg->guard, s, er, ep, jmask);
             }
+            CH_T(7)
             // ---- T: flag propagation (fitting.py:339-353), finish (gen_cal_image.py:458-475, 213-229, 607-629), stores
             uint8_t *gq = kg->a.gdq_out ? kg->a.gdq_out + pe_row : nullptr;
             uint32_t pdq = propagate_flags_packed<G>(qw, jmask, start, e_pdq | lin_dq, gq, npix, c2_opaque(cc1));
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
             *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_poisson) + t_row4 + w4) = ep;
             *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kg->a.pdq_out) + t_row4 + w4) = pdq;
         }
-        CH_T(6)
+        CH_T(8)
     }
 #ifdef CH_STAMP
     if (lane == 0 && a.dbg_buf) {

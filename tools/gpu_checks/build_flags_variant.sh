@@ -9,5 +9,5 @@ rm -rf $W && mkdir -p $W/romanimpreprocess_amd $W/include
 cp -r $REPO/romanimpreprocess_amd/csrc $W/romanimpreprocess_amd/csrc
 cp $REPO/include/*.h $W/include/
 rm -f $W/romanimpreprocess_amd/csrc/*.o
-make -C $W/romanimpreprocess_amd/csrc -j8 LIB=$REPO/romanimpreprocess_amd/libromanhip_$T.so EXTRA="$*" 2>&1 | grep -E "error|Error" || true
+make -C $W/romanimpreprocess_amd/csrc -j8 LIB=$REPO/romanimpreprocess_amd/libromanhip_$T.so EXTRA="$*" $MAKEVARS 2>&1 | grep -E "error|Error" || true
 ls -la $REPO/romanimpreprocess_amd/libromanhip_$T.so

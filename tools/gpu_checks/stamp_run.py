@@ -49,8 +49,8 @@ CHAIN3 = bool(int(os.environ.get("CHAIN3", "1")))
 cb.ctx.set_option("chain2", int(CHAIN2))
 cb.ctx.set_option("chain3", int(CHAIN3))
 if CHAIN3:
-    names3 = ["top: issue finish loads (+drain with 2048)", "A refpix/bias/linearity", "C first iterate", "O2 second iterate / gain",
-              "rotate + issue next row loads", "barrier", "F/T fit, flags, finish, stores", "-", "-"]
+    names3 = ["top: late group loads (+drain with 2048)", "A refpix/bias/linearity", "issue next row's loads", "C first iterate",
+              "O2 second iterate / gain", "issue coefficient set + tail loads", "barrier", "F fit", "T flags, finish, stores"]
     for mask in [int(x) for x in sys.argv[1:]] or [0]:
         cb.ctx.set_option("chain_dbg", mask)
         call()
@@ -62,7 +62,7 @@ if CHAIN3:
         lib.rip_chain_stamps(cb.ctx.h, out)
         tot = sum(out)
         print(f"dbg={mask}: ticks per launch summed over waves {tot/n:.4g}")
-        for i in range(7):
+        for i in range(9):
             print(f"   {names3[i]:44s} {100*out[i]/tot:5.1f}%")
     sys.exit(0)
 names2 = ["ingest A lin", "ingest barrier 1", "ingest C + loads", "ingest barrier 2", "fit O2", "fit barrier 1",
