@@ -36,11 +36,7 @@
 #define C3_WPS 3
 #endif
 #ifndef C3_NBATCH   // groups the forward operator evaluates in lockstep (2 or 4)
-#define C3_NBATCH 2
-#endif
-// groups whose raw values are prefetched one step ahead (the rest are requested at the top of their own step)
-#ifndef C3_GEARLY
-#define C3_GEARLY (G / 2)
+#define C3_NBATCH 4
 #endif
 #define C3_OUTW 60
 #define C3_THREADS (64 * C3_NW)
@@ -175,6 +171,11 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     double *const LN = reinterpret_cast<double *>(FT + 1);
 
     const RIP_K C2KernArgs *kargs = (const RIP_K C2KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+#ifdef C3_DBG
+    const int dbg = a.dbg;  // timing experiments only (tools/gpu_checks/phase_timing.py): bits switch work off, results invalid
+#else
+    constexpr int dbg = 0;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int ny = a.ny, nx = a.nx, nb = a.nb;
@@ -267,20 +268,27 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
             o1 += npix;
         }
     };
-    auto fetch_coefs = [&](const RIP_K ChainArgs *ka, int y, RowRegs<NP, G> &rr) {
+    // planes i0..i1-1 of [cf[0..NP-1], Smin, Smax, Sref, dq, gain]
+    auto fetch_coefs = [&](const RIP_K ChainArgs *ka, int y, RowRegs<NP, G> &rr, int i0, int i1) {
         const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
         const __amdgpu_buffer_rsrc_t rp = c2_rsrc(ka->planes);
-        unsigned o4 = yl * row4;
+        unsigned o4 = yl * row4 + (unsigned)i0 * pl4;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            rr.cf[i] = c2_ld_f32<0>(rp, cc4, o4);
+        for (int i = i0; i < i1; ++i) {
+            if (i < NP)
+                rr.cf[i] = c2_ld_f32<0>(rp, cc4, o4);
+            else if (i == NP)
+                rr.smin = c2_ld_f32<0>(rp, cc4, o4);
+            else if (i == NP + 1)
+                rr.smax = c2_ld_f32<0>(rp, cc4, o4);
+            else if (i == NP + 2)
+                rr.sref = c2_ld_f32<0>(rp, cc4, o4);
+            else if (i == NP + 3)
+                rr.dq = c2_ld_u32<0>(rp, cc4, o4);
+            else
+                rr.gain = c2_ld_f32<0>(rp, cc4, o4);
             o4 += pl4;
         }
-        rr.smin = c2_ld_f32<0>(rp, cc4, o4);
-        rr.smax = c2_ld_f32<0>(rp, cc4, o4 + pl4);
-        rr.sref = c2_ld_f32<0>(rp, cc4, o4 + 2u * pl4);
-        rr.dq = c2_ld_u32<0>(rp, cc4, o4 + 3u * pl4);
-        rr.gain = c2_ld_f32<0>(rp, cc4, o4 + 4u * pl4);
     };
     // coefficient set of destination row y: planes 6..8 at row y-1, 3..5 at row y, 0..2 at row y+1 (rows clamped into the
     // frame; terms whose source lies outside the active box are masked by the caller)
@@ -396,15 +404,46 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     static_assert(G % NB == 0, "batches");
     using NbTag = C3Int<NB>;
 
+    constexpr int GQ1 = G / 4, GQ3 = (3 * G) / 4;  // quarters of the groups (load batches)
     RowRegs<NP, G> rr;
     {
         const RIP_K ChainArgs *ka = &kargs->a;
-        fetch_coefs(ka, R0 - 2, rr);
-        fetch_groups(ka, R0 - 2, rr, 0, C3_GEARLY);
+        fetch_coefs(ka, R0 - 2, rr, 0, NP + 5);
+        fetch_groups(ka, R0 - 2, rr, 0, GQ3);
         fetch_kset(ka, R0 - 3, kC);  // set of the first step's C (destination row R0-3: not evaluated, loads stay in bounds)
     }
 
     int sx = 0;  // x-ring slot of row yi-2
+    // results of the previous step's pixel, stored one step late: on gfx9 stores and loads complete in issue order (one vmcnt),
+    // so stores issued at the end of a step would sit in front of the loads the next step's A waits for
+    float pn_s = 0.0f, pn_er = 0.0f, pn_ep = 0.0f;
+    uint32_t pn_pdq = 0, pn_rq[QW];
+    bool pn_emit = false;
+    unsigned pn_trow = 0;
+#pragma unroll
+    for (int i = 0; i < QW; ++i) pn_rq[i] = 0;
+    auto flush_pending = [&]() {
+        if (pn_emit) {
+            const RIP_K C2KernArgs *kg = c2_args(kargs);
+            const unsigned w4 = c2_opaque(cc4);
+            const size_t t4 = (size_t)pn_trow;
+            if (kg->a.gdq_out && !(dbg & 2)) {
+                uint8_t *p = kg->a.gdq_out + (size_t)(pn_trow >> 2);
+                const unsigned w1 = c2_opaque(cc1);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    *(p + w1) = (uint8_t)(pn_rq[g / 4] >> (8 * (g & 3)));
+                    p += npix;
+                }
+            }
+            if (!(dbg & 4)) {
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.slope) + t4 + w4) = pn_s;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_read) + t4 + w4) = pn_er;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_poisson) + t4 + w4) = pn_ep;
+                *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kg->a.pdq_out) + t4 + w4) = pn_pdq;
+            }
+        }
+    };
     double rcn[G];  // row corrections of the row the next step ingests (wave-uniform: scalar registers)
     {
         const RIP_K double *rt = rip_k(a.rowcorr_t) + (size_t)min(max(R0 - 2, 0), ny - 1) * G;
@@ -423,10 +462,11 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
         const bool do_e = (r >= R0) && (r < R1);
         const unsigned rc_ = (unsigned)min(max(r, 0), ny - 1);
         const unsigned t_row = rc_ * row4;
-        // the raw values of the later groups of row yi: requested here, consumed in the second half of A (the first half
-        // covers part of their latency, the other waves of the SIMD the rest; prefetching them a step ahead like the others
-        // would hold 4 registers per group through C, O2 and the fit)
-        if (C3_GEARLY < G) fetch_groups(ka, yi, rr, C3_GEARLY, G);
+        // Loads are requested in small batches spread over the step (a burst of 30-50 loads per wave stalls the issue of every
+        // wave of the CU behind the vector-memory queue).  Row yi+1: Legendre planes after A; Smin..gain and the first quarter
+        // of the groups after C; the second and third quarter, the IPC coefficients and the tail's planes after O2; the
+        // last quarter here, at the top of the row's own step (consumed in the second half of A).
+        fetch_groups(ka, yi, rr, GQ3, G);
 #ifdef CH_STAMP
         if (a.dbg & 2048) __builtin_amdgcn_s_waitcnt(0);  // exposes what the step still waits for from the previous one
 #endif
@@ -590,14 +630,14 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
         }
 
         CH_T(1)
-        // ---- read noise of pixel (r, c) for the fit, then the raw values of row yi+1 (this row's are consumed; they land while C,
-        // O2 and the fit run)
+        // ---- read noise of pixel (r, c) for the fit, Legendre planes of row yi+1 (this row's are consumed)
+        flush_pending();  // (the previous step's results)
+        pn_emit = false;
         float e_read;
         {
             const RIP_K ChainArgs *kb = &c2_args(kargs)->a;
             e_read = c2_ld_f32<0>(c2_rsrc(kb->planes), cc4, (unsigned)(NP + 5) * pl4 + t_row);
-            fetch_coefs(kb, yi + 1, rr);
-            fetch_groups(kb, yi + 1, rr, 0, C3_GEARLY);
+            fetch_coefs(kb, yi + 1, rr, 0, NP);
         }
         CH_T(2)
         // =========================================================== C: first Neumann iterate of row yc
@@ -614,7 +654,8 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
         {
             const unsigned vC = lane_c & rowbits(yc);
             const bool all = __all(vC == 0x1ffu || vC == 0u);
-            if (do_c) {
+            auto c_pass = [&](auto allc) {
+                constexpr bool ALLC = decltype(allc)::value;
 #pragma unroll
                 for (int g0 = 0; g0 < G; g0 += NB) {
                     float bm[NB], b0[NB];
@@ -623,17 +664,24 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
                     T am[NB], a0[NB], ap[NB], f[NB];
 #pragma unroll
                     for (int b = 0; b < NB; ++b) am[b] = (T)bm[b], a0[b] = (T)b0[b], ap[b] = (T)xn[g0 + b];
-                    if (all)
-                        c3_fwd<T, true, NB>(am, a0, ap, kC, vC, f);
-                    else
-                        c3_fwd<T, false, NB>(am, a0, ap, kC, vC, f);
+                    c3_fwd<T, ALLC, NB>(am, a0, ap, kC, vC, f);
 #pragma unroll
                     for (int b = 0; b < NB; ++b) o1n[g0 + b] = (T)(b0[b] + b0[b]) - f[b];
                 }
+            };
+            if (do_c && all) {
+                c_pass(C2AllT{});
+            } else if (do_c) {
+                c_pass(C2SomeT{});
             } else {
 #pragma unroll
                 for (int g = 0; g < G; ++g) o1n[g] = (T)0;
             }
+        }
+        {
+            const RIP_K ChainArgs *kb = &c2_args(kargs)->a;
+            fetch_coefs(kb, yi + 1, rr, NP, NP + 5);
+            fetch_groups(kb, yi + 1, rr, 0, GQ1);
         }
         CH_T(3)
 
@@ -647,36 +695,47 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
             const bool fastdiv = __all(rcp_safe(e_gain) || !act);
             const bool allact = __all(act || !emit_lane);  // interior wave: every lane that emits is active (the others are not read)
             const float rgain = rip_rcp_mid(e_gain);
+            auto o_pass = [&](auto allc) {
+                constexpr bool ALLC = decltype(allc)::value;
 #pragma unroll
-            for (int g0 = 0; g0 < G; g0 += NB) {
-                float bx[NB];
-                T am[NB], a0[NB], ap[NB], f[NB], o2[NB];
-                ld_o(sB, g0, am, NbTag{});  // row yi-3
-                ld_o(sA, g0, a0, NbTag{});  // row yi-2
-                ld_x(sxm, g0, bx, NbTag{});
+                for (int g0 = 0; g0 < G; g0 += NB) {
+                    float bx[NB];
+                    T am[NB], a0[NB], ap[NB], f[NB], o2[NB];
+                    ld_o(sB, g0, am, NbTag{});  // row yi-3
+                    ld_o(sA, g0, a0, NbTag{});  // row yi-2
+                    ld_x(sxm, g0, bx, NbTag{});
 #pragma unroll
-                for (int b = 0; b < NB; ++b) ap[b] = o1n[g0 + b];
-                if (all)
-                    c3_fwd<T, true, NB>(am, a0, ap, kO, vO, f);
-                else
-                    c3_fwd<T, false, NB>(am, a0, ap, kO, vO, f);
+                    for (int b = 0; b < NB; ++b) ap[b] = o1n[g0 + b];
+                    c3_fwd<T, ALLC, NB>(am, a0, ap, kO, vO, f);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) o2[b] = (a0[b] + (T)bx[b]) - f[b];
-                if constexpr (K64) {
+                    for (int b = 0; b < NB; ++b) o2[b] = (a0[b] + (T)bx[b]) - f[b];
+                    if constexpr (K64) {
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) d[g0 + b] = act ? (float)(o2[b] / (double)e_gain) : bx[b];
-                } else if (fastdiv) {
+                        for (int b = 0; b < NB; ++b) d[g0 + b] = act ? (float)(o2[b] / (double)e_gain) : bx[b];
+                    } else if (ALLC && fastdiv && allact) {  // interior wave
 #pragma unroll
-                    for (int b = 0; b < NB; b += 2) {
-                        const f2 q = div_rcp2(f2{o2[b], o2[b + 1]}, e_gain, rgain);
-                        d[g0 + b] = (allact || act) ? q.x : bx[b];
-                        d[g0 + b + 1] = (allact || act) ? q.y : bx[b + 1];
+                        for (int b = 0; b < NB; b += 2) {
+                            const f2 q = div_rcp2(f2{o2[b], o2[b + 1]}, e_gain, rgain);
+                            d[g0 + b] = q.x;
+                            d[g0 + b + 1] = q.y;
+                        }
+                    } else if (fastdiv) {
+#pragma unroll
+                        for (int b = 0; b < NB; b += 2) {
+                            const f2 q = div_rcp2(f2{o2[b], o2[b + 1]}, e_gain, rgain);
+                            d[g0 + b] = act ? q.x : bx[b];
+                            d[g0 + b + 1] = act ? q.y : bx[b + 1];
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) d[g0 + b] = act ? o2[b] / e_gain : bx[b];
                     }
-                } else {
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) d[g0 + b] = act ? o2[b] / e_gain : bx[b];
                 }
-            }
+            };
+            if (all && fastdiv && allact)
+                o_pass(C2AllT{});
+            else
+                o_pass(C2SomeT{});
 #pragma unroll
             for (int p = 0; p < GP; ++p) dpair[p] = f2{d[2 * p], d[2 * p + 1]};
             st_o(sB, o1n);  // row yi-1 takes the slot of row yi-3
@@ -688,6 +747,7 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
         {
             const RIP_K ChainArgs *kb = &c2_args(kargs)->a;
             fetch_kset(kb, yi, kC);
+            fetch_groups(kb, yi + 1, rr, GQ1, GQ3);
         }
         // what the tail of pixel (r, c) reads: lands while the fit runs
         float e_dark, e_flat_raw;
@@ -706,21 +766,22 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
         CH_T(6)
 
         // =========================================================== F / T: ramp fit, flags, finish, stores of pixel (r, c)
-        if (do_e && emit_lane) {
+        if (do_e && emit_lane && !(dbg & 8)) {
             const RIP_K C2KernArgs *kg = c2_args(kargs);
             const float e_flat = kg->a.flat ? e_flat_raw : 1.0f;
             const uint32_t e_ddq = kg->a.dark_dq ? e_ddq_raw : 0u;
             const unsigned pe = rc_ * (unsigned)nx + cc1;
-            const size_t t_row4 = (size_t)t_row;
-            const size_t pe_row = (size_t)(rc_ * (unsigned)nx);
             if (kg->a.cube_out) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) kg->a.cube_out[(unsigned)g * npix + pe] = d[g];
             }
             RipFitState fs;
             const bool unsat = ((qw[(G - 1) / 4] >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
-            fit_full_pk_a_t<G, rip_full_valid<G, START>(), C3DenseLds<G>>(dpair, fc0, v0, dtab, e_gain, e_read, unsat && act,
-                                                                                  kg->guard, fs);
+            if (dbg & 1) {
+                fs.s = d[0], fs.er = e_read, fs.ep = e_gain, fs.live = false;
+            } else
+                fit_full_pk_a_t<G, rip_full_valid<G, START>(), C3DenseLds<G>>(dpair, fc0, v0, dtab, e_gain, e_read, unsat && act,
+                                                                              kg->guard, fs);
             uint32_t qor = 0;
 #pragma unroll
             for (int i = 0; i < QW; ++i) qor |= qw[i];
@@ -736,8 +797,7 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
             }
             CH_T(7)
             // ---- T: flag propagation (fitting.py:339-353), finish (gen_cal_image.py:458-475, 213-229, 607-629), stores
-            uint8_t *gq = kg->a.gdq_out ? kg->a.gdq_out + pe_row : nullptr;
-            uint32_t pdq = propagate_flags_packed<G>(qw, jmask, start, e_pdq | lin_dq, gq, npix, c2_opaque(cc1));
+            uint32_t pdq = propagate_flags_packed<G>(qw, jmask, start, e_pdq | lin_dq, nullptr, npix, 0u, pn_rq);
             if (kg->a.finish) {
                 const float sd = (act && kg->a.dark_rate) ? s - e_dark : s;
                 const bool lean = kg->a.flat && __all(act && rip_mid36(sd) && (er == 0.0f || rip_mid36(er)) &&
@@ -777,14 +837,13 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
                     ep = ep2;
                 }
             }
-            const unsigned w4 = c2_opaque(cc4);
-            *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.slope) + t_row4 + w4) = s;
-            *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_read) + t_row4 + w4) = er;
-            *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_poisson) + t_row4 + w4) = ep;
-            *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kg->a.pdq_out) + t_row4 + w4) = pdq;
+            pn_s = s, pn_er = er, pn_ep = ep, pn_pdq = pdq;
+            pn_emit = true;
         }
+        pn_trow = t_row;
         CH_T(8)
     }
+    flush_pending();
 #ifdef CH_STAMP
     if (lane == 0 && a.dbg_buf) {
         unsigned long long *o = a.dbg_buf + (((size_t)blockIdx.x * C3_NW + wv) % 4096) * 9;

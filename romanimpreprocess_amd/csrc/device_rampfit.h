@@ -630,7 +630,7 @@ __device__ __forceinline__ uint32_t rip_spread_bit1(uint32_t t) {  // bytes hold
 template <int G>
 __device__ __forceinline__ uint32_t propagate_flags_packed(const uint32_t (&w)[(G + 3) / 4], uint32_t jmask, int start,
                                                            uint32_t pdq_in, uint8_t *gdq_row, unsigned gstride,
-                                                           unsigned lane_off) {
+                                                           unsigned lane_off, uint32_t *rq_out = nullptr) {
     static_assert(G > 4 && G <= 16, "flag words");
     constexpr int QW = (G + 3) / 4;
     // bytes of the last word beyond group G-1: missing groups count as DO_NOT_USE in the all-groups test
@@ -639,6 +639,10 @@ __device__ __forceinline__ uint32_t propagate_flags_packed(const uint32_t (&w)[(
 #pragma unroll
     for (int i = 0; i < QW; ++i)  // bit g of jmask -> JUMP_DET (0x04) of byte g
         rq[i] = w[i] | ((__umul24((jmask >> (4 * i)) & 0xFu, 0x00204081u) & 0x01010101u) << 2);
+    if (rq_out) {  // the updated group flags, still packed (the caller stores them later)
+#pragma unroll
+        for (int i = 0; i < QW; ++i) rq_out[i] = rq[i];
+    }
     if (gdq_row) {  // uniform
         uint8_t *p = gdq_row;
 #pragma unroll

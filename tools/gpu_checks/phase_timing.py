@@ -53,6 +53,11 @@ def run(mask, n=10, batches=5):
     return best
 
 
+if os.environ.get("CHAIN3", "1") == "1":
+    names3 = {0: "full", 1: "no fit", 2: "no groupdq stores", 4: "no plane stores", 6: "no stores", 7: "no fit, no stores", 8: "no F/T"}
+    for m in [int(x) for x in sys.argv[1:]] or [0, 1, 2, 4, 6, 7, 8]:
+        print(f"dbg={m:3d} {names3.get(m, ''):28s} {run(m):8.3f} ms", flush=True)
+    sys.exit(0)
 names = {0: "full", 1: "no C (O1)", 2: "no E-ipc (O2)", 4: "no fit", 8: "no saturated path", 16: "no legendre",
          32: "no lin slow branch", 3: "no ipc", 7: "no ipc, no fit", 23: "no ipc/fit/legendre", 12: "no fit/no sat"}
 for m in [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 8, 12, 16, 32, 7, 23]:
