@@ -356,6 +356,12 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         RowRegs<NP, G> rr;
         fetch_row(R0 - 2, rr);
         int so_c = (R0 - 5 + 2 + 3000) % 3;  // O1 ring slot of row yc = r + 2
+        double rcn[G];  // row corrections of the row the next step ingests
+        {
+            const RIP_K double *rt = rip_k(kargs->a.rowcorr_t) + (size_t)min(max(R0 - 2, 0), ny - 1) * G;
+#pragma unroll
+            for (int g = 0; g < G; ++g) rcn[g] = rt[g];
+        }
         for (int r = R0 - 5; r <= R1; ++r, so_c = (so_c == 2) ? 0 : so_c + 1) {
             const RIP_K ChainArgs *ka = &c2_args(kargs)->a;  // S1 copy of the argument block
             const int yi = r + 3, yc = r + 2;
@@ -363,11 +369,13 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             const bool do_c = (yc >= R0 - 1) && (yc <= R1);
             // ---- S1: A (linearity of row yi from rr), then the loads S2 consumes
             // per-row reference-pixel correction of the G groups: wave-uniform, scalar loads (constant address space)
-            double rc[G];
-            {
-                const int yl = min(max(yi, 0), ny - 1);
+            double rc[G];  // loaded one step ahead: one wide scalar load from the row-major copy of the table
 #pragma unroll
-                for (int g = 0; g < G; ++g) rc[g] = KLD(ka->rowcorr[g * ny + yl]);
+            for (int g = 0; g < G; ++g) rc[g] = rcn[g];
+            {
+                const RIP_K double *rt = rip_k(ka->rowcorr_t) + (size_t)min(max(yi + 1, 0), ny - 1) * G;
+#pragma unroll
+                for (int g = 0; g < G; ++g) rcn[g] = rt[g];
             }
             const bool a_full = do_a && yi >= 0 && yi < ny;  // wave-uniform
             // A: two pairs of groups at a time -- reference-pixel/bias arithmetic and z of both pairs, then their two

@@ -215,7 +215,8 @@ def _set_form(ctx, form):
 
 
 def _default_form(ctx):
-    _set_form(ctx, 3)
+    """the library's defaults: fused, wave-specialised kernel (the wave-private one only where nothing else is instantiated)"""
+    _set_form(ctx, 2)
 
 
 SPECIALISED = [
@@ -334,37 +335,69 @@ def test_saturation_flagging_on_device_matches_host_restatement():
         cb.ctx.drop_caldir(6)
 
 
-@pytest.mark.parametrize("kdt", [np.float32, np.float64])
-def test_full_frame_4096x4096x8_vs_oracle_and_between_forms(kdt):
-    """BASELINE config 2 at its full size (the bench workload; also with the f64 ipc4d of production CALDIR sets): the numpy
-    oracle on the whole frame (about a minute of CPU) against the wave-specialised kernel, bit for bit with LAPACK's channel
-    lines handed in; then the three device forms (specialised, general fused, stage kernels) against each other with the
-    lines fitted on the device."""
-    rp = synth.READ_PATTERN_8
+FULL_FRAME = [
+    # name, read pattern, ipc4d dtype, P_ORDER, rows the oracle runs on
+    ("g8_f32", synth.READ_PATTERN_8, np.float32, 8, 4096),     # BASELINE config 2: the bench workload
+    ("g8_k64", synth.READ_PATTERN_8, np.float64, 8, 4096),     # ... with the f64 ipc4d of production CALDIR sets
+    # BASELINE config 3 (READS = [0..35], 16 groups): the numpy oracle needs more than 7 minutes for a 16-group full frame
+    # (13 truncated refits, O(G^2) variance passes), so it checks a 264-row frame of the full width and the full frame is
+    # checked between the four device forms
+    ("g16_f32", synth.READ_PATTERN_16, np.float32, 8, 264),
+]
+
+
+@pytest.mark.parametrize("name,rp,kdt,p,oracle_rows", FULL_FRAME)
+def test_full_frame_4096x4096_vs_oracle_and_between_forms(name, rp, kdt, p, oracle_rows):
+    """BASELINE configs 2 and 3 at their full size on a NON-PERIODIC frame (sky + 25 Gaussian sources, seeded, generated
+    on the device by synth_gpu): the numpy oracle on the whole frame (about a minute of CPU) against the default fused kernel,
+    bit for bit with LAPACK's channel lines handed in; then every device form (wave-private, wave-specialised, general fused,
+    stage kernels) against each other with the lines fitted on the device."""
+    from romanimpreprocess_amd import synth_gpu
+
     n = 4096
-    cal, ramp = synth.make_tiled_inputs(n, n, read_pattern=rp, p_order=8, seed=1, strip_rows=128, ipc_dtype=kdt)
-    ref = oracle.calibrate_arrays(ramp, cal)
     ctx = gpu_context()
     cb = pipeline.Calibrator(ctx=ctx)
+    if oracle_rows < n:
+        cal_s = synth_gpu.make_caldir(oracle_rows, n, read_pattern=rp, p_order=p, seed=1002, ipc_dtype=kdt)
+        ramp_s = synth_gpu.make_ramp(cal_s, read_pattern=rp, seed=2, cr_frac=0.01)
+        ref_s = oracle.calibrate_arrays(ramp_s, cal_s)
+        cb.load_caldir(6, cal_s)
+        _default_form(ctx)
+        got_s = cb.calibrate(6, ramp_s, channel_lines=_oracle_lines(ref_s, len(rp), n // 128))
+        assert ctx.last_chain_form() == 2
+        for k in ("groupdq", "pixeldq", "slope", "err_read", "err_poisson"):
+            assert_same_bits(got_s[k], ref_s[k], f"{k} ({oracle_rows}-row frame)", zero_sign_ok=True)
+        assert np.count_nonzero(got_s["pixeldq"] & 4) > 1000
+        cb.ctx.drop_caldir(6)
+        del cal_s, ramp_s, ref_s, got_s
+    cal = synth_gpu.make_caldir(n, n, read_pattern=rp, p_order=p, seed=1001, ipc_dtype=kdt)
+    ramp = synth_gpu.make_ramp(cal, read_pattern=rp, seed=1)
     cb.load_caldir(6, cal)
     try:
         _default_form(ctx)
-        got = cb.calibrate(6, ramp, channel_lines=_oracle_lines(ref, len(rp), n // 128))
-        assert ctx.last_chain_form() == 3
-        assert_same_bits(got["groupdq"], ref["groupdq"], "groupdq")
-        assert_same_bits(got["pixeldq"], ref["pixeldq"], "pixeldq")
-        for k in ("slope", "err_read", "err_poisson"):
-            assert_same_bits(got[k], ref[k], k, zero_sign_ok=True)
+        if oracle_rows == n:
+            ref = oracle.calibrate_arrays(ramp, cal)
+            got = cb.calibrate(6, ramp, channel_lines=_oracle_lines(ref, len(rp), n // 128))
+            assert ctx.last_chain_form() == 2
+            assert_same_bits(got["groupdq"], ref["groupdq"], "groupdq")
+            assert_same_bits(got["pixeldq"], ref["pixeldq"], "pixeldq")
+            for k in ("slope", "err_read", "err_poisson"):
+                assert_same_bits(got[k], ref[k], k, zero_sign_ok=True)
+            del ref
+        else:
+            got = cb.calibrate(6, ramp)
         frac_good = np.mean(got["pixeldq"][4:-4, 4:-4] == 0)
         assert frac_good > 0.9 and np.count_nonzero(got["pixeldq"] & 4) > 10000
-        del ref
+        # the sources are there
+        assert np.count_nonzero(ramp["rate"][4:-4, 4:-4] > 100.0) > 200
         outs = []
-        for form in (3, 2, 1, 0):
+        for form in (2, 3, 1, 0):
             _set_form(ctx, form)
             outs.append(cb.calibrate(6, ramp))
-        for other, label in ((outs[1], "wave-specialised"), (outs[2], "general fused"), (outs[3], "stage kernels")):
+            assert ctx.last_chain_form() == form
+        for other, label in ((outs[1], "wave-private"), (outs[2], "general fused"), (outs[3], "stage kernels")):
             for k in ("slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
-                assert_same_bits(outs[0][k], other[k], f"{k}: wave-private vs {label}")
+                assert_same_bits(outs[0][k], other[k], f"{k}: wave-specialised vs {label}")
         # device-fitted lines against LAPACK's: flags identical, slopes within the north-star tolerance
         assert_same_bits(outs[0]["pixeldq"], got["pixeldq"], "pixeldq (device lines)")
         np.testing.assert_allclose(outs[0]["slope"], got["slope"], rtol=1e-5, atol=1e-7)
