@@ -8,14 +8,24 @@ flat) over one 4096 x 4096 x 8-group ramp whose inputs are already resident in H
 independent, so ranks share nothing on the data path: rank 0 scatters the work-item indices (RCCL
 broadcast of an int32 list) and every rank processes its own items (weak scaling).
 
+Workloads (``--workload``):
+  single   (default) BASELINE config 2: one seeded NON-PERIODIC full frame (sky + 25 Gaussian sources through IPC
+           and the inverted linearity curve, read noise, cosmic rays, saturation; generated on the device by synth_gpu) per
+           rank, calibrated K times against one resident CALDIR set.
+  batch72  BASELINE config 4: 18 CALDIR sets (SCAs) resident at once, 72 (filter, SCA) ramps with seed 1000 * filter + sca,
+           item i on rank i mod N; a step is one item, the ranks walk their items round and round.
+
 One JSON line is printed by rank 0 with the metric of BASELINE.json plus
   roofline     : dominant kernel, algorithmic bytes / measured kernel time (HIP events on the library's stream)
   cpu_baseline : the numpy oracle timed on a bounded sample of the same workload on this host (N = 1 only)
+and, at N = 1 (skipped with --no-extras): the exclusive time of the reference-pixel pre-pass, the production-representative
+variants (f64 ipc4d, 16 groups, P_ORDER 10) and the 18-slot batch of config 4.
 """
 
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -45,7 +55,51 @@ def alg_bytes(G, ny, nx, nb, nplanes, gain_size=4, ipc_size=4, data_size=2):
         "rampfit": npix * (G * 6 + 4 + gain_size + 4 + 4 + 4 + 4 + 16),
         "refpix_prepass": G * ny * 128 * 2 * 4 + ny * 128 * 4 * 4 + 2 * 8 * nx * G * (data_size + 4),
     }
+    per_kernel["chain_fused"] = inputs + outputs - G * ny * 128 * 2 - ny * 128 * 4  # everything but the reference-output block
     return inputs + outputs, per_kernel
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_info():
+    model = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"cpu_model": model, "cpus_available": ncpu, "numpy": np.__version__,
+            "threads_env": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}}
+
+
+def _cpu_strip(cal, ramp, rows, timings=None):
+    import oracle
+
+    nb = 4
+    sl = slice(0, rows + 2 * nb)
+    na = rows
+    sub_cal = {
+        "dark": {k: (v[:, sl] if v.ndim == 3 else v[sl]) for k, v in cal["dark"].items()},
+        "gain": {"data": cal["gain"]["data"][sl]},
+        "ipc4d": {"data": np.ascontiguousarray(cal["ipc4d"]["data"][:, :, :na])},
+        "linearitylegendre": {k: (v[:, sl] if v.ndim == 3 else v[sl]) for k, v in cal["linearitylegendre"].items()},
+        "flat": {"data": cal["flat"]["data"][sl]},
+        "read": {"anc": cal["read"]["anc"], "data": cal["read"]["data"][sl],
+                 "amp33": {**cal["read"]["amp33"], "med": cal["read"]["amp33"]["med"][sl],
+                           "std": cal["read"]["amp33"]["std"][sl]}},
+        "biascorr": {"data": np.ascontiguousarray(cal["biascorr"]["data"][:, :na])},
+    }
+    sub_ramp = {"data": ramp["data"][:, sl], "amp33": ramp["amp33"][:, sl], "groupdq": ramp["groupdq"][:, sl],
+                "pixeldq": ramp["pixeldq"][sl], "read_pattern": ramp["read_pattern"], "frame_time": ramp["frame_time"]}
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        oracle.calibrate_arrays(sub_ramp, sub_cal, timings=timings)
+    dt = time.perf_counter() - t0
+    frac = (rows + 2 * nb) / ramp["data"].shape[1]
+    return frac, dt, rows + 2 * nb
 
 
 def cpu_baseline(cal, ramp, target_s=7.0):
@@ -55,10 +109,14 @@ def cpu_baseline(cal, ramp, target_s=7.0):
     probe = _cpu_strip(cal, ramp, min(128, ny - 8))
     per_row = probe[1] / probe[2]
     rows = int(max(128, min(ny - 8, target_s / per_row)))
-    frac, dt, nrows = _cpu_strip(cal, ramp, rows)
-    return {"value": frac / dt, "unit": "ramps/s", "cores": 1, "kind": "port",
-            "sample": f"{nrows}x{ramp['data'].shape[2]}x{ramp['data'].shape[0]} strip of the same ramp "
-                      f"({frac:.4f} ramp) through the numpy oracle, {dt:.1f} s, single thread"}
+    stages = {}
+    frac, dt, nrows = _cpu_strip(cal, ramp, rows, timings=stages)
+    out = {"value": frac / dt, "unit": "ramps/s", "cores": 1, "kind": "port",
+           "sample": f"{nrows}x{ramp['data'].shape[2]}x{ramp['data'].shape[0]} strip of the same ramp "
+                     f"({frac:.4f} ramp) through the numpy oracle, {dt:.1f} s, single thread",
+           "per_stage_s_per_ramp": {k: v / frac for k, v in stages.items()}}
+    out.update(_cpu_info())
+    return out
 
 
 def _replica_worker(args):
@@ -75,7 +133,8 @@ def _replica_worker(args):
     ramp = synth.make_ramp(cal, read_pattern=rp, seed=seed)
     barrier.wait()
     t0 = time.perf_counter()
-    oracle.calibrate_arrays(ramp, cal)
+    with _np.errstate(all="ignore"):
+        oracle.calibrate_arrays(ramp, cal)
     return time.perf_counter() - t0
 
 
@@ -99,30 +158,46 @@ def cpu_replicas(rows, groups, p_order, ipc64, max_procs=16):
                       f"(wall incl. generating the strips {wall:.1f} s)"}
 
 
-def _cpu_strip(cal, ramp, rows):
-    import oracle
+# --------------------------------------------------------------------------------------------- device side
+class Resident:
+    """One ramp's inputs resident in HBM + preallocated outputs."""
 
-    nb = 4
-    sl = slice(0, rows + 2 * nb)
-    na = rows
-    sub_cal = {
-        "dark": {k: (v[:, sl] if v.ndim == 3 else v[sl]) for k, v in cal["dark"].items()},
-        "gain": {"data": cal["gain"]["data"][sl]},
-        "ipc4d": {"data": np.ascontiguousarray(cal["ipc4d"]["data"][:, :, :na])},
-        "linearitylegendre": {k: (v[:, sl] if v.ndim == 3 else v[sl]) for k, v in cal["linearitylegendre"].items()},
-        "flat": {"data": cal["flat"]["data"][sl]},
-        "read": {"anc": cal["read"]["anc"], "data": cal["read"]["data"][sl],
-                 "amp33": {**cal["read"]["amp33"], "med": cal["read"]["amp33"]["med"][sl],
-                           "std": cal["read"]["amp33"]["std"][sl]}},
-        "biascorr": {"data": np.ascontiguousarray(cal["biascorr"]["data"][:, :na])},
-    }
-    sub_ramp = {"data": ramp["data"][:, sl], "amp33": ramp["amp33"][:, sl], "groupdq": ramp["groupdq"][:, sl],
-                "pixeldq": ramp["pixeldq"][sl], "read_pattern": ramp["read_pattern"], "frame_time": ramp["frame_time"]}
+    def __init__(self, torch, dev, ramp, outs=None):
+        g = ramp["groupdq"].copy()
+        g[0] |= 1
+        self.G, self.ny, self.nx = ramp["data"].shape
+        self.data = torch.from_numpy(ramp["data"].view(np.int16)).to(dev)
+        self.a33 = torch.from_numpy(ramp["amp33"].view(np.int16)).to(dev)
+        self.gdq = torch.from_numpy(g).to(dev)
+        self.pdq = torch.from_numpy(ramp["pixeldq"].view(np.int32)).to(dev)
+        self.outs = outs or Outputs(torch, dev, self.G, self.ny, self.nx)
+
+
+class Outputs:
+    def __init__(self, torch, dev, G, ny, nx):
+        self.slope = torch.empty((ny, nx), dtype=torch.float32, device=dev)
+        self.er = torch.empty_like(self.slope)
+        self.ep = torch.empty_like(self.slope)
+        self.pdq = torch.empty((ny, nx), dtype=torch.int32, device=dev)
+        self.gdq = torch.empty((G, ny, nx), dtype=torch.uint8, device=dev)
+
+
+def run_steps(cb, calls, warmup, steps, fence):
+    """`calls`: list of zero-argument callables walked round and round.  Returns (elapsed s, per-stage ms sums, calls)."""
+    n = len(calls)
+    for i in range(warmup):
+        calls[i % n]()
+    fence()
+    cb.ctx.profile(True)
+    cb.ctx.profile_read()
     t0 = time.perf_counter()
-    oracle.calibrate_arrays(sub_ramp, sub_cal)
-    dt = time.perf_counter() - t0
-    frac = (rows + 2 * nb) / ramp["data"].shape[1]
-    return frac, dt, rows + 2 * nb
+    for i in range(steps):
+        calls[(warmup + i) % n]()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ms, ncalls = cb.ctx.profile_read()
+    cb.ctx.profile(False)
+    return elapsed, ms, ncalls
 
 
 def main():
@@ -130,12 +205,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="single", choices=("single", "batch72"))
     ap.add_argument("--groups", type=int, default=8, choices=(8, 16))
     ap.add_argument("--side", type=int, default=4096)
     ap.add_argument("--ipc-dtype", default="f32", choices=("f32", "f64"),
                     help="dtype of the ipc4d coefficients (the reference's production writer stores f64)")
     ap.add_argument("--p-order", type=int, default=8, choices=(3, 8, 10), help="Legendre order of the linearity file")
+    ap.add_argument("--tiled", action="store_true", help="the round-1 input: a 128-row strip repeated down the frame (numpy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip pre-pass exclusive timing, variants and the 18-slot batch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,42 +231,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from romanimpreprocess_amd import pipeline, synth
+    from romanimpreprocess_amd import pipeline, synth, synth_gpu
 
-    rp = synth.READ_PATTERN_8 if args.groups == 8 else synth.READ_PATTERN_16
-    G, N, nb, p_order = len(rp), args.side, 4, args.p_order
-    kdt = np.float64 if args.ipc_dtype == "f64" else np.float32
-    # synthetic CALDIR + ramp (seeded; a strip repeated down the frame so that the host prepares it in seconds)
-    cal, ramp = synth.make_tiled_inputs(N, N, read_pattern=rp, p_order=p_order, seed=1 + rank, strip_rows=128, ipc_dtype=kdt)
+    N, nb = args.side, 4
+
+    def make_inputs(groups, p_order, ipc_dtype, cal_seed, ramp_seed, want_cal=True, cal=None):
+        rp_ = synth.READ_PATTERN_8 if groups == 8 else synth.READ_PATTERN_16
+        kdt_ = np.float64 if ipc_dtype == "f64" else np.float32
+        if args.tiled:
+            return rp_, *synth.make_tiled_inputs(N, N, read_pattern=rp_, p_order=p_order, seed=ramp_seed, strip_rows=128, ipc_dtype=kdt_)
+        if cal is None:
+            cal = synth_gpu.make_caldir(N, N, read_pattern=rp_, p_order=p_order, seed=cal_seed, ipc_dtype=kdt_, device=local_rank)
+        ramp = synth_gpu.make_ramp(cal, read_pattern=rp_, seed=ramp_seed, device=local_rank)
+        return rp_, cal, ramp
+
     cb = pipeline.Calibrator(device=local_rank)
-    cb.load_caldir(0, cal)
-    pid, meta = cb.plan_for(rp, ramp["frame_time"])
-
-    # inputs resident in HBM before the timed region; outputs preallocated
-    gdq_host = ramp["groupdq"].copy()
-    gdq_host[0] |= 1
-    t_data = torch.from_numpy(ramp["data"].view(np.int16)).to(dev)
-    t_a33 = torch.from_numpy(ramp["amp33"].view(np.int16)).to(dev)
-    t_gdq = torch.from_numpy(gdq_host).to(dev)
-    t_pdq = torch.from_numpy(ramp["pixeldq"].view(np.int32)).to(dev)
-    o_slope = torch.empty((N, N), dtype=torch.float32, device=dev)
-    o_er = torch.empty_like(o_slope)
-    o_ep = torch.empty_like(o_slope)
-    o_pdq = torch.empty((N, N), dtype=torch.int32, device=dev)
-    o_gdq = torch.empty((G, N, N), dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-
-    # work-item scatter: rank 0 owns the list of (exposure, SCA) indices; item i goes to rank i % world
-    n_items = (args.steps + args.warmup) * world
-    items = torch.arange(n_items, dtype=torch.int32, device=dev) if rank == 0 else torch.empty(n_items, dtype=torch.int32, device=dev)
-    if world > 1:
-        dist.broadcast(items, src=0)
-    mine = items[rank::world].tolist()
-    assert len(mine) == args.steps + args.warmup
-
-    def step():
-        cb.calibrate_device(0, pid, G, t_data.data_ptr(), True, t_a33.data_ptr(), t_gdq.data_ptr(), t_pdq.data_ptr(),
-                            o_slope.data_ptr(), o_er.data_ptr(), o_ep.data_ptr(), o_pdq.data_ptr(), o_gdq.data_ptr())
 
     def fence():
         cb.synchronize()
@@ -197,49 +254,104 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in mine[: args.warmup]:
-        step()
-    fence()
-    cb.ctx.profile(True)
-    cb.ctx.profile_read()
-    t0 = time.perf_counter()
-    for _ in mine[args.warmup:]:
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ms, ncalls = cb.ctx.profile_read()
-    cb.ctx.profile(False)
+    def call_for(slot, pid, G, res):
+        o = res.outs
+        return lambda: cb.calibrate_device(slot, pid, G, res.data.data_ptr(), True, res.a33.data_ptr(), res.gdq.data_ptr(),
+                                           res.pdq.data_ptr(), o.slope.data_ptr(), o.er.data_ptr(), o.ep.data_ptr(),
+                                           o.pdq.data_ptr(), o.gdq.data_ptr())
 
+    def sane(res):
+        good = (res.outs.pdq[nb:-nb, nb:-nb] == 0)
+        frac_good = float(good.float().mean().item())
+        finite = bool(torch.isfinite(res.outs.slope[nb:-nb, nb:-nb][good]).all().item())
+        if not (frac_good > 0.5 and finite):
+            raise SystemExit(f"bench sanity check failed: good fraction {frac_good}, finite {finite}")
+        return frac_good
+
+    def kernel_report(G, p_order, ipc_dtype, ms, ncalls):
+        total, per_kernel = alg_bytes(G, N, N, nb, p_order + 1, ipc_size=8 if ipc_dtype == "f64" else 4)
+        fused = ms[2] < 0.05 * max(ncalls, 1) and ms[3] < 0.05 * max(ncalls, 1)  # only event gaps
+        names = ["refpix_prepass", "chain_fused" if fused else "cube_stage", "ipc", "rampfit"]
+        avg_ms = {n: ms[i] / max(ncalls, 1) for i, n in enumerate(names) if not (fused and i >= 2)}
+        dom = "chain_fused" if fused else max((n for n in avg_ms if n != "refpix_prepass"), key=avg_ms.get)
+        ach = per_kernel[dom] / (avg_ms[dom] * 1e-3) / 1e9
+        return total, per_kernel, avg_ms, dom, ach
+
+    # ------------------------------------------------------------------------------------------ the headline workload
+    G = args.groups
+    extras = {}
+    if args.workload == "single":
+        rp, cal, ramp = make_inputs(G, args.p_order, args.ipc_dtype, 1000 + 1 + rank, 1 + rank)
+        cb.load_caldir(0, cal)
+        pid, _meta = cb.plan_for(rp, ramp["frame_time"])
+        res = Resident(torch, dev, ramp)
+        calls = [call_for(0, pid, G, res)]
+        n_items = (args.steps + args.warmup) * world
+        workload = (f"single {N}x{N}x{G}-group ramp, full CALDIR (linearitylegendre P_ORDER {args.p_order} + ipc4d + biascorr + dark + "
+                    f"read + flat), u16 cube resident in HBM, f32 gain / {args.ipc_dtype} ipc4d; "
+                    + ("128-row strip repeated down the frame" if args.tiled else
+                       "non-periodic frame (sky + 25 Gaussian sources, read noise, cosmic rays, saturation; seeded, generated on the device)"))
+    else:
+        # BASELINE config 4: 18 SCAs x 4 filters; item i = (filter i // 18, sca 1 + i % 18), seed 1000 * filter + sca
+        rp = synth.READ_PATTERN_8 if G == 8 else synth.READ_PATTERN_16
+        pid = None
+        my_items = [i for i in range(72) if i % world == rank]
+        slots = sorted({1 + i % 18 for i in my_items})
+        cals = {}
+        t_setup = time.perf_counter()
+        for sca in slots:
+            c = synth_gpu.make_caldir(N, N, read_pattern=rp, p_order=args.p_order, seed=5000 + sca,
+                                      ipc_dtype=np.float64 if args.ipc_dtype == "f64" else np.float32, device=local_rank)
+            cb.load_caldir(sca, c)
+            cals[sca] = c
+        calls, resident = [], []
+        outs = Outputs(torch, dev, G, N, N)  # one set of result planes: a consumer would take them before the next item
+        for i in my_items:
+            filt, sca = i // 18, 1 + i % 18
+            r = synth_gpu.make_ramp(cals[sca], read_pattern=rp, seed=1000 * filt + sca, device=local_rank)
+            if pid is None:
+                pid, _meta = cb.plan_for(rp, r["frame_time"])
+            rr_ = Resident(torch, dev, r, outs)
+            resident.append(rr_)
+            calls.append(call_for(sca, pid, G, rr_))
+        del cals
+        res = resident[-1]
+        ramp, cal = None, None
+        n_items = 72
+        extras["setup_s"] = time.perf_counter() - t_setup
+        workload = (f"batch of 72 (filter, SCA) ramps {N}x{N}x{G} groups (seed 1000*filter+sca), {len(slots)} CALDIR sets resident per rank "
+                    f"({len(slots) * 3.1:.0f} GB), item i on rank i mod {world}; a step is one item, the rank's items are walked round and round")
+
+    # work-item scatter: rank 0 owns the list of (exposure, SCA) indices; item i goes to rank i % world
+    items = torch.arange(n_items, dtype=torch.int32, device=dev) if rank == 0 else torch.empty(n_items, dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.broadcast(items, src=0)
+    mine = items[rank::world].tolist()
+    assert len(mine) >= 1
+
+    elapsed, ms, ncalls = run_steps(cb, calls, args.warmup, args.steps, fence)
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
-
-    # sanity: the result of the last step is a real calibration (most active pixels carry no flag, slopes finite)
-    good = (o_pdq[nb:-nb, nb:-nb] == 0)
-    frac_good = float(good.float().mean().item())
-    finite = bool(torch.isfinite(o_slope[nb:-nb, nb:-nb][good]).all().item())
-    if not (frac_good > 0.5 and finite):
-        raise SystemExit(f"bench sanity check failed: good fraction {frac_good}, finite {finite}")
+    frac_good = sane(res)
 
     if rank == 0:
-        total, per_kernel = alg_bytes(G, N, N, nb, p_order + 1, ipc_size=8 if args.ipc_dtype == "f64" else 4)
-        fused = ms[2] < 0.05 * max(ncalls, 1) and ms[3] < 0.05 * max(ncalls, 1)  # only event gaps
-        names = ["refpix_prepass", "chain_fused" if fused else "cube_stage", "ipc", "rampfit"]
-        per_kernel["chain_fused"] = total - G * N * 128 * 2 - N * 128 * 4  # everything but the reference-output block
-        avg_ms = {n: ms[i] / max(ncalls, 1) for i, n in enumerate(names) if not (fused and i >= 2)}
-        # dominant kernel: the fused chain (the pre-pass runs on a second stream UNDER it, so its own event-to-event time is
-        # stretched by the overlap and is not a duration of exclusive use); on the stage path the slowest stage kernel
-        dom = "chain_fused" if fused else max((n for n in avg_ms if n != "refpix_prepass"), key=avg_ms.get)
-        chain_ms = sum(avg_ms.values())
-        ach = per_kernel[dom] / (avg_ms[dom] * 1e-3) / 1e9
+        total, per_kernel, avg_ms, dom, ach = kernel_report(G, args.p_order, args.ipc_dtype, ms, ncalls)
         wall_ms = 1e3 * elapsed / args.steps  # per ramp and GPU; the pre-pass of ramp n+1 overlaps the chain of ramp n
-        # HBM traffic of the dominant kernel: PMC measurement of the same command, committed under profiles/
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
-        if dom == "chain_fused" and (G, N, p_order, args.ipc_dtype) == (8, 4096, 8, "f32") and os.path.exists(tpath):
-            with open(tpath) as tf:
-                traffic = json.load(tf).get("traffic_bytes_per_launch")
+        # HBM traffic of the dominant kernel: PMC measurement of the SAME command, committed under profiles/ (not measured by
+        # this run: counters need rocprofv3); null when no profile of this configuration and kernel build is there
+        traffic, traffic_source = None, None
+        for tag in ("r02", "r01"):
+            tpath = os.path.join(REPO, "profiles", f"{tag}_hbm_traffic.json")
+            if dom == "chain_fused" and (G, N, args.p_order, args.ipc_dtype, args.workload) == (8, 4096, 8, "f32", "single") \
+                    and os.path.exists(tpath):
+                with open(tpath) as tf:
+                    tj = json.load(tf)
+                traffic = tj.get("traffic_bytes_per_launch")
+                traffic_source = (f"profiles/{tag}_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                  f"(tools/profile_round.sh), kernel {tj.get('kernel')}; not re-measured by this run")
+                break
         out = {
             "metric": "SCA ramps/sec (4096x4096x8grp full L1->L2 chain)" if (G, N) == (8, 4096) else f"SCA ramps/sec ({N}x{N}x{G}grp full L1->L2 chain)",
             "value": world * args.steps / elapsed,
@@ -253,20 +365,91 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.ipc_dtype == "f32" else "f32 (IPC stage in f64)",
             "data": "synthetic",
-            "config": {"workload": f"single {N}x{N}x{G}-group ramp, full CALDIR (linearitylegendre P_ORDER {p_order} + ipc4d + "
-                                   f"biascorr + dark + read + flat), u16 cube resident in HBM, f32 gain / {args.ipc_dtype} ipc4d",
-                       "ramps_per_step_per_gpu": 1, "sharding": f"ramps round-robin over {world} GPU(s), index list broadcast over RCCL"},
+            "config": {"workload": workload, "ramps_per_step_per_gpu": 1,
+                       "sharding": f"ramps round-robin over {world} GPU(s), index list broadcast over RCCL"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_kernel": per_kernel[dom], "kernel_ms": avg_ms[dom]},
-            "chain": {"alg_bytes_per_ramp": total, "kernel_ms": avg_ms, "kernel_ms_sum": chain_ms,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "alg_bytes_kernel": per_kernel[dom], "kernel_ms": avg_ms[dom],
+                         "kernel_form": {0: "stage kernels", 1: "general fused", 2: "wave-specialised fused (chain2_kernel.h)",
+                                         3: "wave-private fused (chain3_kernel.h)"}.get(cb.ctx.last_chain_form())},
+            "chain": {"alg_bytes_per_ramp": total, "kernel_ms": avg_ms,
                       "wall_ms_per_ramp": wall_ms, "achieved_GBs": total / (wall_ms * 1e-3) / 1e9,
                       "frac_of_peak": total / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "good_pixel_fraction": frac_good},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        out["chain"]["kernel_ms"]["refpix_prepass_note"] = ("event-to-event on the second stream while the previous ramp's chain "
+                                                           "kernel holds the CUs: not a duration of exclusive use; see refpix_prepass_exclusive")
+        out.update(extras)
+
+        if world == 1 and not args.no_extras and args.workload == "single":
+            # ---- pre-pass alone (overlap off: every kernel of a call runs on one stream, so event gaps are exclusive times)
+            cb.ctx.set_option("overlap", 0)
+            el0, ms0, nc0 = run_steps(cb, calls, 2, 8, fence)
+            cb.ctx.set_option("overlap", 1)
+            ex = ms0[0] / max(nc0, 1)
+            out["chain"]["kernel_ms"]["refpix_prepass_exclusive"] = ex
+            out["chain"]["kernel_ms"]["chain_fused_no_overlap"] = ms0[1] / max(nc0, 1)
+            out["chain"]["kernel_ms_sum_exclusive"] = ex + ms0[1] / max(nc0, 1)
+            out["chain"]["frac_of_peak_sum_of_kernels"] = total / ((ex + ms0[1] / max(nc0, 1)) * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["chain"]["wall_ms_per_ramp_no_overlap"] = 1e3 * el0 / 8
+
+            # ---- production-representative variants (measured by the driver's run, not only by the builder)
+            variants = {}
+            del res, calls
+            for vname, vg, vp, vk in (("ipc4d_f64", 8, 8, "f64"), ("groups16", 16, 8, "f32"), ("p_order10", 8, 10, "f32"),
+                                      ("ipc4d_f64_groups16", 16, 8, "f64")):
+                rp_v, cal_v, ramp_v = make_inputs(vg, vp, vk, 2000 + vg + vp, 3)
+                cb.load_caldir(1, cal_v)
+                pid_v, _m = cb.plan_for(rp_v, ramp_v["frame_time"])
+                res_v = Resident(torch, dev, ramp_v)
+                el_v, ms_v, nc_v = run_steps(cb, [call_for(1, pid_v, vg, res_v)], 2, 10, fence)
+                sane(res_v)
+                tot_v, pk_v, avg_v, dom_v, ach_v = kernel_report(vg, vp, vk, ms_v, nc_v)
+                variants[vname] = {"ramps_per_s": 10 / el_v, "kernel": dom_v, "kernel_ms": avg_v[dom_v], "alg_bytes_kernel": pk_v[dom_v],
+                                   "frac": ach_v / HBM_PEAK_GBS, "kernel_form": cb.ctx.last_chain_form(),
+                                   "config": f"{N}x{N}x{vg} groups, P_ORDER {vp}, {vk} ipc4d"}
+                cb.ctx.drop_caldir(1)
+                del res_v, cal_v, ramp_v
+            out["variants"] = variants
+
+            # ---- BASELINE config 4 on one GPU: 18 CALDIR slots resident, 72 items walked in (filter, SCA) order.  To keep the
+            # default run short, 3 distinct CALDIR sets are uploaded 6 times each and 8 distinct ramps per set are reused;
+            # `--workload batch72` builds all 18 sets and 72 ramps.
+            t_b = time.perf_counter()
+            rp8 = synth.READ_PATTERN_8
+            sets, calls_b, keep = [], [], []
+            outs_b = Outputs(torch, dev, 8, N, N)
+            for k in range(3):
+                c = synth_gpu.make_caldir(N, N, read_pattern=rp8, p_order=8, seed=5000 + k, device=local_rank)
+                for j in range(6):
+                    cb.load_caldir(2 + k * 6 + j, c)
+                rs = []
+                for q in range(4):
+                    r = synth_gpu.make_ramp(c, read_pattern=rp8, seed=1000 * q + k, device=local_rank)
+                    rs.append(Resident(torch, dev, r, outs_b))
+                sets.append(rs)
+                del c
+            pid_b, _m = cb.plan_for(rp8, synth.FRAME_TIME)
+            for i in range(72):
+                filt, sca = i // 18, i % 18
+                rr_ = sets[sca // 6][filt]
+                keep.append(rr_)
+                calls_b.append(call_for(2 + sca, pid_b, 8, rr_))
+            el_b, ms_b, nc_b = run_steps(cb, calls_b, 4, 72, fence)
+            sane(keep[-1])
+            single_ms = 1e3 * elapsed / args.steps
+            out["batch72"] = {"ramps_per_s": 72 / el_b, "ms_per_ramp": 1e3 * el_b / 72, "slots_resident": 18,
+                              "caldir_bytes_resident": 18 * 3.1e9, "items": 72,
+                              "slot_switch_cost_ms": 1e3 * el_b / 72 - single_ms, "setup_s": time.perf_counter() - t_b,
+                              "note": "every item runs against another CALDIR slot than the item before; 3 distinct sets x 6 uploads and "
+                                      "12 distinct ramps stand in for 18 sets / 72 ramps (--workload batch72 builds them all)"}
+            for s_ in range(2, 20):
+                cb.ctx.drop_caldir(s_)
+            del sets, calls_b, keep
+
+        if world == 1 and not args.no_cpu_baseline and cal is not None:
             out["cpu_baseline"] = cpu_baseline(cal, ramp)
             if N == 4096:
-                out["cpu_baseline"]["replicas"] = cpu_replicas(248, G, p_order, args.ipc_dtype == "f64")
+                out["cpu_baseline"]["replicas"] = cpu_replicas(248, G, args.p_order, args.ipc_dtype == "f64")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

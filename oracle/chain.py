@@ -25,8 +25,19 @@ DEFAULT_RAMP_OPT_PARS = {"slope": 0.4, "gain": 1.8, "sigma_read": 6.5}
 
 
 def calibrate_arrays(ramp, cal, exclude_first=True, ramp_opt_pars=None, jump_pars=None,
-                     area_factor=None, nborder=4, stages=None):
-    """Returns dict(slope, err_read, err_poisson, pixeldq, groupdq, data (the corrected cube), K, meta)."""
+                     area_factor=None, nborder=4, stages=None, timings=None):
+    """Returns dict(slope, err_read, err_poisson, pixeldq, groupdq, data (the corrected cube), K, meta).
+    ``timings``: optional dict that receives the seconds spent per stage (refpix, bias_lin, ipc, rampfit, finish)."""
+    import time as _time
+
+    _t = [_time.perf_counter()]
+
+    def _lap(name):
+        if timings is not None:
+            now = _time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + now - _t[0]
+            _t[0] = now
+
     nb = nborder
     data = np.array(ramp["data"], dtype=np.float32)  # dq-init: u16 -> f32
     rdq = np.array(ramp["groupdq"], dtype=np.uint8)
@@ -49,6 +60,7 @@ def calibrate_arrays(ramp, cal, exclude_first=True, ramp_opt_pars=None, jump_par
     else:
         data, refdiag = refpix.correct_cube(data, cal["dark"]["data"], None, None, None)
 
+    _lap("refpix")
     # bias (:559-565)
     if "biascorr" in cal:
         b = cal["biascorr"]["data"]
@@ -64,18 +76,21 @@ def calibrate_arrays(ramp, cal, exclude_first=True, ramp_opt_pars=None, jump_par
     )
     pdq |= dq_lin
 
+    _lap("bias_lin")
     # IPC (:594-597)
     kern = cal["ipc4d"]["data"] if "ipc4d" in cal else None
     gain = cal["gain"]["data"]
     if kern is not None:
         ipc.correct_cube(data, kern, gain)
 
+    _lap("ipc")
     # ramp fit (:434-463)
     uopt = ramp_opt_pars or DEFAULT_RAMP_OPT_PARS
     u_ = float(uopt["slope"]) / float(uopt["gain"]) / float(uopt["sigma_read"]) ** 2
     meta["K"] = rampfit.construct_weights(u_, meta, exclude_first)
     slope, er, ep = rampfit.ramp_fit(data, rdq, pdq, gain, rd["data"], meta, exclude_first, jump_pars)
 
+    _lap("rampfit")
     # dark rate, error algebra, flat (:188-233, :607-629)
     dk = cal["dark"]
     dark_rate = fin.dark_rate_deconvolved(dk["dark_slope"], kern, gain)
@@ -89,6 +104,7 @@ def calibrate_arrays(ramp, cal, exclude_first=True, ramp_opt_pars=None, jump_par
         slope /= flat
         er /= flat
         ep /= flat
+    _lap("finish")
     return {
         "slope": slope, "err_read": er, "err_poisson": ep, "pixeldq": pdq, "groupdq": rdq,
         "data": data, "K": meta["K"], "meta": meta, "flat": flat_dn, "refpix_diag": refdiag,
