@@ -551,3 +551,59 @@ def test_back_to_back_device_calls_without_sync(flag_sat):
         assert not torch.equal(outs[0][0], outs[1][0])
     finally:
         cb.ctx.drop_caldir(9)
+
+
+def test_several_caldir_slots_resident_and_interleaved():
+    """BASELINE config 4 in small: several CALDIR sets (SCAs) resident at once, ramps of different (filter, SCA) items issued
+    interleaved and back to back, every result checked against the oracle run with that item's own calibration set."""
+    dev = torch.device("cuda", 0)
+    rp = synth.READ_PATTERN_8
+    ny, nx = 64, 256
+    ctx = gpu_context()
+    _default_form(ctx)
+    cb = pipeline.Calibrator(ctx=ctx)
+    scas = (3, 7, 12, 18)
+    cals = {}
+    for sca in scas:
+        kdt = np.float64 if sca == 12 else np.float32   # one production-style set with f64 ipc4d among them
+        cals[sca] = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=5000 + sca, ipc_dtype=kdt, bias_amplitude=1.0)
+        cb.load_caldir(sca, cals[sca])
+    pid, _meta = cb.plan_for(rp, synth.FRAME_TIME)
+
+    def to_dev(a):
+        a = np.ascontiguousarray(a)
+        view = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32}.get(a.dtype)
+        return torch.from_numpy(a.view(view) if view else a).to(dev)
+
+    items = [(f, s) for f in range(3) for s in scas]    # (filter, SCA), seed 1000 * filter + sca (SURVEY 8d)
+    order = [items[i] for i in (0, 5, 10, 3, 4, 9, 2, 7, 8, 1, 6, 11)]   # never the same slot twice in a row
+    refs, ins, outs = {}, {}, {}
+    for f, s in items:
+        r = synth.make_ramp(cals[s], read_pattern=rp, seed=1000 * f + s, cr_frac=0.02)
+        refs[(f, s)] = oracle.calibrate_arrays(r, cals[s])
+        g = r["groupdq"].copy()
+        g[0] |= 1
+        ins[(f, s)] = [to_dev(r["data"]), to_dev(r["amp33"]), to_dev(g), to_dev(r["pixeldq"])]
+        outs[(f, s)] = [torch.empty((ny, nx), dtype=torch.float32, device=dev) for _ in range(3)] + [
+            torch.empty((ny, nx), dtype=torch.int32, device=dev), torch.empty((8, ny, nx), dtype=torch.uint8, device=dev)]
+    torch.cuda.synchronize()
+    try:
+        for f, s in order:      # all queued, one synchronisation at the end
+            t, o = ins[(f, s)], outs[(f, s)]
+            cb.calibrate_device(s, pid, 8, t[0].data_ptr(), True, t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
+                                o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr())
+        cb.synchronize()
+        for key in items:
+            ref, o = refs[key], outs[key]
+            # channel lines are fitted on the device here: flags identical, floats within the north-star tolerance
+            assert_same_bits(o[3].cpu().numpy().view(np.uint32), ref["pixeldq"], f"pixeldq of item {key}")
+            assert_same_bits(o[4].cpu().numpy(), ref["groupdq"], f"groupdq of item {key}")
+            np.testing.assert_allclose(o[0].cpu().numpy(), ref["slope"], rtol=1e-5, atol=1e-7)
+            tot = np.hypot(ref["err_read"], ref["err_poisson"])
+            assert np.all(np.abs(o[1].cpu().numpy() - ref["err_read"]) <= 1e-5 * tot + 1e-12)
+            assert np.all(np.abs(o[2].cpu().numpy() - ref["err_poisson"]) <= 1e-5 * tot + 1e-12)
+        # the items do differ (a result computed against the wrong slot would not pass the checks above)
+        assert not np.array_equal(refs[(0, 3)]["slope"], refs[(0, 7)]["slope"])
+    finally:
+        for sca in scas:
+            cb.ctx.drop_caldir(sca)
