@@ -323,21 +323,24 @@ int rip_profile_read(rip_ctx *ctx, double out_ms[4], int *ncalls);
    configuration allows it (f32 gain; 4, 9 or 11 Legendre planes; LDS budget); 0 forces the
    stage-by-stage kernels.  Both give identical results. */
 int rip_set_option(rip_ctx *ctx, const char *name, int value);
-/* further options (all default 1, results identical either way; they exist for A/B timing and tests):
-   "chain2"  -- use the wave-specialised form of the fused kernel (chain2_kernel.h: f32 ipc4d, 6 or 8 groups) where it
-                applies, 0 = always the general fused kernel (chain_kernel.h);
+/* further options (results identical either way; they exist for A/B timing and tests):
+   "chain2"  -- (default 1) use the wave-specialised form of the fused kernel (chain2_kernel.h: f32 ipc4d with 6, 8 or 16
+                groups, f64 ipc4d with 6 or 8) where it applies, 0 = always the general fused kernel (chain_kernel.h);
+   "chain3"  -- (default 0) 1 = use the wave-private form (chain3_kernel.h) wherever it is instantiated; with 0 it runs
+                only where it is the one fused kernel that fits (f64 ipc4d with 16 groups);
    "overlap" -- run the reference-pixel pre-pass of a ramp on a second stream so that it overlaps the previous ramp's
                 fused kernel. */
 
-/* how the last rip_calibrate ran: 0 = stage kernels, 1 = general fused kernel, 2 = wave-specialised fused kernel */
+/* how the last rip_calibrate ran: 0 = stage kernels, 1 = general fused kernel, 2 = wave-specialised fused kernel,
+   3 = wave-private fused kernel */
 int rip_last_chain_form(rip_ctx *ctx);
 
 /* ---- diagnostics ------------------------------------------------------------------------- */
-/* relative half-width of the band around the jump threshold inside which the significance is
-   re-evaluated in the reference's exact operation order (default 1e-5; INFINITY = always exact).
-   Results do not depend on it unless it is set below ~1e-6; it exists so that tests can force
-   either path. */
-void rip_set_guard_band(double rel);
+/* floating-point options of a context.  "guard_band": relative half-width of the band around the jump
+   threshold inside which the significance is re-evaluated in the reference's exact operation order
+   (default 1e-5; INFINITY = always exact).  Results do not depend on it unless it is set below ~1e-6; it
+   exists so that tests can force either path.  Per context (round 1 had a process-wide setter). */
+int rip_set_option_f64(rip_ctx *ctx, const char *name, double value);
 
 #ifdef __cplusplus
 }

@@ -106,7 +106,7 @@ SYMBOLS = {
     "rip_stats_l1_diff": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "rip_stats_l2_pack": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rip_stats_reduce": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
-    "rip_set_guard_band": (None, [C.c_double]),
+    "rip_set_option_f64": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "rip_set_option": (_I, [_VP, C.c_char_p, _I]),
     "rip_last_chain_form": (_I, [_VP]),
     "rip_profile_enable": (_I, [_VP, _I]),
@@ -211,8 +211,12 @@ class Context:
     def set_option(self, name, value):
         self.check(self.lib.rip_set_option(self.h, name.encode(), int(value)))
 
+    def set_option_f64(self, name, value):
+        """floating-point options of this context ("guard_band")"""
+        self.check(self.lib.rip_set_option_f64(self.h, name.encode(), float(value)))
+
     def last_chain_form(self):
-        """0 = stage kernels, 1 = general fused kernel, 2 = wave-specialised fused kernel (last calibrate call)."""
+        """0 = stage kernels, 1 = general fused, 2 = wave-specialised fused, 3 = wave-private fused kernel (last calibrate call)."""
         return int(self.lib.rip_last_chain_form(self.h))
 
     def profile(self, on=True):

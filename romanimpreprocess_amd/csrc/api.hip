@@ -9,7 +9,6 @@
 
 #include "rip_common.h"
 
-double rip_guard_band = 1e-5;  // relative half-width of the exact-order re-evaluation band (rampfit.hip)
 static std::string g_create_error;
 
 int rip_fail(rip_ctx *ctx, int code, const char *fmt, ...) {
@@ -179,7 +178,14 @@ void rip_host_free(rip_ctx *ctx, void *p) {
     if (p) (void)hipHostFree(p);
 }
 
-void rip_set_guard_band(double rel) { rip_guard_band = rel; }
+int rip_set_option_f64(rip_ctx *ctx, const char *name, double value) {
+    if (name && strcmp(name, "guard_band") == 0) {
+        if (!(value >= 0.0)) return rip_fail(ctx, RIP_EINVAL, "guard_band must be >= 0 (INFINITY = exact path everywhere)");
+        ctx->guard_band = value;
+        return RIP_OK;
+    }
+    return rip_fail(ctx, RIP_EINVAL, "unknown option %s", name ? name : "(null)");
+}
 
 int rip_set_option(rip_ctx *ctx, const char *name, int value) {
     if (name && strcmp(name, "fused") == 0) {

@@ -874,7 +874,6 @@ static inline size_t chain2_lds_bytes(int G, size_t ksize = 4) {
 
 template <int NP, int G, int START, typename KT = float>
 static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
-    extern double rip_guard_band;
     const size_t lds = chain2_lds_bytes(G, sizeof(KT));
     static int ncu = 0;
     if (!ncu) {
@@ -896,7 +895,7 @@ static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((chain2_kernel<NP, G, START, KT>), dim3((unsigned)grid), dim3(C2_THREADS), lds, ctx->stream, a,
                        reinterpret_cast<const RipPlanHeader *>(plan->dev), plan->d_variants, plan->d_k, plan->d_diffs,
-                       rip_guard_band);
+                       ctx->guard_band);
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
 }

@@ -867,7 +867,6 @@ constexpr int chain3_wps() {
 
 template <int NP, int G, int START, typename KT = float>
 static int launch_chain3_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
-    extern double rip_guard_band;
     constexpr int WPS = chain3_wps<G, KT>();
     static int ncu = 0;
     if (!ncu) {
@@ -898,7 +897,7 @@ static int launch_chain3_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
     const long grid = (long)nranges * nwgx;
     hipLaunchKernelGGL((chain3_kernel<NP, G, START, KT, WPS>), dim3((unsigned)grid), dim3(C3_THREADS), lds, ctx->stream, a,
                        reinterpret_cast<const RipPlanHeader *>(plan->dev), plan->d_variants, plan->d_k, plan->d_diffs,
-                       rip_guard_band);
+                       ctx->guard_band);
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
 }

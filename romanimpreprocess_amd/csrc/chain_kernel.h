@@ -626,7 +626,6 @@ static inline size_t chain_lds_tables(int G, int rc_rows) { return (size_t)(3 * 
 
 template <int NP, int G, typename KT>
 static int launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
-    extern double rip_guard_band;
     const size_t lds0 = chain_lds_bytes(G, sizeof(KT) == 8 ? RIP_F64 : RIP_F32);
     static int ncu = 0;
     if (!ncu) {
@@ -649,7 +648,7 @@ static int launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((chain_kernel<NP, G, KT>), dim3((unsigned)grid), dim3(CH_BT), lds, ctx->stream, a,
                        reinterpret_cast<const RipPlanHeader *>(plan->dev), plan->d_variants, plan->d_k, plan->d_diffs,
-                       rip_guard_band);
+                       ctx->guard_band);
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
 }

@@ -61,19 +61,18 @@ int rip_launch_rampfit(rip_ctx *ctx, const RipPlan *plan, const RampFitArgs &a, 
     const unsigned blocks = (unsigned)((npix + RF_THREADS - 1) / RF_THREADS);
     const size_t lds = (size_t)a.ngrp * RF_THREADS * 6;
     const RipPlanHeader *h = reinterpret_cast<const RipPlanHeader *>(plan->dev);
-    extern double rip_guard_band;
     if (gain_dtype == RIP_F64) {
         if (lds > 48 * 1024)
             RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rampfit_kernel<double>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(rampfit_kernel<double>, dim3(blocks), dim3(RF_THREADS), lds, ctx->stream, a, h,
-                           plan->d_variants, plan->d_k, plan->d_diffs, rip_guard_band);
+                           plan->d_variants, plan->d_k, plan->d_diffs, ctx->guard_band);
     } else {
         if (lds > 48 * 1024)
             RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rampfit_kernel<float>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(rampfit_kernel<float>, dim3(blocks), dim3(RF_THREADS), lds, ctx->stream, a, h,
-                           plan->d_variants, plan->d_k, plan->d_diffs, rip_guard_band);
+                           plan->d_variants, plan->d_k, plan->d_diffs, ctx->guard_band);
     }
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;

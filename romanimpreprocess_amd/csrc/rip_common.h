@@ -132,6 +132,7 @@ struct rip_ctx {
     int chain_dbg = 0;
     unsigned long long *chain_dbg_buf = nullptr;  // 4096 waves x 6 phases (diagnostic builds)
     bool use_fused = true;  // rip_set_option("fused", 0) forces the stage-by-stage kernels
+    double guard_band = 1e-5;  // relative half-width of the exact-order re-evaluation band of the jump test (rip_set_option_f64)
     bool prof = false;
     std::vector<hipEvent_t> prof_events;  // 6 per rip_calibrate call
     void *ws[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -127,11 +127,11 @@ def test_fused_exact_everywhere_gives_same_flags():
     cb = pipeline.Calibrator(ctx=ctx)
     cb.load_caldir(2, cal)
     a = cb.calibrate(2, ramp)
-    ctx.lib.rip_set_guard_band(float("inf"))
+    ctx.set_option_f64("guard_band", float("inf"))
     try:
         b = cb.calibrate(2, ramp)
     finally:
-        ctx.lib.rip_set_guard_band(1e-5)
+        ctx.set_option_f64("guard_band", 1e-5)
     for k in ("slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
         assert_same_bits(a[k], b[k], k)
     assert np.count_nonzero(a["pixeldq"] & 4) > 100
@@ -607,3 +607,38 @@ def test_several_caldir_slots_resident_and_interleaved():
     finally:
         for sca in scas:
             cb.ctx.drop_caldir(sca)
+
+
+@pytest.mark.parametrize("form", [2, 0])
+def test_read_file_without_reference_output(form):
+    """A read-noise file without ``amp33``: the reference's row step then fits its slope on an all-zero reference block
+    (reference_subtraction.py:104-117, np.polyfit on a rank-deficient system: slope 0) and multiplies it by row medians that
+    are all zero, i.e. it leaves the image as it is; the channel step still acts.  The oracle runs that branch as written
+    (oracle/refpix.row_step with slope None); the device treats the row step as the identity (refpix.hip) -- same bits."""
+    rp = synth.READ_PATTERN_8
+    ny, nx = 64, 256
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=81, bias_amplitude=1.0)
+    cal["read"] = {k: v for k, v in cal["read"].items() if k != "amp33"}
+    ramp = synth.make_ramp(dict(cal, read=dict(cal["read"], amp33={"med": np.full((ny, 128), 29000.0, np.float32),
+                                                                  "std": np.full((ny, 128), 4.0, np.float32),
+                                                                  "M_PINK": 0.8, "RU_PINK": 1.0})), read_pattern=rp, seed=82, cr_frac=0.02)
+    ramp["amp33"] = None
+    with np.errstate(all="ignore"):
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # numpy's RankWarning of the degenerate fit
+            ref = oracle.calibrate_arrays(ramp, cal)
+    ctx = gpu_context()
+    _set_form(ctx, form)
+    cb = pipeline.Calibrator(ctx=ctx)
+    cb.load_caldir(10, cal)
+    try:
+        got = cb.calibrate(10, ramp, want_cube=True, channel_lines=_oracle_lines(ref, len(rp), nx // 128))
+        assert_same_bits(got["cube"], ref["data"], "corrected cube", zero_sign_ok=True)
+        assert_same_bits(got["pixeldq"], ref["pixeldq"], "pixeldq")
+        for k in ("slope", "err_read", "err_poisson"):
+            assert_same_bits(got[k], ref[k], k, zero_sign_ok=True)
+    finally:
+        _default_form(ctx)
+        cb.ctx.drop_caldir(10)

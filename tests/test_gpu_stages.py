@@ -94,11 +94,11 @@ def test_ramp_fit(name, guard):
     meta, caldir, ef = _rampfit_inputs(g)
     assert_same_bits(meta["K"], g["K"], "K")
     rdq, pdq = g["groupdq"].copy(), g["pixeldq"].copy()
-    ctx.lib.rip_set_guard_band(guard)
+    ctx.set_option_f64("guard_band", guard)
     try:
         slope, er, ep = fitting.ramp_fit(g["data"], rdq, pdq, meta, caldir, ProcessLog(), exclude_first=ef, ctx=ctx)
     finally:
-        ctx.lib.rip_set_guard_band(1e-5)
+        ctx.set_option_f64("guard_band", 1e-5)
     assert_same_bits(rdq, g["groupdq_out"], "groupdq")
     assert_same_bits(pdq, g["pixeldq_out"], "pixeldq")
     assert_same_bits(slope, g["slope"], "slope", zero_sign_ok=True)
