@@ -135,6 +135,12 @@ typedef struct {
     int32_t flag_saturation;
     int32_t sat_backup;      /* config SATURATION_BACKUP (gen_cal_image.py:172), default 1 */
     int32_t sat_skip_firstn; /* 1 in the reference's call */
+    /* groups that average several reads: a pixel whose LAST reads saturate holds a group value below the threshold, so
+       the group is compared with threshold * sat_dilution[g], sat_dilution[g] = mean(read_pattern[g]) / read_pattern[g][-1]
+       (stcal's read_pattern rule, "checks for groups with some reads saturated", docs/L1_to_L2_README.rst:139-141; the
+       reference hands the read pattern over at gen_cal_image.py:172-185).  Host pointer to ngrp doubles (also for device
+       ramps), or NULL = 1 for every group.  A NaN entry (0/0 for a group holding only read 0) never flags. */
+    const double *sat_dilution;
 } rip_ramp_desc;
 
 typedef struct {

@@ -111,7 +111,7 @@ def calibrateimage(config, verbose=True, calibrator=None):
     if sat_on_device:
         ramp["groupdq"] = None  # zeros + DO_NOT_USE on the first group: made on the device
     res = cb.calibrate(slot, ramp, exclude_first=exclude_first, ramp_opt_pars=config.get("RAMP_OPT_PARS"),
-                       jump_pars=config.get("JUMP_DETECT_PARS"), area_factor=area, flag_saturation=sat_on_device,
+                       jump_pars=config.get("JUMP_DETECT_PARS"), area_factor=area, flag_saturation=sat_on_device, saturation_read_pattern=True,
                        saturation_backup=backup)
     K = res["K"]
     uopt = config.get("RAMP_OPT_PARS", planmod.DEFAULT_RAMP_OPT_PARS)

@@ -58,6 +58,7 @@ class RampDesc(C.Structure):
         ("amp33", C.c_void_p), ("groupdq", C.c_void_p), ("pixeldq", C.c_void_p), ("area_factor", C.c_void_p),
         ("channel_lines", C.c_void_p),
         ("flag_saturation", C.c_int32), ("sat_backup", C.c_int32), ("sat_skip_firstn", C.c_int32),
+        ("sat_dilution", C.c_void_p),
     ]
 
 

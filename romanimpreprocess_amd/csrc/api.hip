@@ -724,7 +724,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         uint32_t *p2 = (uint32_t *)(w + (size_t)par * one + al(b_gdq));
         const int dnu_first = (plan && plan->h.start == 1) ? 1 : 0;  // the plan excludes the first group
         const int rcs = rip_launch_satflag(ctx, d_data, in->data_dtype, c.sat_thr, c.sat_dq, d_gdq, d_pdq, g2, p2, G, ny, nx,
-                                           in->sat_backup, in->sat_skip_firstn, dnu_first);
+                                           in->sat_backup, in->sat_skip_firstn, dnu_first, in->sat_dilution);
         d_gdq = g2;
         d_pdq = p2;
         return rcs;

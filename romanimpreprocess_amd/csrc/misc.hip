@@ -95,10 +95,14 @@ int rip_launch_flat_area(rip_ctx *ctx, const float *flat_dn, const double *area,
 // Two passes, one thread per pixel: (1) bit g of a per-pixel word = that pixel's own resultant g exceeds its own
 // threshold (the cube is read once, coalesced); (2) OR of the nine neighbours' words, the time logic on the bits, flags.
 // four consecutive pixels per thread (nx is a multiple of 4): 8-byte loads of the u16 cube, 4-byte stores of the flags
+struct SatDilution {
+    double f[64];  // per group: mean(read_pattern[g]) / read_pattern[g][-1], or 1
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void sat_exceed_kernel(const T *__restrict__ data, const float *__restrict__ thr,
                                                          const uint32_t *__restrict__ sat_dq, uint64_t *__restrict__ ex,
-                                                         int G, size_t npix, int skip) {
+                                                         int G, size_t npix, int skip, const SatDilution dil, int use_dil) {
     const size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (p >= npix) return;
     const float4 th = *reinterpret_cast<const float4 *>(thr + p);
@@ -120,9 +124,16 @@ __global__ __launch_bounds__(256) void sat_exceed_kernel(const T *__restrict__ d
             const float4 w = *reinterpret_cast<const float4 *>(data + (size_t)g * npix + p);
             d[0] = w.x, d[1] = w.y, d[2] = w.z, d[3] = w.w;
         }
+        if (use_dil) {  // threshold of a group of several reads: f64(threshold) * mean(reads) / last read
+            const double f = dil.f[g];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (d[i] >= t[i]) m[i] |= 1ull << g;
+            for (int i = 0; i < 4; ++i)
+                if ((double)d[i] >= (double)t[i] * f) m[i] |= 1ull << g;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (d[i] >= t[i]) m[i] |= 1ull << g;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) ex[p + i] = m[i];
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(256) void sat_flags_kernel(const uint64_t *__restri
 
 int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const float *thr, const uint32_t *sat_dq,
                        const uint8_t *gdq_in, const uint32_t *pdq_in, uint8_t *gdq_out, uint32_t *pdq_out, int G, int ny,
-                       int nx, int backup, int skip_firstn, int dnu_first) {
+                       int nx, int backup, int skip_firstn, int dnu_first, const double *dilution) {
     if (G < 1 || G > 64 || backup < 0 || skip_firstn < 0 || skip_firstn > G)
         return rip_fail(ctx, RIP_EINVAL, "saturation flagging: bad group / backup / skip arguments");
     if (nx % 4) return rip_fail(ctx, RIP_EINVAL, "saturation flagging: nx=%d is not a multiple of 4", nx);
@@ -184,12 +195,15 @@ int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const flo
     uint64_t *ex = (uint64_t *)rip_ws(ctx, 9, npix * 8);
     if (!ex) return RIP_ENOMEM;
     const dim3 g1((unsigned)((npix / 4 + 255) / 256)), block(256);
+    SatDilution dil;
+    for (int g = 0; g < 64; ++g) dil.f[g] = (dilution && g < G) ? dilution[g] : 1.0;
+    const int use_dil = dilution ? 1 : 0;
     if (data_dtype == RIP_U16)
         hipLaunchKernelGGL(sat_exceed_kernel<uint16_t>, g1, block, 0, ctx->stream, (const uint16_t *)data, thr, sat_dq, ex, G, npix,
-                           skip_firstn);
+                           skip_firstn, dil, use_dil);
     else
         hipLaunchKernelGGL(sat_exceed_kernel<float>, g1, block, 0, ctx->stream, (const float *)data, thr, sat_dq, ex, G, npix,
-                           skip_firstn);
+                           skip_firstn, dil, use_dil);
     hipLaunchKernelGGL(sat_flags_kernel, dim3((nx / 4 + 255) / 256, ny), block, 0, ctx->stream, ex, gdq_in, pdq_in, gdq_out, pdq_out, G,
                        ny, nx, backup, skip_firstn, dnu_first);
     RIP_HIP(ctx, hipGetLastError());

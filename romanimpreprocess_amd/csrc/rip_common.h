@@ -269,4 +269,4 @@ int rip_launch_flat_area(rip_ctx *ctx, const float *flat_dn, const double *area,
 // dq-init + saturation flagging (misc.hip): gdq_in / pdq_in may be null (= zeros)
 int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const float *thr, const uint32_t *sat_dq,
                        const uint8_t *gdq_in, const uint32_t *pdq_in, uint8_t *gdq_out, uint32_t *pdq_out, int G, int ny,
-                       int nx, int backup, int skip_firstn, int dnu_first);
+                       int nx, int backup, int skip_firstn, int dnu_first, const double *dilution = nullptr);

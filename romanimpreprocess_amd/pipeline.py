@@ -13,6 +13,13 @@ from ._native import (STAGE_ALL, STAGE_BIAS, STAGE_DARK, STAGE_FLAT, STAGE_IPC, 
                       STAGE_REFPIX)
 
 
+def read_pattern_dilution(read_pattern):
+    """mean(read indices) / last read index per group (f64; 0/0 = NaN for a group holding only read 0: never flags): the
+    factor stcal applies to the saturation threshold of groups that average several reads (rip_ramp_desc::sat_dilution)."""
+    with np.errstate(all="ignore"):
+        return np.ascontiguousarray([np.float64(np.mean(r)) / np.float64(r[-1]) for r in read_pattern], dtype=np.float64)
+
+
 class Calibrator:
     def __init__(self, device=None, ctx=None):
         self.ctx = ctx if ctx is not None else _native.default_context(device)
@@ -51,7 +58,7 @@ class Calibrator:
     # ---- host arrays in, host arrays out --------------------------------------------------
     def calibrate(self, slot, ramp, exclude_first=True, ramp_opt_pars=None, jump_pars=None, area_factor=None,
                   stages=STAGE_ALL, want_groupdq=True, want_cube=False, channel_lines=None, flag_saturation=False,
-                  saturation_backup=1, saturation_skip_firstn=1, out=None):
+                  saturation_backup=1, saturation_skip_firstn=1, out=None, saturation_read_pattern=False):
         """Run the chain on one ramp given as numpy arrays.
 
         ``ramp``: dict(data u16|f32 (G,ny,nx), amp33 u16 (G,ny,128)|None, groupdq u8, pixeldq u32,
@@ -59,6 +66,8 @@ class Calibrator:
 
         ``flag_saturation``: dq-init + saturation flagging on the device before the chain (the CALDIR slot must hold
         ``saturation``); ``ramp["groupdq"]`` may then be None and ``ramp["pixeldq"]`` is the mask dq.
+        ``saturation_read_pattern``: compare groups of several reads with threshold * mean(reads) / last read (the read-pattern
+        rule of stcal the reference's call enables, gen_cal_image.py:172-185).
 
         ``out``: optional dict of preallocated C-contiguous result arrays (any of slope, err_read, err_poisson f32 (ny,nx),
         pixeldq u32 (ny,nx), groupdq u8 (G,ny,nx), cube f32 (G,ny,nx)) that are filled instead of new ones.  With page-locked
@@ -92,6 +101,8 @@ class Calibrator:
         rd.groupdq, rd.pixeldq = (None if gdq is None else gdq.ctypes.data), pdq.ctypes.data
         rd.flag_saturation = 1 if flag_saturation else 0
         rd.sat_backup, rd.sat_skip_firstn = int(saturation_backup), int(saturation_skip_firstn)
+        dil = read_pattern_dilution(ramp["read_pattern"]) if (flag_saturation and saturation_read_pattern) else None
+        rd.sat_dilution = None if dil is None else dil.ctypes.data
         rd.area_factor = None if area is None else area.ctypes.data
         rd.channel_lines = None if lines is None else lines.ctypes.data
 

@@ -171,7 +171,8 @@ def test_calibrateimage_files_end_to_end(tmp_path):
     r0 = {"data": ramp["data"], "amp33": ramp["amp33"], "groupdq": np.zeros(ramp["data"].shape, np.uint8),
           "pixeldq": cal["mask"]["dq"].copy(), "read_pattern": rp, "frame_time": synth.FRAME_TIME}
     r0["groupdq"][0] |= 1
-    saturation.flag_saturation(r0, cal["saturation"]["data"], backup=1, skip_firstn=1, sat_dq=cal["saturation"]["dq"])
+    saturation.flag_saturation(r0, cal["saturation"]["data"], backup=1, skip_firstn=1, sat_dq=cal["saturation"]["dq"],
+                               read_pattern=rp)   # the reference hands the read pattern to stcal (gen_cal_image.py:172-185)
     ref = oracle.calibrate_arrays(r0, cal, jump_pars=config["JUMP_DETECT_PARS"])
     act = (slice(4, -4), slice(4, -4))
     assert_same_bits(out["roman"]["dq"], ref["pixeldq"][act], "L2 dq")
@@ -332,6 +333,16 @@ def test_saturation_flagging_on_device_matches_host_restatement():
         b = cb.calibrate(6, r_dev, flag_saturation=True, saturation_backup=backup)
         for k in ("groupdq", "pixeldq", "slope", "err_read", "err_poisson"):
             assert_same_bits(a[k], b[k], f"{k} (backup {backup})")
+        # read-pattern rule (groups averaging several reads are compared with threshold * mean(reads) / last read): groups whose
+        # later reads alone saturate sit between the diluted and the full threshold -- flagged only with the rule on
+        h2 = {"data": ramp["data"], "groupdq": np.zeros(ramp["data"].shape, np.uint8), "pixeldq": mask.copy()}
+        saturation.flag_saturation(h2, thr, backup=backup, skip_firstn=1, n_pix_grow_sat=1, sat_dq=sdq, read_pattern=rp)
+        more = np.count_nonzero(h2["groupdq"] & 2) - np.count_nonzero(h["groupdq"] & 2)
+        assert more > 20, "the synthetic thresholds do not exercise partially saturated groups"
+        c = cb.calibrate(6, r_dev, flag_saturation=True, saturation_backup=backup, saturation_read_pattern=True)
+        d = cb.calibrate(6, dict(ramp, groupdq=h2["groupdq"], pixeldq=h2["pixeldq"]))
+        for k in ("groupdq", "pixeldq", "slope", "err_read", "err_poisson"):
+            assert_same_bits(c[k], d[k], f"{k} (backup {backup}, read-pattern rule)")
         cb.ctx.drop_caldir(6)
 
 

@@ -34,7 +34,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
                             "saturation_dq"],
         "rip_plan_desc": ["ngrp", "tbar", "nreads", "K", "nvariants", "variant_coef", "sthresh_a", "ithresh_b"],
         "rip_ramp_desc": ["location", "data", "data_dtype", "amp33", "area_factor", "channel_lines", "flag_saturation",
-                          "sat_skip_firstn"],
+                          "sat_skip_firstn", "sat_dilution"],
         "rip_outputs": ["location", "slope", "pixeldq", "groupdq", "cube"],
     }
     body = "".join(f'printf("{s} %zu\\n", sizeof({s}));\n' + "".join(
@@ -195,3 +195,22 @@ def test_sharding_world_size_2_gloo(tmp_path):
         assert f"rank {r} ok" in o
 
 
+
+
+def test_flag_saturation_read_pattern_rule():
+    """Groups averaging several reads are compared with threshold * mean(reads) / last read (partial saturation of the later
+    reads): a group value between the diluted and the full threshold is flagged only when the read pattern is handed over."""
+    from oracle.saturation import flag_saturation, read_pattern_dilution
+    rp = [[0], [1], [2, 3], [4, 5, 6, 7, 8, 9]]
+    dil = read_pattern_dilution(rp)
+    assert np.isnan(dil[0]) and dil[1] == 1.0 and dil[2] == 2.5 / 3.0 and dil[3] == 6.5 / 9.0
+    n = 7
+    thr = np.full((n, n), 1000.0, np.float32)
+    data = np.zeros((4, n, n), np.float32)
+    data[3, 3, 3] = 800.0        # below 1000, above 1000 * 6.5 / 9 = 722.2: its last reads saturated
+    data[2, 5, 5] = 800.0        # group [2, 3]: 1000 * 2.5 / 3 = 833.3 > 800: not flagged either way
+    for with_rp, expect in ((False, False), (True, True)):
+        ramp = {"data": data, "groupdq": np.zeros((4, n, n), np.uint8), "pixeldq": np.zeros((n, n), np.uint32)}
+        flag_saturation(ramp, thr, backup=0, skip_firstn=1, read_pattern=rp if with_rp else None)
+        sat = (ramp["groupdq"] & np.uint8(group.SATURATED)) != 0
+        assert bool(sat[3, 3, 3]) is expect and not sat[:, 5, 5].any() and not sat[:3].any()
