@@ -189,6 +189,9 @@ int rip_calibrate(rip_ctx *ctx, int sca_slot, int plan_id, unsigned stages, cons
    (rip_host_alloc) make the copies run at PCIe rate in both directions at once.  Returns when everything has arrived. */
 int rip_calibrate_batch(rip_ctx *ctx, int sca_slot, int plan_id, unsigned stages, int n, const rip_ramp_desc *in,
                         const rip_outputs *out);
+/* after rip_calibrate_batch: the number of ramps (from the front of the batch) whose outputs are complete.  n on success;
+   after an error return every stream has been drained, outputs [0, this) are valid and the rest are not. */
+int rip_calibrate_batch_completed(rip_ctx *ctx);
 
 /* ---- stage-level entry points (host arrays; for function-level drop-in and parity tests) ----- */
 

@@ -57,21 +57,49 @@ def initializationstep(config, caldir, mylog):
 def load_caldir_arrays(caldir):
     """``roman`` branches of the CALDIR files the per-pixel chain needs (KeyError on a missing required key)."""
     cal = {}
-    for key in ("dark", "read", "gain", "linearitylegendre", "ipc4d", "flat"):
+    for key in ("dark", "read", "gain", "linearitylegendre", "flat"):
         cal[key] = calio.roman_branch(caldir[key])
-    for key in ("biascorr", "saturation"):
+    for key in ("ipc4d", "biascorr", "saturation"):   # optional (no ipc4d: "skipping IPC correction", ipc_linearity.py:170-176)
         if key in caldir:
             cal[key] = calio.roman_branch(caldir[key])
     return cal
 
 
+def _file_stamp(path):
+    """(mtime, size) of a calibration file: a file rewritten in place must not be served stale from HBM"""
+    import os
+
+    try:
+        st = os.stat(path)
+        return (st.st_mtime_ns, st.st_size)
+    except OSError:
+        return None
+
+
 def _caldir_slot(cb, caldir):
-    key = (id(cb.ctx), tuple(sorted((k, str(v)) for k, v in caldir.items() if isinstance(v, str))))
+    """The CALDIR slot holding this set of files on the calibrator's context, uploading it first if need be.  The cache key
+    holds the paths AND each file's (mtime, size); a slot is taken from the top (31 downwards) only if nobody owns it or its
+    owner is one of this cache's own, older entries -- a slot a caller loaded explicitly (``Calibrator.load_caldir``) is never
+    replaced silently."""
+    files = tuple(sorted((k, str(v), _file_stamp(str(v))) for k, v in caldir.items() if isinstance(v, str)))
+    key = (id(cb.ctx), files)
     slot = _cal_cache.get(key)
-    if slot is not None and cb.slot_owner(slot) == key:   # still ours (an explicit load_caldir may have reused the slot)
+    if slot is not None and cb.slot_owner(slot) == key:   # still ours
         return slot
-    if slot is None:
-        slot = 31 - len(_cal_cache) % 24   # from the top: low slot numbers are left to explicit load_caldir calls
+    for cand in range(31, 7, -1):   # from the top: low slot numbers are left to explicit load_caldir calls
+        if cand not in cb.shapes:    # never loaded on this context
+            slot = cand
+            break
+    else:
+        # every slot is taken: evict the oldest entry of this cache (never an explicitly loaded slot)
+        slot = None
+        for k_old, s_old in list(_cal_cache.items()):
+            if k_old[0] == id(cb.ctx) and cb.slot_owner(s_old) == k_old:
+                slot = s_old
+                del _cal_cache[k_old]
+                break
+        if slot is None:
+            raise RuntimeError("no free CALDIR slot: slots 8..31 are all held by explicit load_caldir calls")
     cb.load_caldir(slot, load_caldir_arrays(caldir), owner=key)
     _cal_cache[key] = slot
     return slot

@@ -87,6 +87,7 @@ SYMBOLS = {
     "rip_plan_destroy": (_I, [_VP, _I]),
     "rip_calibrate": (_I, [_VP, _I, _I, C.c_uint, C.POINTER(RampDesc), C.POINTER(Outputs)]),
     "rip_calibrate_batch": (_I, [_VP, _I, _I, C.c_uint, _I, C.POINTER(RampDesc), C.POINTER(Outputs)]),
+    "rip_calibrate_batch_completed": (_I, [_VP]),
     "rip_stage_refpix_image": (_I, [_VP, _VP, _I, _I, C.c_double, _I, _I, _VP, _VP, _VP, _VP]),
     "rip_stage_multilin": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "rip_stage_ipc_image": (_I, [_VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _VP, _I, _VP]),

@@ -53,6 +53,7 @@ extern "C" int rip_calibrate_batch(rip_ctx *ctx, int slot, int plan_id, unsigned
     hipStream_t s_in = ctx->stream2, s_out = ctx->stream3;
     BatchSet set[2];
     int rc = RIP_OK;
+    ctx->batch_completed = 0;  // ramps whose results have been queued for download in full (valid after an error return too)
     auto cleanup = [&]() {   // waits for every stream; the device buffers stay with the context
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(s_in);
@@ -143,8 +144,11 @@ extern "C" int rip_calibrate_batch(rip_ctx *ctx, int slot, int plan_id, unsigned
         if (ro.groupdq) BATCH_HIP(hipMemcpyAsync(ro.groupdq, od.groupdq, (size_t)G * npix, hipMemcpyDeviceToHost, s_out));
         BATCH_HIP(hipEventRecord(b.ev_out, s_out));
         b.used = true;
+        ctx->batch_completed = i + 1;
     }
 #undef BATCH_HIP
     cleanup();   // waits for every stream
     return RIP_OK;
 }
+
+extern "C" int rip_calibrate_batch_completed(rip_ctx *ctx) { return ctx ? ctx->batch_completed : RIP_EINVAL; }

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void pink_fill_kernel(const double *__restrict
     z[(size_t)f * L + k] = v;
 }
 
-// sum of Re(Z)[0 : L/2] / sqrt(2) per frame (f64, two-level)
+// sum of Re(Z)[0 : L/2] / sqrt(2) per frame (f64): 256 block partials per frame, added in a FIXED order by pink_out_kernel
+// (an atomicAdd across blocks would make the subtracted mean, hence the frame, differ in the last bit from run to run)
 __global__ __launch_bounds__(256) void pink_sum_kernel(const hipfftDoubleComplex *__restrict__ z, size_t L, double *__restrict__ sums) {
     __shared__ double sh[256];
     const int f = blockIdx.y;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void pink_sum_kernel(const hipfftDoubleComplex
         if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(&sums[f], sh[0]);
+    if (threadIdx.x == 0) sums[(size_t)f * gridDim.x + blockIdx.x] = sh[0];
 }
 
 __global__ __launch_bounds__(256) void pink_out_kernel(const hipfftDoubleComplex *__restrict__ z, size_t L, const double *__restrict__ sums,
@@ -81,7 +82,9 @@ __global__ __launch_bounds__(256) void pink_out_kernel(const hipfftDoubleComplex
     const int f = blockIdx.y;
     const size_t half = L / 2;
     if (k >= half) return;
-    const double mean = sums[f] / (double)half;
+    double tot = 0.0;
+    for (int b = 0; b < 256; ++b) tot += sums[(size_t)f * 256 + b];  // same order in every thread and every run
+    const double mean = tot / (double)half;
     out[(size_t)f * half + k] = (float)(z[(size_t)f * L + k].x / sqrt(2.0) - mean);
 }
 
@@ -115,7 +118,7 @@ extern "C" int rip_stage_noise_1f(rip_ctx *ctx, int rows, int width, int nframes
     // frames are transformed in chunks so that the complex buffer stays below ~1 GB
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nframes, ((size_t)1 << 30) / (L * sizeof(hipfftDoubleComplex))));
     PK_HIP(hipMalloc((void **)&z, (size_t)chunk * L * sizeof(hipfftDoubleComplex)));
-    PK_HIP(hipMalloc((void **)&d_s, (size_t)chunk * sizeof(double)));
+    PK_HIP(hipMalloc((void **)&d_s, (size_t)chunk * 256 * sizeof(double)));
     PK_HIP(hipMalloc((void **)&d_o, (size_t)chunk * half * sizeof(float)));
     if (normals) PK_HIP(hipMalloc((void **)&d_n, (size_t)chunk * 2 * L * sizeof(double)));
     int n1 = (int)L;
@@ -142,7 +145,6 @@ extern "C" int rip_stage_noise_1f(rip_ctx *ctx, int rows, int width, int nframes
             done();
             return rc;
         }
-        PK_HIP(hipMemsetAsync(d_s, 0, (size_t)chunk * sizeof(double), ctx->stream));
         hipLaunchKernelGGL(pink_sum_kernel, dim3(256, nf), dim3(256), 0, ctx->stream, z, L, d_s);
         hipLaunchKernelGGL(pink_out_kernel, dim3((unsigned)((half + 255) / 256), nf), dim3(256), 0, ctx->stream, z, L, (const double *)d_s, d_o);
         PK_HIP(hipGetLastError());

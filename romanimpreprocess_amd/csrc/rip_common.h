@@ -141,6 +141,7 @@ struct rip_ctx {
     hipStream_t stream3 = nullptr;
     void *batch_buf[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t batch_bytes[4] = {0, 0, 0, 0};
+    int batch_completed = 0;  // of the last rip_calibrate_batch: ramps completed (all of them unless it returned an error)
 };
 
 // ---------------------------------------------------------------- host helpers
