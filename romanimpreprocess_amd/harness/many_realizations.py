@@ -77,9 +77,16 @@ def ideal_slope(cal, rate, nb=pars.nborder):
     return ideal
 
 
-def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=None, reference_alias=True):
+def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=None, reference_alias=True, generator="host",
+        timings=None):
     """Generate and calibrate ``nseeds`` realisations (this rank's share of them), exchange, reduce.  Returns the
-    (8, ny, nx) f32 planes as a numpy array on rank 0, None on the other ranks."""
+    (8, ny, nx) f32 planes as a numpy array on rank 0, None on the other ranks.
+
+    ``generator``: "host" = ``synth.make_ramp`` (numpy; minutes per full frame), "device" = ``synth_gpu.RampFactory`` (the same
+    recipe in torch on the GPU: about half a second per full frame, nothing crosses PCIe -- BASELINE config 5 at full size).
+    ``timings``: optional dict that receives the seconds spent generating, calibrating + stacking, and reducing."""
+    import time
+
     import torch
 
     device = device or torch.device("cuda", calibrator.ctx.device)
@@ -93,19 +100,34 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
     slope = torch.empty((ny, nx), dtype=torch.float32, device=device)
     er, ep = torch.empty_like(slope), torch.empty_like(slope)
     pdq = torch.empty((ny, nx), dtype=torch.int32, device=device)
+    factory, rate_t = None, None
+    if generator == "device":
+        from .. import synth_gpu
+
+        factory = synth_gpu.RampFactory(cal, rp, device=calibrator.ctx.device)
+        rate_t = torch.from_numpy(np.ascontiguousarray(rate)).to(device)
+    t_gen = t_cal = 0.0
     for k, sd in enumerate(seeds):
-        ramp = synth.make_ramp(cal, read_pattern=rp, seed=sd, rate=rate)
-        gdq = ramp["groupdq"].copy()
-        gdq[0] |= 1
-        cube = torch.from_numpy(ramp["data"].view(np.int16)).to(device)
-        a33 = torch.from_numpy(ramp["amp33"].view(np.int16)).to(device)
-        t_gdq = torch.from_numpy(gdq).to(device)
-        t_pdq = torch.from_numpy(ramp["pixeldq"].view(np.int32)).to(device)
+        t0 = time.perf_counter()
+        if factory is not None:
+            cube, a33, t_gdq, t_pdq = factory.make(sd, rate_t, poisson=True)
+        else:
+            ramp = synth.make_ramp(cal, read_pattern=rp, seed=sd, rate=rate)
+            gdq = ramp["groupdq"].copy()
+            gdq[0] |= 1
+            cube = torch.from_numpy(ramp["data"].view(np.int16)).to(device)
+            a33 = torch.from_numpy(ramp["amp33"].view(np.int16)).to(device)
+            t_gdq = torch.from_numpy(gdq).to(device)
+            t_pdq = torch.from_numpy(ramp["pixeldq"].view(np.int32)).to(device)
         torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
         calibrator.calibrate_device(slot, pid, len(rp), cube.data_ptr(), True, a33.data_ptr(), t_gdq.data_ptr(),
                                     t_pdq.data_ptr(), slope.data_ptr(), er.data_ptr(), ep.data_ptr(), pdq.data_ptr())
         st.push(k, cube, slope, er, ep, pdq)
         calibrator.synchronize()
+        t_gen += t1 - t0
+        t_cal += time.perf_counter() - t1
+    t_red = time.perf_counter()
     ideal = torch.from_numpy(ideal_slope(cal, rate, nb)).to(device)
     rows = []
     for stack in (st.diffs, st.images, st.err, st.good):
@@ -115,4 +137,7 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
     planes = reduce_rows(*rows, ideal[y0:y0 + nrows].contiguous(), y0, ny, nb=nb, reference_alias=reference_alias,
                          ctx=calibrator.ctx)
     full = sharding.gather_rows(planes, ny)
+    if timings is not None:
+        timings.update({"generate_s": t_gen, "calibrate_and_stack_s": t_cal, "exchange_and_reduce_s": time.perf_counter() - t_red,
+                        "realisations_on_this_rank": len(seeds)})
     return None if full is None else full.cpu().numpy()

@@ -159,85 +159,128 @@ def _ipc_forward(img, K):
     return out
 
 
+class RampFactory:
+    """Seeded Level-1 ramps of one scene / calibration set, generated on the device and LEFT there (the many-realisations
+    harness makes hundreds of them: the calibration arrays are uploaded once, each ramp takes about half a second of f64
+    torch work for a full frame and never crosses PCIe)."""
+
+    def __init__(self, cal, read_pattern=None, frame_time=synth.FRAME_TIME, nb=pars.nborder, device=0, exclude_first=True,
+                 saturation_backup=1):
+        self.dev = dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.rp = synth.READ_PATTERN_8 if read_pattern is None else read_pattern
+        self.G, self.nb, self.frame_time = len(self.rp), nb, frame_time
+        self.exclude_first, self.backup = exclude_first, saturation_backup
+        lin = cal["linearitylegendre"]
+        self.ny, self.nx = lin["Smin"].shape
+        self.t = synth.group_times(self.rp, frame_time)
+        self.nread = [float(len(r)) for r in self.rp]
+
+        def dv(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(F64)
+
+        self.gain, self.dark_slope = dv(cal["gain"]["data"]), dv(cal["dark"]["dark_slope"])
+        self.sigma_read, self.sat_level = dv(cal["read"]["data"]), dv(cal["saturation"]["data"])
+        self.K = dv(cal["ipc4d"]["data"])
+        self.Smin = dv(lin["Smin"])
+        self.span = dv(lin["Smax"]) - self.Smin
+        self.coef, self.Sref = dv(lin["data"]), dv(lin["Sref"])
+        self.dark = torch.from_numpy(np.ascontiguousarray(cal["dark"]["data"][:self.G])).to(dev)  # f32, widened per group
+        b = cal["biascorr"]["data"] if "biascorr" in cal else None
+        self.bias = None if b is None else torch.from_numpy(np.ascontiguousarray(b[b.shape[0] - self.G:])).to(dev)
+        a33 = cal["read"]["amp33"]
+        self.a33_med, self.a33_std, self.m_pink = dv(a33["med"]), dv(a33["std"]), float(a33["M_PINK"])
+        self.border = torch.ones((self.ny, self.nx), dtype=torch.bool, device=dev)
+        self.border[nb:self.ny - nb, nb:self.nx - nb] = False
+        self.mask = torch.from_numpy(np.array(cal["mask"]["dq"], dtype=np.uint32).view(np.int32)).to(dev)
+
+    def _phi(self, S):
+        z = 2 * (S - self.Smin) / self.span - 1
+        val, der = _legendre_tail(z, self.coef[1:], 1)
+        return self.coef[0] + val, der * 2.0 / self.span
+
+    def make(self, seed, rate, cr_frac=1e-3, poisson=False):
+        """``rate``: (ny, nx) tensor or array of linearised DN/s.  ``poisson``: accumulate Poisson electron counts read by read
+        (rate * gain * frame_time per read, averaged over the reads of each group -- the covariance structure the ramp-fit
+        weights and error estimates assume) instead of the noiseless signal.  Returns device tensors: data (G,ny,nx) int16 (the u16 bits),
+        amp33 (G,ny,128) int16, groupdq (G,ny,nx) uint8 (after dq-init + saturation flagging, DO_NOT_USE on group 0 when the
+        first group is excluded), pixeldq (ny,nx) int32."""
+        dev, G, ny, nx, nb = self.dev, self.G, self.ny, self.nx, self.nb
+        g = _gen(dev, 7_000_003 + int(seed))
+        zero = torch.zeros((), dtype=F64, device=dev)
+        one = torch.ones((), dtype=F64, device=dev)
+
+        def normal(*shape):
+            return torch.randn(*shape, dtype=F64, device=dev, generator=g)
+
+        def uniform(*shape):
+            return torch.rand(*shape, dtype=F64, device=dev, generator=g)
+
+        rate = rate if torch.is_tensor(rate) else torch.from_numpy(np.ascontiguousarray(rate)).to(dev)
+        act = (slice(nb, ny - nb), slice(nb, nx - nb))
+        total_rate = rate.to(F64) + self.dark_slope
+        cr_mask = uniform(ny, nx) < cr_frac
+        cr_grp = torch.randint(2, max(G, 3), (ny, nx), device=dev, generator=g)
+        cr_amp = torch.where(cr_mask, 50.0 * 100.0 ** uniform(ny, nx), zero)
+        data = torch.empty((G, ny, nx), dtype=torch.int16, device=dev)
+        amp33 = torch.empty((G, ny, pars.channelwidth), dtype=torch.int16, device=dev)
+        groupdq = torch.zeros((G, ny, nx), dtype=torch.uint8, device=dev)
+        S_guess = self.Sref
+        sat = int(pixel.SATURATED)
+        sig_groups = None
+        if poisson:
+            lam = torch.clamp(total_rate * self.gain * self.frame_time, min=0.0)   # electrons per read
+            q = torch.zeros_like(lam)
+            sig_groups, last = [], -1
+            for gi, reads in enumerate(self.rp):
+                acc = torch.zeros_like(lam)
+                for r in reads:
+                    while last < r:     # electrons collected up to the END of read r (read 0 ends one frame after the reset)
+                        q = q + torch.poisson(lam, generator=g)
+                        last += 1
+                    acc += q
+                # the deterministic model samples the signal at the mean read index: keep its time origin
+                sig_groups.append(acc / len(reads) / self.gain - total_rate * self.frame_time)
+        for gi in range(G):
+            base = sig_groups[gi] if poisson else total_rate * float(self.t[gi])
+            sig = base + torch.where(cr_grp <= gi, cr_amp, zero)
+            conv = sig.clone()
+            conv[act] = _ipc_forward(sig[act] * self.gain[act], self.K) / self.gain[act]
+            S = S_guess.clone()
+            for _ in range(4):
+                val, der = self._phi(S)
+                S = S - (val - conv) / torch.where(der.abs() > 0.2, der, one)
+            S_guess = S
+            row_noise = 3.0 * normal(ny, 1)
+            raw = S + row_noise + self.sigma_read / np.sqrt(self.nread[gi]) * normal(ny, nx)
+            if self.bias is not None:
+                raw[act] += self.bias[gi].to(F64)
+            ref = self.dark[gi].to(F64) + row_noise + self.sigma_read * normal(ny, nx)
+            raw = torch.where(self.border, ref, raw)
+            sat_now = (raw >= self.sat_level) & ~self.border
+            raw = torch.where(sat_now, torch.minimum(raw, self.sat_level + 200.0), raw)
+            data[gi] = torch.clamp(torch.round(raw), 0, 65535).to(torch.int32).to(torch.int16)  # wraps to the u16 bit pattern
+            groupdq[gi] |= torch.where(sat_now, sat, 0).to(torch.uint8)
+            r33 = self.a33_med + self.m_pink * row_noise + self.a33_std * normal(ny, pars.channelwidth)
+            amp33[gi] = torch.clamp(torch.round(r33), 0, 65535).to(torch.int32).to(torch.int16)
+        # saturation is sticky forward in time and flagged `backup` groups early; group 0 is not checked
+        for gi in range(1, G):
+            groupdq[gi] |= groupdq[gi - 1] & sat
+        for _ in range(self.backup):
+            for gi in range(1, G - 1):
+                groupdq[gi] |= groupdq[gi + 1] & sat
+        groupdq[0] &= 0xFF ^ sat
+        if self.exclude_first:
+            groupdq[0] |= int(pixel.DO_NOT_USE)
+        return data, amp33, groupdq, self.mask
+
+
 def make_ramp(cal, read_pattern=None, frame_time=synth.FRAME_TIME, seed=1, cr_frac=1e-3, rate=None, exclude_first=True,
               nb=pars.nborder, saturation_backup=1, device=0):
-    dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
-    rp = synth.READ_PATTERN_8 if read_pattern is None else read_pattern
-    G = len(rp)
-    lin = cal["linearitylegendre"]
-    ny, nx = lin["Smin"].shape
-    g = _gen(dev, 7_000_003 + int(seed))
-    t = synth.group_times(rp, frame_time)
-    nread = [float(len(r)) for r in rp]
+    """``synth.make_ramp`` on the device; numpy arrays back (same dict layout)."""
+    f = RampFactory(cal, read_pattern, frame_time, nb, device, exclude_first, saturation_backup)
     if rate is None:
-        rate = synth.make_rate_image(ny, nx, seed, nb=nb)
-
-    def dv(a):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(F64)
-
-    def normal(*shape):
-        return torch.randn(*shape, dtype=F64, device=dev, generator=g)
-
-    def uniform(*shape):
-        return torch.rand(*shape, dtype=F64, device=dev, generator=g)
-
-    act = (slice(nb, ny - nb), slice(nb, nx - nb))
-    gain = dv(cal["gain"]["data"])
-    total_rate = dv(rate) + dv(cal["dark"]["dark_slope"])
-    cr_mask = uniform(ny, nx) < cr_frac
-    cr_grp = torch.randint(2, max(G, 3), (ny, nx), device=dev, generator=g)
-    cr_amp = torch.where(cr_mask, 50.0 * 100.0 ** uniform(ny, nx), torch.zeros((), dtype=F64, device=dev))
-    sigma_read = dv(cal["read"]["data"])
-    sat_level = dv(cal["saturation"]["data"])
-    K = dv(cal["ipc4d"]["data"])
-    Smin, Smax = dv(lin["Smin"]), dv(lin["Smax"])
-    span = Smax - Smin
-    coef = dv(lin["data"])
-    a33 = cal["read"]["amp33"]
-    a33_med, a33_std = dv(a33["med"]), dv(a33["std"])
-    border = torch.ones((ny, nx), dtype=torch.bool, device=dev)
-    border[act] = False
-
-    def phi(S):
-        z = 2 * (S - Smin) / span - 1
-        val, der = _legendre_tail(z, coef[1:], 1)
-        return coef[0] + val, der * 2.0 / span
-
-    data = np.zeros((G, ny, nx), dtype=np.uint16)
-    amp33 = np.zeros((G, ny, pars.channelwidth), dtype=np.uint16)
-    groupdq = torch.zeros((G, ny, nx), dtype=torch.uint8, device=dev)
-    S_guess = dv(lin["Sref"])
-    for gi in range(G):
-        sig = total_rate * float(t[gi]) + torch.where(cr_grp <= gi, cr_amp, torch.zeros((), dtype=F64, device=dev))
-        conv = sig.clone()
-        conv[act] = _ipc_forward(sig[act] * gain[act], K) / gain[act]
-        S = S_guess.clone()
-        for _ in range(4):
-            val, der = phi(S)
-            S = S - (val - conv) / torch.where(der.abs() > 0.2, der, torch.ones((), dtype=F64, device=dev))
-        S_guess = S
-        row_noise = 3.0 * normal(ny, 1)
-        raw = S + row_noise + sigma_read / np.sqrt(nread[gi]) * normal(ny, nx)
-        if "biascorr" in cal:
-            b = cal["biascorr"]["data"]
-            raw[act] += dv(b[b.shape[0] - G + gi])
-        ref = dv(cal["dark"]["data"][gi]) + row_noise + sigma_read * normal(ny, nx)
-        raw = torch.where(border, ref, raw)
-        sat_now = (raw >= sat_level) & ~border
-        raw = torch.where(sat_now, torch.minimum(raw, sat_level + 200.0), raw)
-        data[gi] = torch.clamp(torch.round(raw), 0, 65535).to(torch.int32).cpu().numpy().astype(np.uint16)
-        groupdq[gi] |= torch.where(sat_now, int(pixel.SATURATED), 0).to(torch.uint8)
-        r33 = a33_med + float(a33["M_PINK"]) * row_noise + a33_std * normal(ny, pars.channelwidth)
-        amp33[gi] = torch.clamp(torch.round(r33), 0, 65535).to(torch.int32).cpu().numpy().astype(np.uint16)
-    gq = groupdq.cpu().numpy()
-    sat = np.uint8(pixel.SATURATED)
-    for gi in range(1, G):
-        gq[gi] |= gq[gi - 1] & sat
-    for _ in range(saturation_backup):
-        for gi in range(1, G - 1):
-            gq[gi] |= gq[gi + 1] & sat
-    gq[0] &= ~sat
-    if exclude_first:
-        gq[0] |= np.uint8(pixel.DO_NOT_USE)
-    return {"data": data, "amp33": amp33, "groupdq": gq, "pixeldq": np.array(cal["mask"]["dq"], dtype=np.uint32, copy=True),
-            "read_pattern": rp, "frame_time": frame_time, "rate": np.asarray(rate, dtype=np.float32)}
+        rate = synth.make_rate_image(f.ny, f.nx, seed, nb=nb)
+    data, amp33, gq, _mask = f.make(seed, np.asarray(rate, dtype=np.float64), cr_frac)
+    return {"data": data.cpu().numpy().view(np.uint16), "amp33": amp33.cpu().numpy().view(np.uint16), "groupdq": gq.cpu().numpy(),
+            "pixeldq": np.array(cal["mask"]["dq"], dtype=np.uint32, copy=True), "read_pattern": f.rp, "frame_time": frame_time,
+            "rate": np.asarray(rate, dtype=np.float32)}

@@ -136,6 +136,46 @@ def test_harness_end_to_end_small_frame():
     assert np.median(z) < 3.0
 
 
+def test_harness_with_the_device_generator():
+    """The realisations generated ON the device (synth_gpu.RampFactory: what makes BASELINE config 5 feasible at full size) go
+    through the same chain and statistics: planes consistent with recomputing every realisation one by one, the scatter over
+    realisations equal to the pipeline's own error estimate, the mean unbiased."""
+    from romanimpreprocess_amd import synth_gpu
+    from romanimpreprocess_amd.utils import maskhandling
+
+    rp = synth.READ_PATTERN_8
+    ny, nx, nseeds = 72, 256, 24
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=13)
+    cb = pipeline.Calibrator(ctx=gpu_context())
+    cb.load_caldir(0, cal)
+    tm = {}
+    out = mr.run(cb, 0, cal, nseeds=nseeds, seed0=100, read_pattern=rp, device=DEV, reference_alias=False, generator="device",
+                 timings=tm)
+    assert out.shape == (8, ny, nx) and tm["realisations_on_this_rank"] == nseeds
+    # recompute: the factory is seeded, so the same realisations come out again
+    rate = synth.make_rate_image(ny, nx, 100)
+    f = synth_gpu.RampFactory(cal, rp, device=0)
+    slopes, goods = [], []
+    for j in range(nseeds):
+        data, a33, gq, _m = f.make(100 + 10 * (j + 1), rate, poisson=True)
+        ramp = {"data": data.cpu().numpy().view(np.uint16), "amp33": a33.cpu().numpy().view(np.uint16), "groupdq": gq.cpu().numpy(),
+                "pixeldq": cal["mask"]["dq"].copy(), "read_pattern": rp, "frame_time": synth.FRAME_TIME}
+        res = cb.calibrate(0, ramp, want_groupdq=False)
+        im = np.zeros((ny, nx), np.float32)
+        im[4:-4, 4:-4] = res["slope"][4:-4, 4:-4]
+        gd = np.zeros((ny, nx), bool)
+        gd[4:-4, 4:-4] = ~maskhandling.PixelMask1.build(res["pixeldq"][4:-4, 4:-4], ctx=gpu_context())
+        slopes.append(im), goods.append(gd)
+    assert_same_bits(out[2], np.median(np.stack(slopes), axis=0), "median(images)")
+    assert_same_bits(out[3], np.sum(goods, axis=0).astype(np.float32), "N")
+    ok = out[3] >= nseeds - 2
+    assert ok.mean() > 0.5
+    ratio = out[5][ok] / np.maximum(out[7][ok], 1e-6)   # std over realisations / median of the pipeline's error
+    assert 0.85 < np.median(ratio) < 1.15, np.median(ratio)
+    z = out[6][ok] / (out[5][ok] / np.sqrt(out[3][ok]) + 1e-6)     # (mean - ideal) in standard errors
+    assert abs(np.median(z)) < 0.5 and np.median(np.abs(z)) < 1.5
+
+
 _TWO_RANK_WORKER = """
 import os, sys
 sys.path.insert(0, {repo!r})
