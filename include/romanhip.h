@@ -344,6 +344,17 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value);
    3 = wave-private fused kernel */
 int rip_last_chain_form(rip_ctx *ctx);
 
+/* pseudo-Poisson noise layers ("O" directives, gen_noise_image.py:173-240): per element of I (n doubles, host memory) the
+   member of the Pearson family with the moments tilnu_21 I, tilnu_31 I, 3 tilnu_21^2 I^2 + tilnu_41 I, replacing
+   L1_to_L2/GalPoisson/draw_with_tilnus.py:draw_from_Pearson (:12-135) and the solvers / samplers it calls.
+   types  (n int32, or NULL): 0 = outside the admissible region (deviate 0), 1, 3, 4, 5, 6 = Pearson type;
+   params (4 n doubles, or NULL): type 1: a, b, mean, c; 3: shape, scale, shift, sign; 4: m, nu, a, lambda; 5: a, b, mu, sign;
+          6: alpha, beta, scale, shift -- the reference's formulas in f64 (pinned by goldens);
+   draws  (n doubles, or NULL): one deviate each from a counter-based generator keyed by (seed, stream, element); the
+          reference's scipy / numpy streams cannot be reproduced: parity of the random part unpinned (moments tested). */
+int rip_stage_pearson(rip_ctx *ctx, size_t n, const double *I, double tilnu21, double tilnu31, double tilnu41, uint64_t seed,
+                      uint32_t stream, double *draws, int32_t *types, double *params);
+
 /* ---- diagnostics ------------------------------------------------------------------------- */
 /* floating-point options of a context.  "guard_band": relative half-width of the band around the jump
    threshold inside which the significance is re-evaluated in the reference's exact operation order

@@ -18,7 +18,9 @@ and handed to the kernel).  Layers are therefore statistically, not bit-wise, co
     reference output, 1/f noise): the 1/f frames -- 34 Fourier transforms of 2^20 points per group -- are made by
     ``rip_stage_noise_1f`` (hipFFT, device deviates); the white deviates and the assembly follow the reference's lines in
     numpy on the host (``NOISE: {CORRELATED: false}`` switches the step off).
-Not built: the pseudo-Poisson layers (``O``, the GalPoisson sampler); asking for them raises NotImplementedError.
+The pseudo-Poisson layers (``O``): moment ratios on the host (``GalPoisson/find_tilnus.py``), Pearson-family deviates on the
+    device (``rip_stage_pearson``, ``GalPoisson/draw_with_tilnus.py``; parameters pinned by goldens, deviates from the device's
+    counter-based generator).
 """
 
 import re
@@ -29,6 +31,8 @@ import numpy as np
 
 from .. import _native, calio, pars
 from ..utils import sky
+from .GalPoisson.draw_with_tilnus import draw_from_Pearson
+from .GalPoisson.find_tilnus import get_tilde_nus
 from .gen_cal_image import calibrateimage
 
 
@@ -239,7 +243,39 @@ def make_noise_cube(config, rng=None):
                 print("***", noiseflags, zclip, iqr, med)
                 diff = np.clip(diff, med - zclip * iqr / 1.34896, med + zclip * iqr / 1.34896)
         if "O" in cmd:
-            raise NotImplementedError("pseudo-Poisson layers ('O': GalPoisson sampler) are not built")
+            # pseudo-Poisson layer (gen_noise_image.py:173-240): per end slice, the moment ratios of the ramp-fit slope under
+            # Poisson noise (host), then one Pearson-family deviate per pixel (device) scaled by the pixel's gain * rate
+            with calio.open_tree(config["CALDIR"]["gain"]) as g_:
+                gain = np.clip(np.asarray(g_["roman"]["data"]), 1e-4, 1e4)
+            with calio.open_tree(config["OUT"]) as f_L2:
+                withsky = np.asarray(f_L2["roman"]["data_withsky"])
+                pinfo = calio._materialise(f_L2["processinfo"])
+                t_fr = f_L2["roman"]["meta"]["exposure"]["frame_time"]
+            d = (gain.shape[-1] - withsky.shape[-1]) // 2
+            if d > 0:
+                gain = gain[d:-d, d:-d]
+            gI = gain * withsky
+            ngrp_o = len(read_pattern)
+            w, _has, endslice = ramp_weight_vectors(pinfo, ngrp_o)
+            start = 1 if pinfo["exclude_first"] else 0
+            a_beta = np.array([read_pattern[k][0] for k in range(ngrp_o)], dtype=int)   # (the L2 file's processinfo holds the same)
+            N_beta = np.array([len(read_pattern[k]) for k in range(ngrp_o)], dtype=int)
+            noise_array = np.zeros(endslice.shape, dtype=np.float32)
+            for k in range(start + 1, ngrp_o):
+                tilnu21, tilnu31, tilnu41, _tilnu42 = get_tilde_nus(N_beta, a_beta, w[k])
+                tilnu21 *= t_fr          # e/frame -> e/s
+                tilnu31 *= t_fr**2
+                tilnu41 *= t_fr**3
+                pixels = np.where(endslice == k)
+                print("n pix", len(pixels[0]), "tilnus", tilnu21, tilnu31, tilnu41)
+                sys.stdout.flush()
+                if len(pixels[0]):
+                    noise_array[pixels] = draw_from_Pearson(
+                        tilnu21, tilnu31, tilnu41, gI[pixels],
+                        rng=host_rng if host_rng is not None else np.random.default_rng([int(seed) & 0xFFFFFFFF, i_noise, k]),
+                        stream=100 * (i_noise + 1) + k)
+            diff = np.asarray(diff, dtype=np.float32).copy()
+            diff[:, :] += noise_array / gain
         if "P" in cmd:
             noiseflags = _get_subscript(cmd, "P")
             with calio.open_tree(config["OUT"]) as f_L2:

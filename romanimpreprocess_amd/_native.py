@@ -88,6 +88,7 @@ SYMBOLS = {
     "rip_calibrate": (_I, [_VP, _I, _I, C.c_uint, C.POINTER(RampDesc), C.POINTER(Outputs)]),
     "rip_calibrate_batch": (_I, [_VP, _I, _I, C.c_uint, _I, C.POINTER(RampDesc), C.POINTER(Outputs)]),
     "rip_calibrate_batch_completed": (_I, [_VP]),
+    "rip_stage_pearson": (_I, [_VP, C.c_size_t, _VP, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_uint32, _VP, _VP, _VP]),
     "rip_stage_refpix_image": (_I, [_VP, _VP, _I, _I, C.c_double, _I, _I, _VP, _VP, _VP, _VP]),
     "rip_stage_multilin": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "rip_stage_ipc_image": (_I, [_VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _VP, _I, _VP]),

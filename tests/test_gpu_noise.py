@@ -69,7 +69,7 @@ def _write_inputs(tmp_path, rp, ny, nx):
                              "instrument": {"detector": "WFI04"}}}}
     calio.write_asdf(str(tmp_path / "l1.asdf"), l1)
     config = {"IN": str(tmp_path / "l1.asdf"), "OUT": str(tmp_path / "l2.asdf"), "CALDIR": caldir, "SLICEOUT": True,
-              "NOISE": {"LAYER": ["Ra", "R", "RaS2", "Raz2", "Ccomment", "Pr", "Pb2r"], "TEMP": str(tmp_path / "tmp.asdf"), "SEED": 11,
+              "NOISE": {"LAYER": ["Ra", "R", "RaS2", "Raz2", "Ccomment", "Pr", "Pb2r", "OS2"], "TEMP": str(tmp_path / "tmp.asdf"), "SEED": 11,
                         "OUT": str(tmp_path / "noise.asdf")}, "NOISE_PRECISION": 32}
     return cal, ramp, config
 
@@ -85,7 +85,7 @@ def test_noise_layers_end_to_end(tmp_path):
     out = calio.read_asdf(config["NOISE"]["OUT"])
     noise = np.asarray(out["noise"])
     l2 = calio.read_asdf(config["OUT"])
-    assert noise.shape == (7,) + np.asarray(l2["roman"]["data"]).shape and noise.dtype == np.float32
+    assert noise.shape == (8,) + np.asarray(l2["roman"]["data"]).shape and noise.dtype == np.float32
     good = np.asarray(l2["roman"]["dq"]) == 0
     err_read = np.sqrt(np.asarray(l2["roman"]["var_rnoise"]))[good]
     for i in (0, 1, 2):
@@ -114,8 +114,11 @@ def test_noise_layers_end_to_end(tmp_path):
     for i in (5, 6):
         ratio = np.std(noise[i][good]) / np.sqrt(np.mean(err_p**2))
         assert 0.7 < ratio < 1.4, (i, ratio)
-    with pytest.raises(NotImplementedError):
-        gen_noise_image.make_noise_cube(dict(config, NOISE=dict(config["NOISE"], LAYER=["O"])))
+    # pseudo-Poisson layer ('O': Pearson-family deviates with the slope's second to fourth moments under Poisson noise): its
+    # scatter is the Poisson error of the slope as well, its mean is zero
+    ratio = np.std(noise[7][good]) / np.sqrt(np.mean(err_p**2))
+    assert 0.8 < ratio < 1.25, ratio
+    assert abs(np.mean(noise[7][good])) < 0.05 * np.std(noise[7][good])
 
 
 @pytest.mark.parametrize("gdt", [np.float32, np.float64])

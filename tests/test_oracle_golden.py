@@ -272,3 +272,15 @@ def test_il_known_answers_of_the_reference_workflow_test():
         S, _ = linearity.invlinearity(conv / g["gain"], g["coefs"], g["Smin"], g["Smax"])
         assert np.all(np.abs(S[10:12, 10:13] - target) < 0.002)
         assert_same_bits(S[1:-1, 1:-1], ref_out[1:-1, 1:-1], "IL.apply block")
+
+
+def test_get_tilde_nus_matches_the_reference(golden):
+    """The host mirror of GalPoisson/find_tilnus.get_tilde_nus against values computed by the reference's own module."""
+    from romanimpreprocess_amd.L1_to_L2.GalPoisson.find_tilnus import get_tilde_nus
+
+    g = golden("pearson_params")
+    names = sorted({k[3:-4] for k in g if k.startswith("tn_") and k.endswith("_out")})
+    assert len(names) >= 8
+    for name in names:
+        got = np.array(get_tilde_nus(g[f"tn_{name}_N"], g[f"tn_{name}_a"], g[f"tn_{name}_W"]), dtype=np.float64)
+        assert_same_bits(got, g[f"tn_{name}_out"], f"tilde nus of {name}")

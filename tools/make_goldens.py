@@ -534,10 +534,116 @@ def case_harness():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def case_pearson():
+    """The reference's GalPoisson modules (importable as they stand: numpy + scipy only): get_tilde_nus for several MA tables and
+    weight vectors, and -- with the per-type SAMPLERS replaced by recorders, so that only the reference's classification and
+    parameter formulas run -- the Pearson type and the distribution parameters of every element of intensity arrays."""
+    import importlib
+
+    ft = importlib.import_module("romanimpreprocess.L1_to_L2.GalPoisson.find_tilnus")
+    dw = importlib.import_module("romanimpreprocess.L1_to_L2.GalPoisson.draw_with_tilnus")
+    out = {}
+    # ---- get_tilde_nus
+    tables = {
+        "doc": ([1, 2, 4, 4, 4, 1], [2, 3, 5, 23, 44, 49], [-0.1, -0.4, -0.2, 0.2, 0.4, 0.1]),
+        "pair": ([4, 4], [5, 12], [-0.5, 0.5]),
+    }
+    from romanimpreprocess_amd import synth
+    READ_PATTERNS = {"g8": synth.READ_PATTERN_8, "g6": synth.READ_PATTERN_6, "g16": synth.READ_PATTERN_16}
+    fitting = importlib.import_module("romanimpreprocess.utils.fitting")
+    for name, rp in READ_PATTERNS.items():
+        meta = ref_meta(rp, 3.04)
+        K = fitting.construct_weights(0.4 / 1.8 / 6.5**2, meta, exclude_first=True)
+        nb_, ab_ = [len(r) for r in rp], [r[0] for r in rp]
+        tables["K_" + name] = (nb_, ab_, np.asarray(K, dtype=np.float64))
+        Kt = np.zeros(len(rp), np.float32)   # a two-point weight vector of a truncated ramp (gen_noise_image.py:192-197)
+        Kt[3] = 1.0 / (meta["tbar"][3] - meta["tbar"][1])
+        Kt[1] = -Kt[3]
+        tables["trunc_" + name] = (nb_, ab_, Kt)
+    for name, (nb_, ab_, w) in tables.items():
+        nus = ft.get_tilde_nus(np.array(nb_), np.array(ab_), np.asarray(w))
+        out[f"tn_{name}_N"], out[f"tn_{name}_a"], out[f"tn_{name}_W"] = np.array(nb_), np.array(ab_), np.asarray(w)
+        out[f"tn_{name}_out"] = np.array(nus, dtype=np.float64)
+    # ---- classification + parameters: samplers replaced by recorders
+    rec = {}
+
+    def r1(t21, t31, t41, I, rng=None):
+        rec["p1"] = np.stack(dw.solve_beta_parameters_vec(t21, t31, t41, I), axis=-1)
+        return np.full(np.shape(I), 1.0)
+
+    def r3(t21, t31, I, rng=None):
+        I = np.asarray(I, dtype=float)
+        scale = abs(t31) / (2.0 * t21)
+        shapes = 4.0 * t21**3 * I / t31**2
+        rec["p3"] = np.stack([shapes, np.full(I.shape, scale), shapes * scale, np.full(I.shape, 1.0 if t31 > 0 else -1.0)], axis=-1)
+        return np.full(np.shape(I), 3.0)
+
+    def r5(t21, t31, I, rng=None):
+        a, b, mu = dw.solve_pearson5_parameters_vec(t21, t31, I)
+        rec["p5"] = np.stack([a, b, mu, np.full(np.shape(a), 1.0 if t31 >= 0 else -1.0)], axis=-1)
+        return np.full(np.shape(I), 5.0)
+
+    def r6(t21, t31, t41, I, rng=None):
+        al, be, sc, sh, _sg = dw.solve_pearson6_params(t21, t31, t41, I)
+        rec["p6"] = np.stack([al, be, sc, sh], axis=-1)
+        return np.full(np.shape(I), 6.0)
+
+    p4 = []
+
+    def dev(m, nu, *, a=1.0, lam=0.0, size=None, rng=None):
+        p4.append((m, nu, a, lam))
+        return 4.0
+
+    def ar(m, nu, a, lam, rng=None):
+        p4.append((m, nu, a, lam))
+        return 4.0
+
+    saved = {k: getattr(dw, k) for k in ("random_from_type1", "random_from_type3", "random_from_type5", "random_from_type6",
+                                         "pt4_rvs_devroye", "pt4_rvs_ar", "devroye_acc_rate")}
+    dw.devroye_acc_rate = lambda nu, a, m: 1.0   # every type-4 element goes to the first recorder, in element order
+    dw.random_from_type1, dw.random_from_type3, dw.random_from_type5, dw.random_from_type6 = r1, r3, r5, r6
+    dw.pt4_rvs_devroye, dw.pt4_rvs_ar = dev, ar
+    try:
+        I = np.concatenate([np.geomspace(1e-3, 1e5, 97), [0.0, -5.0, 0.01, 0.02, 3.0, 1e7]])
+        cases = {
+            "poisson_like": (1.0, 1.0, 1.0),          # kappa = t41 t21 / t31^2 = 1: type 1
+            "neg_skew": (0.8, -0.6, 0.5),             # type 1, negative skew
+            "beta_prime": (1.0, 1.0, 1.7),            # 1.5 < kappa < 1.875: type 6
+            "beta_prime_neg": (0.5, -0.4, 0.55),      # type 6 (kappa = 1.72), negative skew
+            "heavy_tail": (1.0, 0.5, 1.0),            # kappa = 4: type 4
+            "heavy_tail_neg": (2.0, -1.0, 3.0),       # type 4, negative third moment
+            "symmetric": (1.0, 0.0, 2.0),             # beta_1 = 0: type 4 with nu = 0 (Student-like)
+            "light_tail": (1.0, 0.1, -0.5),           # negative excess kurtosis: type 1 near-symmetric beta
+        }
+        tn = tables["K_" + next(iter(READ_PATTERNS))]
+        nus = ft.get_tilde_nus(np.array(tn[0]), np.array(tn[1]), np.asarray(tn[2]))
+        cases["ramp_fit_weights"] = (nus[0] * 3.04, nus[1] * 3.04**2, nus[2] * 3.04**3)   # as gen_noise_image.py:214-217 scales them
+        for name, (t21, t31, t41) in cases.items():
+            rec.clear()
+            p4.clear()
+            types = dw.draw_from_Pearson(t21, t31, t41, I, rng=np.random.default_rng(1)).astype(np.int32)
+            par = np.zeros(I.shape + (4,))
+            Ic = np.clip(I, 0.01, None)
+            for code, key in ((1, "p1"), (3, "p3"), (5, "p5"), (6, "p6")):
+                if np.any(types == code):
+                    par[types == code] = rec[key]
+            if np.any(types == 4):
+                par[types == 4] = np.array(p4)
+            del Ic
+            out[f"cl_{name}_t"] = np.array([t21, t31, t41])
+            out[f"cl_{name}_types"], out[f"cl_{name}_params"] = types, par
+        out["cl_I"] = I
+    finally:
+        for k, v in saved.items():
+            setattr(dw, k, v)
+    save("pearson_params", **out)
+
+
 CASES = {
     "lin_known_answer": case_lin_known_answer, "multilin": case_multilin, "ipc": case_ipc,
     "weights": case_weights, "rampfit": case_rampfit, "flat": case_flat, "refpix": case_refpix,
     "chain": case_chain, "post": case_post, "harness": case_harness, "il": case_il, "il_example": case_il_example,
+    "pearson": case_pearson,
 }
 
 if __name__ == "__main__":
