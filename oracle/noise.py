@@ -5,8 +5,10 @@ numpy restatements, with the random deviates as arguments, of
   * its resampled-Poisson branch (``:285-331``),
   * ``sim_to_isim.noise_1f_frame`` (``sim_to_isim.py:265-303``).
 The reference draws its deviates from galsim generators inside these code paths (not importable offline, streams not
-reproducible), so nothing here can be pinned by executing the reference: PARITY UNPINNED for the random part; the arithmetic
-applied to given deviates follows the cited lines operation by operation (numpy 2 promotion rules).
+reproducible): PARITY UNPINNED for the random part.  ``noise_1f_frame`` IS pinned: the reference's function is numpy-only apart
+from the draw, so tools/make_goldens.py takes it from sim_to_isim.py with ``ast``, executes it with a deviate stand-in that
+fills from given normals, and tests/test_oracle_golden.py holds this restatement to the same frame bit for bit.  The other
+two follow the cited lines operation by operation (numpy 2 promotion rules) on given deviates.
 """
 
 import numpy as np

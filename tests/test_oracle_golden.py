@@ -284,3 +284,18 @@ def test_get_tilde_nus_matches_the_reference(golden):
     for name in names:
         got = np.array(get_tilde_nus(g[f"tn_{name}_N"], g[f"tn_{name}_a"], g[f"tn_{name}_W"]), dtype=np.float64)
         assert_same_bits(got, g[f"tn_{name}_out"], f"tilde nus of {name}")
+
+
+def test_noise_1f_frame_matches_the_reference(golden):
+    """oracle.noise.noise_1f_frame against the reference's own function (taken from sim_to_isim.py with ast and executed by
+    tools/make_goldens.py noise1f): the same normals give the same frame, bit for bit (SHA-256 of the 4096 x 128 f32 frame)."""
+    import hashlib
+
+    from oracle import noise as onoise
+
+    g = golden("noise_1f_frame")
+    for seed in g["seeds"]:
+        normals = np.random.default_rng(int(seed)).standard_normal(4 * 4096 * 128)
+        frame = onoise.noise_1f_frame(normals, 4096, 128)
+        assert_same_bits(frame[::257], g[f"s{seed}_rows"], f"sampled rows, seed {seed}")
+        assert hashlib.sha256(np.ascontiguousarray(frame)).hexdigest() == str(g[f"s{seed}_sha256"])

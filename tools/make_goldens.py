@@ -639,11 +639,44 @@ def case_pearson():
     save("pearson_params", **out)
 
 
+def case_noise1f():
+    """``noise_1f_frame`` of from_sim/sim_to_isim.py (:265-303): the module cannot be imported (romanisim, galsim, astropy), but
+    the function is numpy-only apart from the deviate draw, so it is taken from the file with ``ast`` and EXECUTED as it stands,
+    with ``galsim.GaussianDeviate(rng).generate(a)`` standing in as "fill a from the normals handed in" and ``pars`` being the
+    reference's own pars module.  The fixture keeps the seed of the normals, samples of the frame and its SHA-256."""
+    import ast
+    import importlib
+
+    path = os.path.join(REF_SRC, "romanimpreprocess", "from_sim", "sim_to_isim.py")
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "noise_1f_frame"]
+    assert len(keep) == 1
+    ref_pars = importlib.import_module("romanimpreprocess.pars")
+
+    class _GD:
+        def __init__(self, rng):
+            self.rng = rng
+
+        def generate(self, a):
+            a[...] = self.rng.standard_normal(a.size).reshape(a.shape)
+
+    ns = {"np": np, "pars": ref_pars, "galsim": types.SimpleNamespace(GaussianDeviate=_GD)}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    out = {}
+    for seed in (3, 4):
+        frame = ns["noise_1f_frame"](np.random.default_rng(seed))
+        assert frame.shape == (ref_pars.nside, ref_pars.channelwidth) and frame.dtype == np.float32
+        out[f"s{seed}_sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(frame)).hexdigest())
+        out[f"s{seed}_rows"] = frame[::257].copy()
+        out[f"s{seed}_std"] = np.float64(np.std(frame))
+    save("noise_1f_frame", seeds=np.array([3, 4]), **out)
+
+
 CASES = {
     "lin_known_answer": case_lin_known_answer, "multilin": case_multilin, "ipc": case_ipc,
     "weights": case_weights, "rampfit": case_rampfit, "flat": case_flat, "refpix": case_refpix,
     "chain": case_chain, "post": case_post, "harness": case_harness, "il": case_il, "il_example": case_il_example,
-    "pearson": case_pearson,
+    "pearson": case_pearson, "noise1f": case_noise1f,
 }
 
 if __name__ == "__main__":
