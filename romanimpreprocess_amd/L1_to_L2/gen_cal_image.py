@@ -106,7 +106,9 @@ def _caldir_slot(cb, caldir):
 
 
 def calibrateimage(config, verbose=True, calibrator=None):
-    """Run the calibrations specified by ``config`` (dict, normally from YAML) and write the L2 file."""
+    """Run the calibrations specified by ``config`` (dict, normally from YAML) and write the L2 file.  Beyond the reference's
+    surface: ``config["IN"]`` may be an L1 tree (dict) instead of a path, and with ``config["OUT"] = None`` the L2 tree is
+    returned instead of written (the noise-layer driver keeps its intermediate exposures in memory that way)."""
     for unsupported in ("romancal_ramp_fit", "correct_wfi18_transient"):
         if config.get(unsupported):
             raise NotImplementedError(f"{unsupported} is outside the GPU L1->L2 path of this package")
@@ -188,16 +190,19 @@ def calibrateimage(config, verbose=True, calibrator=None):
         im2["amp33"] = ramp["amp33"]
     processinfo = {
         "medsky": medsky, "medgain": medgain, "skyorder": skyorder, "skycoefs": skycoefs,
-        "ramp_opt_pars": dict(uopt), "weights": K, "config": config, "log": mylog.output,
+        "ramp_opt_pars": dict(uopt), "weights": K, "log": mylog.output,
+        "config": {k: v for k, v in config.items() if not (k == "IN" and isinstance(v, dict))},
         "exclude_first": bool(exclude_first),
         "meta": {k: (v if not isinstance(v, np.ndarray) else v) for k, v in meta.items() if k != "read_pattern"},
     }
     if config.get("SLICEOUT"):
         endslice = sky.endslice(rdq, nb, ctx=cb.ctx)  # raises ValueError("too many groups") for >= 128 groups
         processinfo["endslice"] = endslice
-    calio.write_asdf(config["OUT"], {"roman": im2, "processinfo": processinfo})
     if verbose:
         print(mylog.output)
+    if config.get("OUT") is None:   # in-memory use (the noise-layer driver): the L2 tree instead of a file
+        return {"roman": im2, "processinfo": processinfo}
+    calio.write_asdf(config["OUT"], {"roman": im2, "processinfo": processinfo})
     return
 
 

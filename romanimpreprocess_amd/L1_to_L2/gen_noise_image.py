@@ -183,18 +183,27 @@ def make_noise_cube(config, rng=None):
     seed = config["NOISE"].get("SEED", 0) if (rng is None or host_rng is not None) else int(rng)
     nb = pars.nborder
     noiseimage = None
+    # config["NOISE"]["IN_MEMORY"] (default true): the noise-injected exposures and their L2 images stay in memory instead of going
+    # through the TEMP files of the reference (same arithmetic; a layer then costs its two chain runs and the noise generation,
+    # not four full-frame ASDF round trips); the dark-based reference image of the layers without 'a' is computed once
+    in_memory = bool(config["NOISE"].get("IN_MEMORY", True))
+    with calio.open_tree(config["IN"]) as f_in:
+        base_tree = calio._materialise(f_in if isinstance(f_in, dict) else dict(f_in))
+    with calio.open_tree(config["OUT"]) as f_orig:
+        orig_data = np.asarray(f_orig["roman"]["data"])
+    dark_ref = None   # L2 "data" of the dark cube itself
     for i_noise, cmd in enumerate(layers):
-        with calio.open_tree(config["IN"]) as f_in:
-            mytree = deepcopy(calio._materialise(f_in if isinstance(f_in, dict) else dict(f_in)))
-        with calio.open_tree(config["OUT"]) as f_orig:
-            diff = np.zeros_like(np.asarray(f_orig["roman"]["data"]))
+        mytree = {k: v for k, v in base_tree.items()}
+        mytree["roman"] = {k: (v.copy() if k in ("data", "amp33") and isinstance(v, np.ndarray) else v)
+                           for k, v in base_tree["roman"].items()}
+        diff = np.zeros_like(orig_data)
         if noiseimage is None:
             noiseimage = np.zeros((len(layers),) + diff.shape, dtype=np.float32)
         read_pattern = mytree["roman"]["meta"]["exposure"]["read_pattern"]
 
         if "R" in cmd:
             noiseflags = _get_subscript(cmd, "R")
-            origfile = config["OUT"]
+            ref_data = orig_data
             if "a" not in noiseflags:  # start from the dark instead of the data
                 with calio.open_tree(config["CALDIR"]["dark"]) as fb:
                     dark = np.asarray(fb["roman"]["data"])
@@ -202,12 +211,18 @@ def make_noise_cube(config, rng=None):
                     if de not in [0, 1]:
                         raise ValueError("Dark date cube has the wrong shape.")
                     mytree["roman"]["data"] = dark.astype(mytree["roman"]["data"].dtype)[de:, :, :]
-                calio.write_asdf(config["NOISE"]["TEMP"], mytree)
-                config3 = deepcopy(config)
-                config3["IN"] = config["NOISE"]["TEMP"]
-                config3["OUT"] = config["NOISE"]["TEMP"][:-5] + "_refL2.asdf"
-                calibrateimage(config3)
-                origfile = config3["OUT"]
+                if in_memory:
+                    if dark_ref is None:
+                        dark_ref = np.asarray(calibrateimage(dict(config, IN=mytree, OUT=None))["roman"]["data"])
+                    ref_data = dark_ref
+                else:
+                    calio.write_asdf(config["NOISE"]["TEMP"], mytree)
+                    config3 = deepcopy(config)
+                    config3["IN"] = config["NOISE"]["TEMP"]
+                    config3["OUT"] = config["NOISE"]["TEMP"][:-5] + "_refL2.asdf"
+                    calibrateimage(config3)
+                    with calio.open_tree(config3["OUT"]) as f_ref:
+                        ref_data = np.asarray(f_ref["roman"]["data"])
             with calio.open_tree(config["CALDIR"]["read"]) as fr:
                 read = np.asarray(fr["roman"]["data"], dtype=np.float32)
             data = np.ascontiguousarray(mytree["roman"]["data"])
@@ -229,13 +244,16 @@ def make_noise_cube(config, rng=None):
                 mytree["roman"]["data"] = cube
                 if a33 is not None:
                     mytree["roman"]["amp33"] = a33
-            calio.write_asdf(config["NOISE"]["TEMP"], mytree)
-            config2 = deepcopy(config)
-            config2["IN"] = config["NOISE"]["TEMP"]
-            config2["OUT"] = config["NOISE"]["TEMP"][:-5] + "_L2.asdf"
-            calibrateimage(config2)
-            with calio.open_tree(config2["OUT"]) as f_out, calio.open_tree(origfile) as f_orig:
-                diff = np.asarray(f_out["roman"]["data"]) - np.asarray(f_orig["roman"]["data"])
+            if in_memory:
+                diff = np.asarray(calibrateimage(dict(config, IN=mytree, OUT=None))["roman"]["data"]) - ref_data
+            else:
+                calio.write_asdf(config["NOISE"]["TEMP"], mytree)
+                config2 = deepcopy(config)
+                config2["IN"] = config["NOISE"]["TEMP"]
+                config2["OUT"] = config["NOISE"]["TEMP"][:-5] + "_L2.asdf"
+                calibrateimage(config2)
+                with calio.open_tree(config2["OUT"]) as f_out:
+                    diff = np.asarray(f_out["roman"]["data"]) - ref_data
             if "z" in noiseflags:
                 zclip = float(_get_subscript(noiseflags.upper(), "Z"))
                 p25, med, p75 = sky.nanpercentiles(diff, [25.0, 50.0, 75.0])

@@ -106,6 +106,11 @@ def test_noise_layers_end_to_end(tmp_path):
     # same seed, same layers
     again = gen_noise_image.make_noise_cube(config)
     assert_same_bits(again, noise, "layers from the same seed")
+    # the exposures kept in memory (default) or sent through the TEMP files as the reference does: the same layers
+    one = dict(config["NOISE"], LAYER=["R", "Raz3S1"])
+    mem = gen_noise_image.make_noise_cube(dict(config, NOISE=one))
+    files = gen_noise_image.make_noise_cube(dict(config, NOISE=dict(one, IN_MEMORY=False)))
+    assert_same_bits(mem, files, "in-memory vs temp-file layers")
     # host deviates in the reference's order give different, equally valid layers
     other = gen_noise_image.make_noise_cube(dict(config, NOISE=dict(config["NOISE"], LAYER=["Ra"])), np.random.default_rng(3))
     assert 0.8 < np.std(other[0][good]) / np.sqrt(np.mean(err_read**2)) < 1.25
