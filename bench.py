@@ -212,6 +212,7 @@ def main():
                     help="dtype of the ipc4d coefficients (the reference's production writer stores f64)")
     ap.add_argument("--p-order", type=int, default=8, choices=(3, 8, 10), help="Legendre order of the linearity file")
     ap.add_argument("--tiled", action="store_true", help="the round-1 input: a 128-row strip repeated down the frame (numpy)")
+    ap.add_argument("--chain3", type=int, default=None, choices=(0, 1), help="A/B switch: 1 = wave-private fused kernel wherever instantiated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip pre-pass exclusive timing, variants and the 18-slot batch")
     args = ap.parse_args()
@@ -246,6 +247,8 @@ def main():
         return rp_, cal, ramp
 
     cb = pipeline.Calibrator(device=local_rank)
+    if args.chain3 is not None:
+        cb.ctx.set_option("chain3", args.chain3)
 
     def fence():
         cb.synchronize()

@@ -335,8 +335,8 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value);
 /* further options (results identical either way; they exist for A/B timing and tests):
    "chain2"  -- (default 1) use the wave-specialised form of the fused kernel (chain2_kernel.h: f32 ipc4d with 6, 8 or 16
                 groups, f64 ipc4d with 6 or 8) where it applies, 0 = always the general fused kernel (chain_kernel.h);
-   "chain3"  -- (default 0) 1 = use the wave-private form (chain3_kernel.h) wherever it is instantiated; with 0 it runs
-                only where it is the one fused kernel that fits (f64 ipc4d with 16 groups);
+   "chain3"  -- the wave-private form (chain3_kernel.h): 2 (default) = where it is the faster fused kernel (f64 ipc4d), 1 =
+                wherever it is instantiated, 0 = only where it is the one fused kernel that fits (f64 ipc4d with 16 groups);
    "overlap" -- run the reference-pixel pre-pass of a ramp on a second stream so that it overlaps the previous ramp's
                 fused kernel. */
 

@@ -1,28 +1,30 @@
-"""Moment ratios of the ramp-fit slope under Poisson noise (host, numpy): drop-in for the reference's
-``L1_to_L2/GalPoisson/find_tilnus.py`` (``raw_weights`` :12-41, ``get_tilde_nus`` :44-77)."""
+"""Moment ratios of the ramp-fit slope under Poisson noise (host, numpy).  Same call surface and results as the reference's
+``L1_to_L2/GalPoisson/find_tilnus.py`` (``raw_weights`` :12-41, ``get_tilde_nus`` :44-77).
+
+Model: every raw read j >= 1 adds an independent Poisson increment (rate I per frame) to all later reads; group k is the mean
+of reads a_k .. a_k + N_k - 1 and the slope is sum_k W_k (group k).  The increment of read j therefore enters the slope with
+the coefficient c_j = sum_k W_k (number of reads of group k at or after j) / N_k, and the slope's cumulants are I sum_j c_j^p.
+"""
 
 import numpy as np
 
 
 def raw_weights(N_beta, a_beta):
-    """Matrix L (M groups x N reads) averaging raw reads into groups: group k = mean of reads a_beta[k] .. a_beta[k]+N_beta[k]-1."""
-    N_beta, a_beta = np.asarray(N_beta), np.asarray(a_beta)
-    assert len(N_beta) == len(a_beta)
-    nreads = np.max(a_beta + N_beta)
-    L = np.zeros((len(N_beta), nreads))
-    for k in range(len(N_beta)):
-        L[k, a_beta[k]:a_beta[k] + N_beta[k]] = 1.0 / N_beta[k]
-    return L
+    """(groups x reads) averaging matrix: entry (k, j) = 1 / N_k for the reads j of group k, else 0."""
+    counts, first = np.asarray(N_beta, dtype=int), np.asarray(a_beta, dtype=int)
+    if counts.shape != first.shape:
+        raise AssertionError("N_beta and a_beta must have the same length")
+    reads = np.arange(int(np.max(first + counts)))
+    member = (reads[None, :] >= first[:, None]) & (reads[None, :] < (first + counts)[:, None])
+    return member / counts[:, None].astype(float)
 
 
 def get_tilde_nus(N_beta, a_beta, W):
-    """(tilnu_21, tilnu_31, tilnu_41, tilnu_42) of the slope sum_k W_k (group k) when every read adds an independent Poisson
-    increment: the weight of the increment of read j is the tail sum of W L from read j on."""
-    L = raw_weights(N_beta, a_beta)
-    T = np.cumsum(L[:, ::-1], axis=1)[:, ::-1]
-    WT = np.dot(W, T[:, 1:])
-    nu_21 = np.sum(WT**2)
-    nu_31 = np.sum(WT**3)
-    nu_41 = np.sum(WT**4)
-    nu_42 = 3 * nu_21**2
-    return nu_21, nu_31 - 3 * nu_21**2, nu_41 - 10 * nu_21 * nu_31 - nu_21 * nu_42 + 18 * nu_21**3, nu_42
+    """(tilnu_21, tilnu_31, tilnu_41, tilnu_42) for the weight vector ``W`` (one weight per group), in units of frames."""
+    avg = raw_weights(N_beta, a_beta)
+    # reads of group k at or after read j, over N_k: the reversed running sum of the averaging matrix along the read axis
+    tail = np.flip(np.cumsum(np.flip(avg, axis=1), axis=1), axis=1)
+    coeff = np.asarray(W, dtype=float) @ tail[:, 1:]          # read 0 carries no increment
+    k2, k3, k4 = (np.sum(coeff**p) for p in (2, 3, 4))
+    gauss4 = 3.0 * k2 * k2
+    return k2, k3 - 3.0 * k2 * k2, k4 - 10.0 * k2 * k3 - k2 * gauss4 + 18.0 * k2**3, gauss4

@@ -197,7 +197,7 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value) {
         return RIP_OK;
     }
     if (name && strcmp(name, "chain3") == 0) {
-        ctx->use_chain3 = value != 0;
+        ctx->use_chain3 = (value < 0 || value > 2) ? 2 : value;
         return RIP_OK;
     }
     if (name && strcmp(name, "overlap") == 0) {

@@ -25,7 +25,8 @@ C3_DECL(11)
 int rip_launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int nplanes, int k_dtype) {
     // wave-private kernel (chain3_kernel.h) first; 1 = no instantiation for this plan
     const bool only3 = a.ngrp == 16 && k_dtype == RIP_F64;  // no other fused instantiation
-    if ((ctx->use_chain3 || only3) && (nplanes == 4 || nplanes == 9 || nplanes == 11)) {
+    const bool want3 = ctx->use_chain3 == 1 || (ctx->use_chain3 == 2 && k_dtype == RIP_F64);
+    if ((want3 || only3) && (nplanes == 4 || nplanes == 9 || nplanes == 11)) {
         const bool k64 = k_dtype == RIP_F64;
         int rc = 1;
         if (nplanes == 4) rc = k64 ? rip_launch_chain3_k64_np4(ctx, plan, a) : rip_launch_chain3_np4(ctx, plan, a);

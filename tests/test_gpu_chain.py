@@ -211,13 +211,15 @@ def test_calibrateimage_files_end_to_end(tmp_path):
 def _set_form(ctx, form):
     """3: wave-private fused kernel, 2: wave-specialised, 1: general fused, 0: stage kernels"""
     ctx.set_option("fused", 1 if form else 0)
-    ctx.set_option("chain3", 1 if form == 3 else 0)
+    ctx.set_option("chain3", 1 if form == 3 else 0)   # (the library's default, 2, picks by ipc4d dtype)
     ctx.set_option("chain2", 1 if form >= 2 else 0)
 
 
 def _default_form(ctx):
-    """the library's defaults: fused, wave-specialised kernel (the wave-private one only where nothing else is instantiated)"""
-    _set_form(ctx, 2)
+    """the library's defaults: fused; wave-specialised kernel for f32 ipc4d, wave-private kernel for f64 ipc4d"""
+    ctx.set_option("fused", 1)
+    ctx.set_option("chain2", 1)
+    ctx.set_option("chain3", 2)
 
 
 SPECIALISED = [
@@ -389,7 +391,7 @@ def test_full_frame_4096x4096_vs_oracle_and_between_forms(name, rp, kdt, p, orac
         if oracle_rows == n:
             ref = oracle.calibrate_arrays(ramp, cal)
             got = cb.calibrate(6, ramp, channel_lines=_oracle_lines(ref, len(rp), n // 128))
-            assert ctx.last_chain_form() == 2
+            assert ctx.last_chain_form() == (3 if kdt is np.float64 else 2)
             assert_same_bits(got["groupdq"], ref["groupdq"], "groupdq")
             assert_same_bits(got["pixeldq"], ref["pixeldq"], "pixeldq")
             for k in ("slope", "err_read", "err_poisson"):
