@@ -355,6 +355,72 @@ int rip_last_chain_form(rip_ctx *ctx);
 int rip_stage_pearson(rip_ctx *ctx, size_t n, const double *I, double tilnu21, double tilnu31, double tilnu41, uint64_t seed,
                       uint32_t stream, double *draws, int32_t *types, double *params);
 
+/* ---- Level-1 synthesis -- DEVICE pointers, asynchronous on the context's stream ------------------ */
+/* The per-pixel work of from_sim/sim_to_isim.py that turns an electron-count image into a raw exposure: make_l1_fullcal
+   (:163-262, with the loop of romanisim.l1.apportion_counts_to_resultants it calls), fill_in_refdata_and_1f (:306-403) and the
+   EXTRACT_REF block (:711-730).  Calibration arrays as the CALDIR files hold them, resident in HBM: */
+typedef struct rip_synth_cal {
+    int32_t ny, nx, nb;        /* full frame and its reference-pixel border; active region (ny-2nb, nx-2nb)             */
+    int32_t channelwidth;      /* nx = 32 channels of this many columns; the reference output has one channel's width  */
+    int32_t nplanes;           /* Legendre planes of the linearity file, 2..17                                          */
+    int32_t gain_dtype;        /* RIP_F32 or RIP_F64                                                                     */
+    int32_t ipc_dtype;         /* RIP_F32 or RIP_F64                                                                     */
+    int32_t amp33_valid;       /* read file has a valid amp33 block (med, std, M_PINK, RU_PINK)                          */
+    const void *gain;          /* (ny,nx)                                                                               */
+    const float *read_noise;   /* read file "data" (ny,nx)                                                              */
+    const float *resetnoise;   /* read file "resetnoise" (ny,nx)                                                        */
+    const float *dark_slope;   /* dark file "dark_slope" (ny,nx)                                                        */
+    const float *dark;         /* the LAST ngrp planes of the dark file's "data": (ngrp,ny,nx)                          */
+    const float *lin_coefs;    /* (nplanes,ny,nx)                                                                       */
+    const float *smin, *smax;  /* (ny,nx)                                                                               */
+    const void *ipc4d;         /* (3,3,ny-2nb,nx-2nb), or NULL: no IPC (IL(..., ipc_file=None))                          */
+    const float *biascorr;     /* the last ngrp planes of the biascorr file's "data": (ngrp,ny-2nb,nx-2nb), or NULL      */
+    double tbias;              /* biascorr "t0" (used only with biascorr)                                               */
+    const float *amp33_med, *amp33_std;   /* (ny,channelwidth), or NULL                                                 */
+    double m_pink, ru_pink;    /* amp33 "M_PINK", "RU_PINK"                                                             */
+    double u_pink, c_pink;     /* read file anc "U_PINK", "C_PINK"                                                      */
+} rip_synth_cal;
+
+/* romanisim.l1.apportion_counts_to_resultants, the sampling part (dependency absent from the reference tree: published
+   algorithm restated, oracle/l1sim.py): read r takes Binomial(counts - collected so far, (t_r - t_{r-1}) / (t_last - t_{r-1}))
+   electrons; reads_e (nreads,nya,nxa) i32 = electrons collected up to each read, so reads_e[nreads-1] == counts.  counts
+   (nya,nxa) f32 holds integers, or -- poisson != 0 -- the MEAN, of which a Poisson deviate is drawn first (what
+   Image2D.simulate :660-662 adds before it calls make_l1_fullcal).  t_reads: nreads times, HOST array, ascending.
+   Deviates from the device generator (Philox; inversion / BTRS binomial, inversion / PTRS Poisson) keyed by (seed, read,
+   pixel).  The distribution is what is reproduced, not romanisim's numpy stream. */
+int rip_synth_apportion(rip_ctx *ctx, const float *counts, int nya, int nxa, int poisson, int nreads, const double *t_reads,
+                        uint64_t seed, int32_t *reads_e);
+
+/* make_l1_fullcal :203-260 after the sampling: reset noise in electrons (normal * resetnoise * gain - t0 * dark_slope / gain),
+   per read IL.apply(electrons + reset, electrons=True) (ipc_linearity.py:461-513: i32 + f32 -> f64, ipc_fwd, / gain, 24
+   bisection steps of invlinearity in f64), resultant = f32 mean of its reads, + normal * read_noise / sqrt(reads), + biascorr,
+   rounded half to even.  group_count: HOST array, reads per resultant (sum = the number of planes of reads_e).
+   normals_reset (nya,nxa) f32 and normals_read (ngrp,nya,nxa) f32 standard normal deviates, or NULL: device generator (seed).
+   Outputs, each optional: start_e (nya,nxa) f32 the reset-noise image; resultants (ngrp,nya,nxa) f32; cube (ngrp,ny,nx) u16 --
+   the resultants clipped to 0..65535 inside a zero border (what romanisim.l1.make_asdf builds around them).
+   Exact given the deviates (goldens from the reference's function). */
+int rip_synth_resultants(rip_ctx *ctx, const rip_synth_cal *cal, int ngrp, const int32_t *group_count, const int32_t *reads_e,
+                         const float *normals_reset, const float *normals_read, uint64_t seed, float *start_e,
+                         float *resultants, uint16_t *cube);
+
+/* fill_in_refdata_and_1f :306-403, in place on cube (ngrp,ny,nx) u16 and amp33 (ngrp,ny,channelwidth) u16 (or NULL: no
+   reference output): reference pixels = normal * read / sqrt(reads) + normal * resetnoise + dark, active pixels kept, every
+   pixel + (1/f frame of its channel * U_PINK + common frame * C_PINK) / sqrt(reads) with odd channels mirrored, rounded and
+   clipped to u16; amp33 = med + (normal * std + RU_PINK * frame + M_PINK * common) / sqrt(reads), cast.  banding == 0 skips
+   the correlated noise (fill_in_banding=False; amp33 is then left untouched, as in the reference).
+   normals (ngrp+1,ny,nx) f32, frames (ngrp,34,ny,channelwidth) f32 in the reference's draw order per group (common, channels
+   0..31, reference output) and white33 (ngrp,ny,channelwidth) f32, or NULL each: device generators (seed; frames as
+   rip_stage_noise_1f makes them).  Exact given the deviates (goldens from the reference's function). */
+int rip_synth_fill(rip_ctx *ctx, const rip_synth_cal *cal, int ngrp, const int32_t *group_count, int banding, const float *normals,
+                   const float *frames, const float *white33, uint64_t seed, uint16_t *cube, uint16_t *amp33);
+
+/* rip_stage_noise_1f with the frames left on the device: out (nframes,rows,width) f32 DEVICE memory. */
+int rip_synth_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, uint64_t seed, uint32_t stream_id, float *out);
+
+/* EXTRACT_REF (:711-730) on n-element planes: reference_read = data[0]; data[k] = clip(i32(data[k]) - (i32(data[0]) -
+   offset), 0, 65535) for k = 1..ngrp-1, in place (the caller drops plane 0).  Used for the cube and for amp33.  Exact. */
+int rip_synth_extract_ref(rip_ctx *ctx, uint16_t *data, int ngrp, size_t n, int offset, uint16_t *reference_read);
+
 /* ---- diagnostics ------------------------------------------------------------------------- */
 /* floating-point options of a context.  "guard_band": relative half-width of the band around the jump
    threshold inside which the significance is re-evaluated in the reference's exact operation order

@@ -69,6 +69,17 @@ class Outputs(C.Structure):
     ]
 
 
+class SynthCal(C.Structure):   # rip_synth_cal: DEVICE pointers
+    _fields_ = [
+        ("ny", C.c_int32), ("nx", C.c_int32), ("nb", C.c_int32), ("channelwidth", C.c_int32), ("nplanes", C.c_int32),
+        ("gain_dtype", C.c_int32), ("ipc_dtype", C.c_int32), ("amp33_valid", C.c_int32),
+        ("gain", C.c_void_p), ("read_noise", C.c_void_p), ("resetnoise", C.c_void_p), ("dark_slope", C.c_void_p),
+        ("dark", C.c_void_p), ("lin_coefs", C.c_void_p), ("smin", C.c_void_p), ("smax", C.c_void_p), ("ipc4d", C.c_void_p),
+        ("biascorr", C.c_void_p), ("tbias", C.c_double), ("amp33_med", C.c_void_p), ("amp33_std", C.c_void_p),
+        ("m_pink", C.c_double), ("ru_pink", C.c_double), ("u_pink", C.c_double), ("c_pink", C.c_double),
+    ]
+
+
 # every symbol include/romanhip.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 _I = C.c_int
@@ -109,6 +120,11 @@ SYMBOLS = {
     "rip_stats_l1_diff": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "rip_stats_l2_pack": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "rip_stats_reduce": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
+    "rip_synth_apportion": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, C.c_uint64, _VP]),
+    "rip_synth_resultants": (_I, [_VP, C.POINTER(SynthCal), _I, _VP, _VP, _VP, _VP, C.c_uint64, _VP, _VP, _VP]),
+    "rip_synth_fill": (_I, [_VP, C.POINTER(SynthCal), _I, _VP, _I, _VP, _VP, _VP, C.c_uint64, _VP, _VP]),
+    "rip_synth_noise_1f": (_I, [_VP, _I, _I, _I, C.c_uint64, C.c_uint32, _VP]),
+    "rip_synth_extract_ref": (_I, [_VP, _VP, _I, C.c_size_t, _I, _VP]),
     "rip_set_option_f64": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "rip_set_option": (_I, [_VP, C.c_char_p, _I]),
     "rip_last_chain_form": (_I, [_VP]),

@@ -1,5 +1,6 @@
 // Inverse linearity (the simulation-side inverse of A4): ipc_linearity.invlinearity
 // (ipc_linearity.py:347-394) -- the step the reference documents as the slowest of its simulation -> Level 1 workflow.
+// (per-pixel arithmetic: invlin_device.h)
 // 24 bisection steps on z in (-1, 1); each evaluates the Legendre series of ipc_linearity._lin (:192-231) WITHOUT the linear
 // extrapolation branch, in numpy's operation order and dtypes:
 //     phi (f32) += coefs[L] (f32) * poly (ZT)          one rounding per operation; with ZT = f64 the sum is rounded back to f32
@@ -8,6 +9,7 @@
 // then S = Smin + (Smax - Smin) / 2 * (1 + z).  One thread per pixel; coefficient planes are read once per pixel (registers).
 // Host arrays in and out, like the other stage entries.  Exact.
 #include "rip_common.h"
+#include "invlin_device.h"
 
 namespace {
 
@@ -40,32 +42,8 @@ __global__ __launch_bounds__(256) void invlin_kernel(const ZT *__restrict__ slin
     float c[NP];
 #pragma unroll
     for (int L = 0; L < NP; ++L) c[L] = coefs[(size_t)L * npix + i];
-    ZT c1[NP], c2[NP];   // (2L+1)/(L+1) and L/(L+1): f64 division, then the cast numpy applies to a Python float operand
-#pragma unroll
-    for (int L = 1; L < NP; ++L) {
-        c1[L] = (ZT)((double)(2 * L + 1) / (double)(L + 1));
-        c2[L] = (ZT)((double)L / (double)(L + 1));
-    }
-    const ZT target = slin[i];
-    ZT z = (ZT)0;
-    ZT step = (ZT)1;
-    bool ex = false;
-    for (int j = 1; j <= 24; ++j) {
-        step = step * (ZT)0.5;
-        ex = (z < (ZT)0 ? -z : z) > (ZT)1;
-        float phi = c[0];
-        ZT pp = (ZT)1, p = z;
-#pragma unroll
-        for (int L = 1; L < NP; ++L) {
-            phi = (float)((ZT)phi + (ZT)c[L] * p);
-            const ZT pn = (c1[L] * z) * p - c2[L] * pp;
-            pp = p;
-            p = pn;
-        }
-        z = z + (((ZT)phi < target) ? step : -step);
-    }
-    const float half = (smax[i] - smin[i]) / 2.0f;
-    out[i] = (ZT)smin[i] + (ZT)half * ((ZT)1 + z);
+    bool ex;
+    out[i] = rip_invlin_pixel<ZT, NP>(slin[i], c, smin[i], smax[i], ex);
     if (exflag) exflag[i] = ex ? 1 : 0;
 }
 

@@ -1,0 +1,38 @@
+// Per-pixel inverse linearity (ipc_linearity.invlinearity, ipc_linearity.py:347-394), shared by the stage kernel (invlin.hip)
+// and the Level-1 synthesis (synth.hip).  24 bisection steps on z in (-1, 1); each evaluates the Legendre series of
+// ipc_linearity._lin (:192-231) WITHOUT the linear extrapolation branch, in numpy's operation order and dtypes:
+//     phi (f32) += coefs[L] (f32) * poly (ZT)          one rounding per operation; with ZT = f64 the sum is rounded back to f32
+//     poly_next = c1_L * z * poly - c2_L * poly_prev    c1, c2 Python floats: cast to f32 when z is f32, exact f64 otherwise
+//     z += phi < Slin ? 2^-j : -2^-j
+// then S = Smin + (Smax - Smin) / 2 * (1 + z).  `ex` = |z| > 1 at the last evaluation (the reference's second return value).
+#pragma once
+#include <hip/hip_runtime.h>
+
+template <typename ZT, int NP>
+__device__ __forceinline__ ZT rip_invlin_pixel(ZT target, const float (&c)[NP], float smin, float smax, bool &ex) {
+    ZT c1[NP], c2[NP];   // (2L+1)/(L+1) and L/(L+1): f64 division, then the cast numpy applies to a Python float operand
+#pragma unroll
+    for (int L = 1; L < NP; ++L) {
+        c1[L] = (ZT)((double)(2 * L + 1) / (double)(L + 1));
+        c2[L] = (ZT)((double)L / (double)(L + 1));
+    }
+    ZT z = (ZT)0;
+    ZT step = (ZT)1;
+    ex = false;
+    for (int j = 1; j <= 24; ++j) {
+        step = step * (ZT)0.5;
+        ex = (z < (ZT)0 ? -z : z) > (ZT)1;
+        float phi = c[0];
+        ZT pp = (ZT)1, p = z;
+#pragma unroll
+        for (int L = 1; L < NP; ++L) {
+            phi = (float)((ZT)phi + (ZT)c[L] * p);
+            const ZT pn = (c1[L] * z) * p - c2[L] * pp;
+            pp = p;
+            p = pn;
+        }
+        z = z + (((ZT)phi < target) ? step : -step);
+    }
+    const float half = (smax - smin) / 2.0f;
+    return (ZT)smin + (ZT)half * ((ZT)1 + z);
+}

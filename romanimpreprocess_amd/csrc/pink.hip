@@ -88,10 +88,10 @@ __global__ __launch_bounds__(256) void pink_out_kernel(const hipfftDoubleComplex
     out[(size_t)f * half + k] = (float)(z[(size_t)f * L + k].x / sqrt(2.0) - mean);
 }
 
-}   // namespace
-
-extern "C" int rip_stage_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, const double *normals, uint64_t seed,
-                                  uint32_t stream_id, float *out) {
+// out: host memory (frames copied back chunk by chunk, call synchronous) or, out_dev, device memory (asynchronous apart from the
+// release of the transform buffers at the end)
+int noise_1f_impl(rip_ctx *ctx, int rows, int width, int nframes, const double *normals, uint64_t seed, uint32_t stream_id, float *out,
+                  bool out_dev) {
     if (rows < 1 || width < 1 || nframes < 1 || !out) return rip_fail(ctx, RIP_EINVAL, "noise_1f: bad arguments");
     RIP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t L = (size_t)2 * rows * width, half = L / 2;
@@ -119,7 +119,7 @@ extern "C" int rip_stage_noise_1f(rip_ctx *ctx, int rows, int width, int nframes
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nframes, ((size_t)1 << 30) / (L * sizeof(hipfftDoubleComplex))));
     PK_HIP(hipMalloc((void **)&z, (size_t)chunk * L * sizeof(hipfftDoubleComplex)));
     PK_HIP(hipMalloc((void **)&d_s, (size_t)chunk * 256 * sizeof(double)));
-    PK_HIP(hipMalloc((void **)&d_o, (size_t)chunk * half * sizeof(float)));
+    if (!out_dev) PK_HIP(hipMalloc((void **)&d_o, (size_t)chunk * half * sizeof(float)));
     if (normals) PK_HIP(hipMalloc((void **)&d_n, (size_t)chunk * 2 * L * sizeof(double)));
     int n1 = (int)L;
     if (hipfftPlanMany(&plan, 1, &n1, nullptr, 1, n1, nullptr, 1, n1, HIPFFT_Z2Z, chunk) != HIPFFT_SUCCESS) {
@@ -146,12 +146,25 @@ extern "C" int rip_stage_noise_1f(rip_ctx *ctx, int rows, int width, int nframes
             return rc;
         }
         hipLaunchKernelGGL(pink_sum_kernel, dim3(256, nf), dim3(256), 0, ctx->stream, z, L, d_s);
-        hipLaunchKernelGGL(pink_out_kernel, dim3((unsigned)((half + 255) / 256), nf), dim3(256), 0, ctx->stream, z, L, (const double *)d_s, d_o);
+        float *dst = out_dev ? out + (size_t)f0 * half : d_o;
+        hipLaunchKernelGGL(pink_out_kernel, dim3((unsigned)((half + 255) / 256), nf), dim3(256), 0, ctx->stream, z, L, (const double *)d_s, dst);
         PK_HIP(hipGetLastError());
-        PK_HIP(hipMemcpyAsync(out + (size_t)f0 * half, d_o, (size_t)nf * half * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        PK_HIP(hipStreamSynchronize(ctx->stream));
+        if (!out_dev) PK_HIP(hipMemcpyAsync(out + (size_t)f0 * half, d_o, (size_t)nf * half * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (!out_dev) PK_HIP(hipStreamSynchronize(ctx->stream));   // device output: the next chunk follows in stream order
     }
+    if (out_dev) PK_HIP(hipStreamSynchronize(ctx->stream));   // before the buffers go
 #undef PK_HIP
     done();
     return RIP_OK;
+}
+
+}   // namespace
+
+extern "C" int rip_stage_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, const double *normals, uint64_t seed,
+                                  uint32_t stream_id, float *out) {
+    return noise_1f_impl(ctx, rows, width, nframes, normals, seed, stream_id, out, false);
+}
+
+extern "C" int rip_synth_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, uint64_t seed, uint32_t stream_id, float *out) {
+    return noise_1f_impl(ctx, rows, width, nframes, nullptr, seed, stream_id, out, true);
 }

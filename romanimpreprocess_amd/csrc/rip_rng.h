@@ -1,0 +1,121 @@
+// Counter-based random deviates for the simulation-side kernels (synth.hip): Philox-4x32-10 keyed by a 64-bit seed, the
+// counter words chosen by the caller (pixel, read / plane, attempt, domain tag), so every deviate is a pure function of its
+// coordinates: reproducible, order-independent, no generator state in memory.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace riprng {
+
+__device__ __forceinline__ void philox(uint32_t (&c)[4], uint64_t seed) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (uint32_t)p1;
+        c[3] = (uint32_t)p0;
+        c[0] = n0;
+        c[2] = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// uniform in (0, 1) from two words (53 bits)
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+    return ((double)(((uint64_t)hi << 21) | (lo >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// one f32 standard normal for (a, b, tag): Box-Muller on two 24-bit uniforms
+__device__ __forceinline__ float normal_f32(uint64_t seed, uint32_t a, uint32_t b, uint32_t tag) {
+    uint32_t c[4] = {a, b, tag, 0x6c317379u};
+    philox(c, seed);
+    const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+}
+
+// Poisson deviate of mean lam: inversion below 10, W. Hoermann's transformed rejection (PTRS, 1993) above
+__device__ inline double poisson(double lam, uint64_t seed, uint32_t a, uint32_t b, uint32_t tag) {
+    if (!(lam > 0.0)) return 0.0;
+    if (lam < 10.0) {
+        uint32_t c[4] = {a, b, tag, 0x706f6932u};
+        philox(c, seed);
+        const double u = u53(c[0], c[1]);
+        double p = exp(-lam), cdf = p;
+        int k = 0;
+        while (u > cdf && k < 200) {
+            ++k;
+            p *= lam / k;
+            cdf += p;
+        }
+        return (double)k;
+    }
+    const double slam = sqrt(lam), loglam = log(lam);
+    const double bb = 0.931 + 2.53 * slam, aa = -0.059 + 0.02483 * bb, inv_alpha = 1.1239 + 1.1328 / (bb - 3.4), vr = 0.9277 - 3.6224 / (bb - 2.0);
+    for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+        uint32_t c[4] = {a, b, tag ^ (attempt << 24), 0x70747232u};
+        philox(c, seed);
+        const double u = u53(c[0], c[1]) - 0.5, v = u53(c[2], c[3]);
+        const double us = 0.5 - fabs(u);
+        const double k = floor((2.0 * aa / us + bb) * u + lam + 0.43);
+        if (us >= 0.07 && v <= vr) return k;
+        if (k < 0.0 || (us < 0.013 && v > us)) continue;
+        if (log(v) + log(inv_alpha) - log(aa / (us * us) + bb) <= -lam + k * loglam - lgamma(k + 1.0)) return k;
+    }
+    return floor(lam + 0.5);   // not reached in practice
+}
+
+// Binomial(n, p) deviate: inversion (sequential search) where n min(p, 1-p) < 10, else W. Hoermann's transformed rejection
+// with squeeze (BTRS, "The generation of binomial random variates", 1993); the acceptance test compares with the exact ratio
+// of probabilities through lgamma.
+__device__ inline int binomial(int n, double p, uint64_t seed, uint32_t a, uint32_t b, uint32_t tag) {
+    if (n <= 0 || !(p > 0.0)) return 0;
+    if (p >= 1.0) return n;
+    const bool flip = p > 0.5;
+    const double q = flip ? 1.0 - p : p;
+    int k;
+    if ((double)n * q < 10.0) {
+        uint32_t c[4] = {a, b, tag, 0x62696e31u};
+        philox(c, seed);
+        const double u = u53(c[0], c[1]);
+        const double odds = q / (1.0 - q);
+        double pm = exp((double)n * log1p(-q)), cdf = pm;
+        k = 0;
+        while (u > cdf && k < n && k < 400) {
+            ++k;
+            pm *= odds * (double)(n - k + 1) / (double)k;
+            cdf += pm;
+        }
+    } else {
+        const double nd = (double)n, sd = sqrt(nd * q * (1.0 - q));
+        const double bb = 1.15 + 2.53 * sd, aa = -0.0873 + 0.0248 * bb + 0.01 * q, cc = nd * q + 0.5, vr = 0.92 - 4.2 / bb;
+        const double alpha = (2.83 + 5.1 / bb) * sd, lr = log(q / (1.0 - q));
+        const double m = floor((nd + 1.0) * q);
+        const double lpm = -lgamma(m + 1.0) - lgamma(nd - m + 1.0) + m * lr;   // log pmf(m) up to the common terms
+        k = (int)m;
+        for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+            uint32_t c[4] = {a, b, tag ^ (attempt << 24), 0x62747273u};
+            philox(c, seed);
+            const double u = u53(c[0], c[1]) - 0.5;
+            double v = u53(c[2], c[3]);
+            const double us = 0.5 - fabs(u);
+            const double kd = floor((2.0 * aa / us + bb) * u + cc);
+            if (kd < 0.0 || kd > nd) continue;
+            if (us >= 0.07 && v <= vr) {
+                k = (int)kd;
+                break;
+            }
+            v = log(v * alpha / (aa / (us * us) + bb));
+            if (v <= -lgamma(kd + 1.0) - lgamma(nd - kd + 1.0) + kd * lr - lpm) {
+                k = (int)kd;
+                break;
+            }
+        }
+    }
+    return flip ? n - k : k;
+}
+
+}   // namespace riprng

@@ -50,3 +50,26 @@ def gpu_context():
     """The process-wide libromanhip context; the test FAILS (not skips) if the library or GPU is missing."""
     from romanimpreprocess_amd import _native
     return _native.default_context(0)
+
+
+def l1sim_golden_cal(g):
+    """The calibration dict of the ``l1sim`` fixture (keys ``cal_<file>_<entry>[_<sub>]``), and its read pattern."""
+    cal = {}
+    for key in list(g.keys()):
+        if not key.startswith("cal_"):
+            continue
+        _, name, rest = key.split("_", 2)
+        node = cal.setdefault(name, {})
+        if name == "read" and rest.split("_", 1)[0] in ("anc", "amp33"):
+            sub, leaf = rest.split("_", 1)
+            v = g[key]
+            node.setdefault(sub, {})[leaf] = v if v.ndim else v.item()
+        else:
+            v = g[key]
+            node[rest] = v if v.ndim else v.item()
+    counts, flat = g["read_pattern_counts"], list(g["read_pattern_flat"])
+    rp, at = [], 0
+    for c in counts:
+        rp.append([int(r) for r in flat[at:at + int(c)]])
+        at += int(c)
+    return cal, rp

@@ -36,6 +36,8 @@ def test_ctypes_structs_match_the_header(tmp_path):
         "rip_ramp_desc": ["location", "data", "data_dtype", "amp33", "area_factor", "channel_lines", "flag_saturation",
                           "sat_skip_firstn", "sat_dilution"],
         "rip_outputs": ["location", "slope", "pixeldq", "groupdq", "cube"],
+        "rip_synth_cal": ["ny", "channelwidth", "amp33_valid", "gain", "dark", "smax", "ipc4d", "biascorr", "tbias", "amp33_std",
+                          "m_pink", "c_pink"],
     }
     body = "".join(f'printf("{s} %zu\\n", sizeof({s}));\n' + "".join(
         f'printf("{s}.{f} %zu\\n", offsetof({s}, {f}));\n' for f in fl) for s, fl in fields.items())
@@ -44,7 +46,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
     subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
     got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
     mirror = {"rip_caldir_desc": _native.CaldirDesc, "rip_plan_desc": _native.PlanDesc,
-              "rip_ramp_desc": _native.RampDesc, "rip_outputs": _native.Outputs}
+              "rip_ramp_desc": _native.RampDesc, "rip_outputs": _native.Outputs, "rip_synth_cal": _native.SynthCal}
     for s, fl in fields.items():
         assert int(got[s]) == C.sizeof(mirror[s]), s
         for f in fl:

@@ -300,3 +300,29 @@ def test_noise_1f_frame_matches_the_reference(golden):
         frame = onoise.noise_1f_frame(normals, 4096, 128)
         assert_same_bits(frame[::257], g[f"s{seed}_rows"], f"sampled rows, seed {seed}")
         assert hashlib.sha256(np.ascontiguousarray(frame)).hexdigest() == str(g[f"s{seed}_sha256"])
+
+
+def test_l1_synthesis_matches_the_reference_functions():
+    """oracle/l1sim.py against make_l1_fullcal and fill_in_refdata_and_1f executed from the reference's file (fixture l1sim)"""
+    from conftest import l1sim_golden_cal
+    from oracle import l1sim
+
+    g = load_golden("l1sim")
+    cal, rp = l1sim_golden_cal(g)
+    read_time = float(g["read_time"])
+    res, start = l1sim.make_l1_fullcal(g["counts"], rp, cal, read_time, g["normals_reset"], g["reads_e"], g["normals_read"])
+    assert_same_bits(res, g["resultants"], "rounded resultants of make_l1_fullcal")
+    tij = l1sim.read_pattern_to_tij(rp, read_time)
+    # the apportioned electrons are cumulative, end at the counts, and restating the draw with the same generator gives them back
+    assert np.array_equal(g["reads_e"][-1], g["counts"].astype(np.int32)) and np.all(np.diff(g["reads_e"], axis=0) >= 0)
+    assert np.array_equal(l1sim.binomial_shares(g["counts"], tij, np.random.default_rng(903 + 1)), g["reads_e"])
+    im = l1sim.embed(res, 32, 512)
+    assert np.array_equal(im, g["im_before"])
+    amp33 = np.zeros(g["amp33_after"].shape, dtype=np.uint16)
+    l1sim.fill_in_refdata_and_1f(im, cal, tij, g["normals_fill"], frames=g["frames"], white33=g["white33"], amp33=amp33,
+                                 channelwidth=16)
+    assert np.array_equal(im, g["im_after"]), "cube after fill_in_refdata_and_1f"
+    assert np.array_equal(amp33, g["amp33_after"]), "reference output after fill_in_refdata_and_1f"
+    # reference pixels really changed, the active region moved by the 1/f noise only
+    assert np.all(g["im_before"][:, :4] == 0) and np.all(im[:, :4] > 0)
+    assert np.max(np.abs(im[:, 4:-4, 4:-4].astype(np.int32) - g["im_before"][:, 4:-4, 4:-4].astype(np.int32))) < 40

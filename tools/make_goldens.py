@@ -672,11 +672,118 @@ def case_noise1f():
     save("noise_1f_frame", seeds=np.array([3, 4]), **out)
 
 
+def case_l1sim():
+    """``make_l1_fullcal`` (:163-262) and ``fill_in_refdata_and_1f`` (:306-403) of from_sim/sim_to_isim.py, taken from the file
+    with ``ast`` and EXECUTED as they stand on a 32 x 512 frame (the smallest one that satisfies the border rules the two
+    functions and ``IL.apply`` hard-code: (8192 - 504 // 2) % 256 == 4, (8192 - 24 // 2) % 16 == 4; ``pars.nside`` = 32 rows and
+    ``pars.channelwidth`` = 16 columns in the namespace they run in).  ``IL`` is the reference's own class
+    (utils/ipc_linearity.py, imported unmodified).  Stand-ins: ``galsim.GaussianDeviate(rng).generate(a)`` fills ``a`` from a
+    numpy generator and records what it drew; ``asdf.open`` serves in-memory trees; ``rstl1`` (romanisim.l1, absent from the
+    reference tree and from this image) is oracle/l1sim.py's restatement of its published algorithm, cosmic rays and
+    persistence off.  The fixture stores the calibration arrays, every deviate handed out (for the 1/f part the frames ``noise_1f_frame`` returned), and the outputs."""
+    import ast
+    import copy
+    import warnings
+
+    from oracle import l1sim
+
+    ny, nx, nb, cw = 32, 512, 4, 16
+    rp = [[0], [1, 2], [3, 4, 5, 6], [7]]
+    read_time = 3.04
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=3, seed=901, bias_amplitude=2.0)
+    # make_caldir sizes the reference-output statistics for 128-column channels: cut them to this frame's 16
+    a33 = cal["read"]["amp33"]
+    a33["med"], a33["std"] = np.ascontiguousarray(a33["med"][:, :cw]), np.ascontiguousarray(a33["std"][:, :cw])
+    files = {k: register(f"/mem/l1sim_{k}.asdf", cal[k]) for k in ("read", "gain", "dark", "biascorr", "linearitylegendre", "ipc4d")}
+
+    path = os.path.join(REF_SRC, "romanimpreprocess", "from_sim", "sim_to_isim.py")
+    tree = ast.parse(open(path).read())
+    names = ("make_l1_fullcal", "noise_1f_frame", "fill_in_refdata_and_1f")
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(keep) == 3
+    drawn, captured = [], {}
+
+    class _Rng:   # what the extracted code passes around as `rng`
+        def __init__(self, seed):
+            self.normal = np.random.default_rng(seed)
+            self.binom = np.random.default_rng(seed + 1)
+
+    class _GD:
+        def __init__(self, rng):
+            self.rng = rng
+
+        def generate(self, a):
+            a[...] = self.rng.normal.standard_normal(a.size).reshape(a.shape)
+            drawn.append(np.array(a, copy=True))
+
+    def _tij(read_pattern):
+        return l1sim.read_pattern_to_tij(read_pattern, read_time)
+
+    def _apportion(counts, tij, inv_linearity=None, crparam=None, persistence=None, tstart=None, rng=None, seed=None):
+        reads_e = l1sim.binomial_shares(counts, tij, rng.binom)
+        captured["reads_e"] = reads_e
+        res = l1sim.apportion_counts_to_resultants(reads_e, tij, lambda e: inv_linearity.apply(e, electrons=True))
+        dq = np.zeros(res.shape, dtype=np.uint32)
+        dq |= inv_linearity.dq
+        return res, dq
+
+    def _readnoise(resultants, tij, rng=None, seed=None, read_noise=None):
+        nrm = np.zeros(resultants.shape, dtype="f4")
+        _GD(rng).generate(nrm)
+        return l1sim.add_read_noise_to_resultants(resultants, tij, read_noise, nrm)
+
+    ns = {"np": np, "galsim": types.SimpleNamespace(GaussianDeviate=_GD), "asdf": sys.modules["asdf"], "copy": copy,
+          "warnings": warnings, "IL": ref_il.IL, "u": types.SimpleNamespace(DN=1),
+          "pars": types.SimpleNamespace(nborder=nb, nside=ny, channelwidth=cw), "parameters": types.SimpleNamespace(nborder=nb),
+          "rstl1": types.SimpleNamespace(read_pattern_to_tij=_tij, apportion_counts_to_resultants=_apportion,
+                                         add_read_noise_to_resultants=_readnoise)}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    frames_made, make_frame = [], ns["noise_1f_frame"]
+
+    def _recording_frame(rng):   # the reference's generator (pinned by the noise1f case); its frames are kept, not their 2**11 deviates
+        n_before = len(drawn)
+        f = make_frame(rng)
+        del drawn[n_before:]
+        frames_made.append(f.copy())
+        return f
+
+    ns["noise_1f_frame"] = _recording_frame
+
+    rng0 = np.random.default_rng(902)
+    counts = rng0.poisson(np.where(rng0.random((ny - 2 * nb, nx - 2 * nb)) < 0.03, 9.0e4, 2500.0)).astype(np.float32)
+    res, dq = ns["make_l1_fullcal"](types.SimpleNamespace(array=counts), rp, files, rng=_Rng(903))
+    normals_reset, normals_read = drawn[0], drawn[1]
+    del drawn[:]
+    im = l1sim.embed(np.asarray(res), ny, nx, nb)
+    im_before = im.copy()
+    amp33 = np.zeros((len(rp), ny, cw), dtype=np.uint16)
+    ns["fill_in_refdata_and_1f"](im, files, _Rng(904), _tij(rp), fill_in_banding=True, amp33=amp33)
+    # draw order: the (ngrp+1, ny, nx) block, then per group: common frame, 32 channel frames, white (ny, cw), amp33's frame
+    G = len(rp)
+    normals_fill, white33 = drawn[0], np.stack(drawn[1:])
+    assert white33.shape == (G, ny, cw) and len(frames_made) == 34 * G
+    frames = np.stack(frames_made).reshape(G, 34, ny, cw)
+    ref_first, rest = l1sim.extract_ref(im, 1000)   # EXTRACT_REF (:711-730) restated; the block is inline code of a method
+    flat = {}
+    for k in ("read", "gain", "dark", "biascorr", "linearitylegendre", "ipc4d"):
+        for kk, v in cal[k].items():
+            if isinstance(v, dict):
+                for k3, v3 in v.items():
+                    flat[f"cal_{k}_{kk}_{k3}"] = np.asarray(v3)
+            else:
+                flat[f"cal_{k}_{kk}"] = np.asarray(v)
+    save("l1sim", read_pattern_flat=np.array([r for g in rp for r in g]), read_pattern_counts=np.array([len(g) for g in rp]),
+         read_time=np.float64(read_time), counts=counts, normals_reset=normals_reset, normals_read=normals_read,
+         reads_e=captured["reads_e"], resultants=np.asarray(res, dtype=np.float32), dq=dq, im_before=im_before,
+         normals_fill=normals_fill.astype(np.float32), frames=frames, white33=white33.astype(np.float32),
+         im_after=im, amp33_after=amp33, **flat)
+
+
 CASES = {
     "lin_known_answer": case_lin_known_answer, "multilin": case_multilin, "ipc": case_ipc,
     "weights": case_weights, "rampfit": case_rampfit, "flat": case_flat, "refpix": case_refpix,
     "chain": case_chain, "post": case_post, "harness": case_harness, "il": case_il, "il_example": case_il_example,
-    "pearson": case_pearson, "noise1f": case_noise1f,
+    "pearson": case_pearson, "noise1f": case_noise1f, "l1sim": case_l1sim,
 }
 
 if __name__ == "__main__":
