@@ -361,7 +361,8 @@ int rip_stage_pearson(rip_ctx *ctx, size_t n, const double *I, double tilnu21, d
    EXTRACT_REF block (:711-730).  Calibration arrays as the CALDIR files hold them, resident in HBM: */
 typedef struct rip_synth_cal {
     int32_t ny, nx, nb;        /* full frame and its reference-pixel border; active region (ny-2nb, nx-2nb)             */
-    int32_t channelwidth;      /* nx = 32 channels of this many columns; the reference output has one channel's width  */
+    int32_t channelwidth;      /* columns per readout channel (nx / channelwidth channels: 32 of 128 on a full frame);   */
+                               /* the reference output has one channel's width                                           */
     int32_t nplanes;           /* Legendre planes of the linearity file, 2..17                                          */
     int32_t gain_dtype;        /* RIP_F32 or RIP_F64                                                                     */
     int32_t ipc_dtype;         /* RIP_F32 or RIP_F64                                                                     */
@@ -408,8 +409,8 @@ int rip_synth_resultants(rip_ctx *ctx, const rip_synth_cal *cal, int ngrp, const
    pixel + (1/f frame of its channel * U_PINK + common frame * C_PINK) / sqrt(reads) with odd channels mirrored, rounded and
    clipped to u16; amp33 = med + (normal * std + RU_PINK * frame + M_PINK * common) / sqrt(reads), cast.  banding == 0 skips
    the correlated noise (fill_in_banding=False; amp33 is then left untouched, as in the reference).
-   normals (ngrp+1,ny,nx) f32, frames (ngrp,34,ny,channelwidth) f32 in the reference's draw order per group (common, channels
-   0..31, reference output) and white33 (ngrp,ny,channelwidth) f32, or NULL each: device generators (seed; frames as
+   normals (ngrp+1,ny,nx) f32, frames (ngrp,nch+2,ny,channelwidth) f32 in the reference's draw order per group (common, channels
+   0..nch-1, reference output; nch = nx / channelwidth) and white33 (ngrp,ny,channelwidth) f32, or NULL each: device generators (seed; frames as
    rip_stage_noise_1f makes them).  Exact given the deviates (goldens from the reference's function). */
 int rip_synth_fill(rip_ctx *ctx, const rip_synth_cal *cal, int ngrp, const int32_t *group_count, int banding, const float *normals,
                    const float *frames, const float *white33, uint64_t seed, uint16_t *cube, uint16_t *amp33);

@@ -150,11 +150,11 @@ __global__ __launch_bounds__(256) void zero_border_kernel(uint16_t *cube, int ny
 
 struct FillArgs {
     const float *normals;   // (ngrp+1, ny, nx) or null
-    const float *frames;    // (ngrp, 34, ny, cw) or null: no banding
+    const float *frames;    // (ngrp, nch+2, ny, cw) or null: no banding
     const float *white33;   // (ngrp, ny, cw) or null
     const float *read_noise, *resetnoise, *dark, *med, *std;
     uint16_t *cube, *amp33;
-    int ny, nx, nb, cw, ngrp;
+    int ny, nx, nb, cw, ngrp, nch;
     float u_pink, c_pink, ru_pink, m_pink;
     uint64_t seed;
     float root[RIP_MAX_GROUPS];   // f32(len ** 0.5): the divisor of an f32 array by a Python float
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void fill_kernel(FillArgs a) {
         const int ch = x / a.cw, xc = x % a.cw;
         const int xs = (ch & 1) ? a.cw - 1 - xc : xc;
         const size_t fsz = (size_t)a.ny * a.cw;
-        const float *fj = a.frames + (size_t)j * 34 * fsz;
+        const float *fj = a.frames + (size_t)j * (a.nch + 2) * fsz;
         const float common = fj[(size_t)y * a.cw + xs] * a.c_pink;
         const float stripe = fj[(size_t)(1 + ch) * fsz + (size_t)y * a.cw + xs] * a.u_pink + common;
         v = v + stripe / a.root[j];
@@ -191,11 +191,11 @@ __global__ __launch_bounds__(256) void amp33_kernel(FillArgs a) {
     const int xc = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, j = blockIdx.z;
     if (xc >= a.cw) return;
     const size_t fsz = (size_t)a.ny * a.cw, i = (size_t)y * a.cw + xc;
-    const float *fj = a.frames + (size_t)j * 34 * fsz;
+    const float *fj = a.frames + (size_t)j * (a.nch + 2) * fsz;
     const float nrm = a.white33 ? a.white33[(size_t)j * fsz + i] : riprng::normal_f32(a.seed, (uint32_t)i, (uint32_t)j, TAG_WHITE33);
     const float white = nrm * a.std[i];
     const float common = fj[i] * a.c_pink;
-    const float pink = a.ru_pink * fj[33 * fsz + i] + a.m_pink * common;
+    const float pink = a.ru_pink * fj[(size_t)(a.nch + 1) * fsz + i] + a.m_pink * common;
     const float level = a.med[i] + (white + pink) / a.root[j];
     a.amp33[(size_t)j * fsz + i] = (uint16_t)(long long)level;   // the C cast numpy's astype performs: towards zero, modulo 2^16
 }
@@ -329,16 +329,17 @@ extern "C" int rip_synth_fill(rip_ctx *ctx, const rip_synth_cal *cal, int ngrp, 
     int rc = check_cal(ctx, cal, ngrp, group_count, "synth_fill");
     if (rc) return rc;
     if (!cube || !cal->read_noise || !cal->resetnoise || !cal->dark) return rip_fail(ctx, RIP_EINVAL, "synth_fill: missing array");
-    if (cal->channelwidth < 1 || cal->nx != 32 * cal->channelwidth)
-        return rip_fail(ctx, RIP_EINVAL, "synth_fill: %d columns are not 32 channels of %d", cal->nx, cal->channelwidth);
+    if (cal->channelwidth < 1 || cal->nx % cal->channelwidth)
+        return rip_fail(ctx, RIP_EINVAL, "synth_fill: %d columns are not whole channels of %d", cal->nx, cal->channelwidth);
+    const int nch = cal->nx / cal->channelwidth;
     const bool do33 = banding && amp33 && cal->amp33_valid;
     if (do33 && (!cal->amp33_med || !cal->amp33_std)) return rip_fail(ctx, RIP_EINVAL, "synth_fill: amp33 statistics missing");
     RIP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t fsz = (size_t)cal->ny * cal->channelwidth;
     if (banding && !frames) {
-        float *made = (float *)rip_ws(ctx, 12, (size_t)ngrp * 34 * fsz * sizeof(float));
+        float *made = (float *)rip_ws(ctx, 12, (size_t)ngrp * (nch + 2) * fsz * sizeof(float));
         if (!made) return RIP_ENOMEM;
-        rc = rip_synth_noise_1f(ctx, cal->ny, cal->channelwidth, ngrp * 34, seed, 0x31660000u, made);
+        rc = rip_synth_noise_1f(ctx, cal->ny, cal->channelwidth, ngrp * (nch + 2), seed, 0x31660000u, made);
         if (rc) return rc;
         frames = made;
     }
@@ -357,6 +358,7 @@ extern "C" int rip_synth_fill(rip_ctx *ctx, const rip_synth_cal *cal, int ngrp, 
     a.nx = cal->nx;
     a.nb = cal->nb;
     a.cw = cal->channelwidth;
+    a.nch = nch;
     a.ngrp = ngrp;
     a.u_pink = (float)cal->u_pink;
     a.c_pink = (float)cal->c_pink;

@@ -79,7 +79,10 @@ class L1Synth:
         self.ny, self.nx = gain.shape
         self.nb = nb
         self.nya, self.nxa = self.ny - 2 * nb, self.nx - 2 * nb
-        self.cw = channelwidth or self.nx // 32
+        # channels are pars.channelwidth columns wide wherever the frame allows it (the calibration chain's geometry: nx / 128
+        # channels); otherwise the reference's 32 channels
+        self.cw = channelwidth or (pars.channelwidth if self.nx % pars.channelwidth == 0 else self.nx // 32)
+        self.nch = self.nx // self.cw
         self._keep = []
 
         def up(a, dt=None):

@@ -83,7 +83,10 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
     (8, ny, nx) f32 planes as a numpy array on rank 0, None on the other ranks.
 
     ``generator``: "host" = ``synth.make_ramp`` (numpy; minutes per full frame), "device" = ``synth_gpu.RampFactory`` (the same
-    recipe in torch on the GPU: about half a second per full frame, nothing crosses PCIe -- BASELINE config 5 at full size).
+    recipe in torch on the GPU: about half a second per full frame, nothing crosses PCIe -- BASELINE config 5 at full size),
+    "hip" = the reference's own synthesis path on the device (``from_sim.sim_to_isim.L1Synth``: Poisson totals, binomial shares
+    per read, ``make_l1_fullcal``, ``fill_in_refdata_and_1f`` as HIP kernels; dq-init and saturation flagging by the
+    calibration call itself).
     ``timings``: optional dict that receives the seconds spent generating, calibrating + stacking, and reducing."""
     import time
 
@@ -106,9 +109,31 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
 
         factory = synth_gpu.RampFactory(cal, rp, device=calibrator.ctx.device)
         rate_t = torch.from_numpy(np.ascontiguousarray(rate)).to(device)
+    hip_synth, counts_mean, t_pdq_hip = None, None, None
+    if generator == "hip":
+        from ..from_sim import sim_to_isim
+
+        hip_synth = sim_to_isim.L1Synth(cal, rp, synth.FRAME_TIME, ctx=calibrator.ctx, nb=nb)
+        act = (slice(nb, ny - nb), slice(nb, nx - nb))
+        per_s = (np.asarray(rate, dtype=np.float64)[act] + cal["dark"]["dark_slope"][act]) * cal["gain"]["data"][act]   # e/s
+        counts_mean = torch.from_numpy(np.clip(per_s * hip_synth.t_reads[-1], 0.0, None).astype(np.float32)).to(device)
+        t_pdq_hip = torch.from_numpy(np.array(cal["mask"]["dq"], dtype=np.uint32).view(np.int32)).to(device)
+    elif generator not in ("host", "device"):
+        raise ValueError(f"generator {generator!r}: host, device or hip")
     t_gen = t_cal = 0.0
     for k, sd in enumerate(seeds):
         t0 = time.perf_counter()
+        if hip_synth is not None:
+            cube, a33 = hip_synth.make(counts_mean, sd, poisson=True)
+            calibrator.synchronize()
+            t1 = time.perf_counter()
+            calibrator.calibrate_device(slot, pid, len(rp), cube.data_ptr(), True, a33.data_ptr(), None, t_pdq_hip.data_ptr(),
+                                        slope.data_ptr(), er.data_ptr(), ep.data_ptr(), pdq.data_ptr(), flag_saturation=True)
+            st.push(k, cube, slope, er, ep, pdq)
+            calibrator.synchronize()
+            t_gen += t1 - t0
+            t_cal += time.perf_counter() - t1
+            continue
         if factory is not None:
             cube, a33, t_gdq, t_pdq = factory.make(sd, rate_t, poisson=True)
         else:

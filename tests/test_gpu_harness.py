@@ -222,3 +222,26 @@ def test_two_ranks_give_the_single_process_planes(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o[-2000:]
     assert_same_bits(np.load(out), single, "two ranks vs one")
+
+
+def test_harness_with_the_reference_synthesis_path_on_the_device():
+    """generator="hip": every realisation made by the reference's own synthesis steps as HIP kernels (Poisson totals, binomial
+    shares per read, make_l1_fullcal, fill_in_refdata_and_1f with 1/f noise and reference output), flagged for saturation and
+    calibrated by the chain: the scatter over realisations equals the pipeline's error estimate and the mean is unbiased."""
+    rp = synth.READ_PATTERN_8
+    ny, nx, nseeds = 72, 256, 32
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=13)
+    cb = pipeline.Calibrator(ctx=gpu_context())
+    cb.load_caldir(0, cal)
+    tm = {}
+    out = mr.run(cb, 0, cal, nseeds=nseeds, seed0=100, read_pattern=rp, device=DEV, reference_alias=False, generator="hip", timings=tm)
+    assert out.shape == (8, ny, nx) and tm["realisations_on_this_rank"] == nseeds
+    ok = out[3] >= nseeds - 2
+    assert ok[4:-4, 4:-4].mean() > 0.5
+    ratio = out[5][ok] / np.maximum(out[7][ok], 1e-6)   # std over realisations / median of the pipeline's error
+    assert 0.85 < np.median(ratio) < 1.15, np.median(ratio)
+    z = out[6][ok] / (out[5][ok] / np.sqrt(out[3][ok]) + 1e-6)     # (mean - ideal) in standard errors
+    assert abs(np.median(z)) < 0.5 and np.median(np.abs(z)) < 1.5, (np.median(z), np.median(np.abs(z)))
+    # a second run gives the same planes: the device generators are keyed by the seeds
+    again = mr.run(cb, 0, cal, nseeds=nseeds, seed0=100, read_pattern=rp, device=DEV, reference_alias=False, generator="hip")
+    assert np.array_equal(out, again)
