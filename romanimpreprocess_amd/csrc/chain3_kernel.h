@@ -38,7 +38,12 @@
 #ifndef C3_NBATCH   // groups the forward operator evaluates in lockstep (2 or 4)
 #define C3_NBATCH 4
 #endif
+#ifndef C3_OUTW   // columns a wave emits; -DC3_OUTW=64 -DC3_HALO=0 is a TIMING experiment (aligned windows, wrong strip edges)
 #define C3_OUTW 60
+#endif
+#ifndef C3_HALO
+#define C3_HALO 2
+#endif
 #define C3_THREADS (64 * C3_NW)
 // One s_barrier per row step keeps the waves of a workgroup within a row of each other: neighbouring strips share cache lines
 // (60-column pitch against 128-byte lines), and the second request for a line then finds it in L2 (measured: FETCH_SIZE
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     const int R0 = ((int)blockIdx.x / nwgx) * rows_per;
     const int R1 = min(ny, R0 + rows_per);
     const int strip = wgx * C3_NW + wv;
-    const int ch0 = max(wgx * C3_NW * C3_OUTW - 2, 0) / RIP_CW;
+    const int ch0 = max(wgx * C3_NW * C3_OUTW - C3_HALO, 0) / RIP_CW;
     for (int i = tid; i < NCH * G * 2; i += C3_THREADS) {
         const int ch = i / (G * 2), g = (i / 2) % G, w = i & 1;
         LN[i] = (ch0 + ch < nch) ? a.lines[(g * nch + ch0 + ch) * 2 + w] : 0.0;
@@ -223,13 +228,13 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     __syncthreads();
     if ((int)blockIdx.x >= nwgx * nranges || R0 >= ny || strip >= nstrips) return;
 
-    const int c = strip * C3_OUTW - 2 + lane;
+    const int c = strip * C3_OUTW - C3_HALO + lane;
     const bool col_ok = (c >= 0 && c < nx);
     const bool col_act = (c >= ax0 && c < ax1);
     const int cc = col_ok ? c : (c < 0 ? 0 : nx - 1);
     const int chr = cc / RIP_CW - ch0;
     const bool emit_lane = lane >= 2 && lane < 62 && col_ok;
-    const bool edge_wave = (strip * C3_OUTW - 2 < 0) || (strip * C3_OUTW + 62 > nx);  // wave-uniform: some lane is off the frame
+    const bool edge_wave = (strip * C3_OUTW - C3_HALO < 0) || (strip * C3_OUTW - C3_HALO + 64 > nx);  // wave-uniform: some lane is off the frame
     const unsigned cc4 = (unsigned)cc * 4u, cc2 = (unsigned)cc * 2u, cc1 = (unsigned)cc;
     const unsigned ccK = K64 ? cc4 * 2u : cc4;
     unsigned colmask = 0;  // bit k: the source column of term k is in the active box (and so is c)
