@@ -91,6 +91,22 @@ template <int AUX = C2_NT>
 __device__ __forceinline__ uint32_t c2_ld_u8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, AUX);
 }
+// XCD-aware block order (the dispatcher deals consecutive block ids round the 8 XCDs, each with its own L2): block ids that
+// share an XCD get CONSECUTIVE cells of the (row range, strip) grid, so that neighbouring strips -- whose 256-column windows at
+// a 252-column pitch share cache lines and halo columns -- find each other's lines in their L2.  Bijective for any grid size;
+// a speed choice only (-DC2_XCD=0: identity).
+#ifndef C2_XCD
+#define C2_XCD 1
+#endif
+__device__ __forceinline__ int c2_xcd_block(int b, int n) {
+#if C2_XCD
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+#else
+    return b;
+#endif
+}
+
 struct C2Keep {   // first of two reads: keep the line
     static constexpr int value = 0;
 };
@@ -171,10 +187,11 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
     const int nstrips = (nx + C2_OUTW - 1) / C2_OUTW;
     const int nranges = gridDim.x / nstrips;
     const int rows_per = (ny + nranges - 1) / nranges;
-    const int strip = (int)blockIdx.x % nstrips;
-    const int R0 = ((int)blockIdx.x / nstrips) * rows_per;
+    const int bid = c2_xcd_block((int)blockIdx.x, (int)gridDim.x);
+    const int strip = bid % nstrips;
+    const int R0 = (bid / nstrips) * rows_per;
     const int R1 = min(ny, R0 + rows_per);
-    if ((int)blockIdx.x >= nstrips * nranges || R0 >= ny) return;
+    if (bid >= nstrips * nranges || R0 >= ny) return;
     const int c = strip * C2_OUTW - 2 + col;
     const bool col_ok = (c >= 0 && c < nx);
     const bool col_act = (c >= ax0 && c < ax1);

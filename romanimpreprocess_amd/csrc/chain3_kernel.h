@@ -203,8 +203,9 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     const int nwgx = (nstrips + C3_NW - 1) / C3_NW;
     const int nranges = gridDim.x / nwgx;
     const int rows_per = (ny + nranges - 1) / nranges;
-    const int wgx = (int)blockIdx.x % nwgx;
-    const int R0 = ((int)blockIdx.x / nwgx) * rows_per;
+    const int bid = c2_xcd_block((int)blockIdx.x, (int)gridDim.x);   // neighbouring workgroups of a row range on one XCD
+    const int wgx = bid % nwgx;
+    const int R0 = (bid / nwgx) * rows_per;
     const int R1 = min(ny, R0 + rows_per);
     const int strip = wgx * C3_NW + wv;
     const int ch0 = max(wgx * C3_NW * C3_OUTW - C3_HALO, 0) / RIP_CW;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
         reinterpret_cast<uint32_t *>(FT)[i] = v;
     }
     __syncthreads();
-    if ((int)blockIdx.x >= nwgx * nranges || R0 >= ny || strip >= nstrips) return;
+    if (bid >= nwgx * nranges || R0 >= ny || strip >= nstrips) return;
 
     const int c = strip * C3_OUTW - C3_HALO + lane;
     const bool col_ok = (c >= 0 && c < nx);
