@@ -140,8 +140,8 @@ void rip_ctx_destroy(rip_ctx *ctx) {
             if (p->dev) (void)hipFree(p->dev);
             delete p;
         }
-    for (int i = 0; i < 10; ++i)
-        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    for (void *p : ctx->ws)   // every workspace slot, the Level-1 synthesis ones included
+        if (p) (void)hipFree(p);
     for (void *p : ctx->batch_buf)
         if (p) (void)hipFree(p);
     if (ctx->stream3) {
