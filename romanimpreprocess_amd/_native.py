@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libromanhip.so")
+LIB_PATH = os.environ.get("ROMANHIP_LIB") or os.path.join(_HERE, "libromanhip.so")   # the env var: A/B timing of library variants
 
 RIP_MAX_GROUPS = 64
 RIP_F32, RIP_F64, RIP_U16 = 0, 1, 2

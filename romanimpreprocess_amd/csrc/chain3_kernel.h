@@ -29,7 +29,9 @@
 
 #include "chain2_kernel.h"
 
-#ifndef C3_NW
+#ifndef C3_NW   // waves (adjacent strips) per workgroup.  Same-box A/B on the bench's non-periodic frame (f64 ipc4d): 4 waves 1.41 ms,
+                // 2 waves 1.46-1.66 ms (on a tiled, homogeneous frame 2 waves are 3-4 % faster: 69 strips pack better; the real
+                // frame's clustered saturated / jump pixels want the larger group), 3 waves 1.58 ms
 #define C3_NW 4
 #endif
 #ifndef C3_WPS   // waves per SIMD the 8-group f32 instantiation is compiled for (register budget 512 / C3_WPS)
