@@ -15,9 +15,10 @@ and handed to the kernel).  Layers are therefore statistically, not bit-wise, co
     accumulation into the resultants and the ramp-fit weights of every pixel's end slice in one pass; exact given the
     deviates).
   * the correlated part of a read-noise layer (``sim_to_isim.fill_in_refdata_and_1f`` :306-402: fresh reference pixels,
-    reference output, 1/f noise): the 1/f frames -- 34 Fourier transforms of 2^20 points per group -- are made by
-    ``rip_stage_noise_1f`` (hipFFT, device deviates); the white deviates and the assembly follow the reference's lines in
-    numpy on the host (``NOISE: {CORRELATED: false}`` switches the step off).
+    reference output, 1/f noise): ``rip_synth_fill`` on the device (``from_sim.sim_to_isim.L1Synth.fill``: pinned by goldens made by
+    executing the reference's function); the 1/f frames -- 34 Fourier transforms of 2^20 points per group -- come from hipFFT
+    with device deviates, the white deviates from the device or, with a host generator, from it in the reference's order
+    (``NOISE: {CORRELATED: false}`` switches the step off).
 The pseudo-Poisson layers (``O``): moment ratios on the host (``GalPoisson/find_tilnus.py``), Pearson-family deviates on the
     device (``rip_stage_pearson``, ``GalPoisson/draw_with_tilnus.py``; parameters pinned by goldens, deviates from the device's
     counter-based generator).
@@ -77,52 +78,6 @@ def noise_1f_frames(nframes, rows=pars.nside, width=pars.channelwidth, normals=N
     return out
 
 
-def fill_in_refdata_and_1f(im, caldir, rng, tij, fill_in_banding=True, amp33=None, seed=0, stream=0, ctx=None):
-    """Reference pixels, reference output and correlated noise of a Level-1 cube, in place (``sim_to_isim.py:306-402``):
-    the border becomes dark + read noise + reset noise, every science channel and the reference output receive 1/f noise
-    (one common frame per group plus one per channel), the cube is rounded back to its integer type.  ``rng``: a
-    ``numpy.random.Generator`` for the white deviates; the 1/f frames -- 34 Fourier transforms of 2^20 points per group,
-    the expensive part -- are made on the GPU with device deviates (``seed``, ``stream``)."""
-    ngrp, ny, nx = np.shape(im)
-    nborder = pars.nborder
-    cw = pars.channelwidth
-    noise = rng.standard_normal((ngrp + 1, ny, nx), dtype=np.float32)
-    with calio.open_tree(caldir["read"]) as f:
-        noise[:-1, :, :] *= np.asarray(f["roman"]["data"])[None, :, :]
-        noise[-1, :, :] *= np.asarray(f["roman"]["resetnoise"])
-        u_pink = float(f["roman"]["anc"]["U_PINK"])
-        c_pink = float(f["roman"]["anc"]["C_PINK"])
-        amp33info = {"valid": False}
-        if amp33 is not None and "amp33" in f["roman"]:
-            amp33info = calio._materialise(f["roman"]["amp33"])
-    for j in range(len(tij)):
-        noise[j, :, :] /= len(tij[j]) ** 0.5
-    noise[:-1, :, :] += noise[-1, :, :][None, :, :]
-    with calio.open_tree(caldir["dark"]) as f:
-        dark = np.asarray(f["roman"]["data"])
-        de = dark.shape[0] - ngrp
-        noise[:-1, :, :] += dark[de:, :, :]
-    act = (slice(None), slice(nborder, ny - nborder), slice(nborder, nx - nborder))
-    noise[:-1][act] = im[act].astype(noise.dtype)
-    if fill_in_banding:
-        nch = nx // cw
-        per_group = 1 + nch + (1 if amp33info.get("valid") else 0)
-        for j in range(len(tij)):
-            frames = noise_1f_frames(per_group, rows=ny, width=cw, seed=seed, stream=stream + j * per_group, ctx=ctx)
-            common_noise = frames[0] * c_pink
-            for ch in range(nch):
-                pinknoise = frames[1 + ch] * u_pink + common_noise
-                if ch % 2 == 1:
-                    pinknoise = pinknoise[:, ::-1]
-                noise[j, :, cw * ch:cw * (ch + 1)] += (pinknoise / len(tij[j]) ** 0.5).astype(noise.dtype)
-            if amp33info.get("valid"):
-                whitenoise = rng.standard_normal((ny, cw), dtype=np.float32)
-                whitenoise *= amp33info["std"]
-                pinknoise = amp33info["RU_PINK"] * frames[1 + nch] + amp33info["M_PINK"] * common_noise
-                amp33[j, :, :] = (amp33info["med"] + (whitenoise + pinknoise) / len(tij[j]) ** 0.5).astype(amp33.dtype)
-    im[:, :, :] = np.clip(np.round(noise[:-1, :, :]), 0, 2**16 - 1).astype(im.dtype)
-
-
 def ramp_weight_vectors(processinfo, ngrp):
     """The weights the ramp fit applied to a pixel as a function of its end slice (gen_noise_image.py:236-252): the stored
     optimal weights for a full ramp, the two-point weights for one truncated at ``iend``.  Returns (w (ngrp,ngrp) f32,
@@ -176,9 +131,30 @@ def poisson_resample(diff, skylevel, gain, frame_time, read_pattern, weights, ha
     return diff
 
 
+class _Files:
+    """The files a layer list keeps coming back to (read, dark, gain, the L2 output), each read once per call."""
+
+    def __init__(self):
+        self.trees = {}
+
+    def tree(self, src):
+        if isinstance(src, dict):
+            return src if "roman" in src else {"roman": src}
+        key = str(src)
+        if key not in self.trees:
+            with calio.open_tree(src) as f:
+                self.trees[key] = calio._materialise(f if isinstance(f, dict) else dict(f))
+        return self.trees[key]
+
+    def roman(self, src):
+        return self.tree(src)["roman"]
+
+
 def make_noise_cube(config, rng=None):
     """The noise realisations listed in ``config["NOISE"]["LAYER"]``: array (N_noise, ny_active, nx_active) f32."""
     layers = config["NOISE"]["LAYER"]
+    files = _Files()
+    synth_dev = None   # from_sim.sim_to_isim.L1Synth of this CALDIR set: reference pixels and correlated noise on the device
     host_rng = rng if isinstance(rng, np.random.Generator) else None
     seed = config["NOISE"].get("SEED", 0) if (rng is None or host_rng is not None) else int(rng)
     nb = pars.nborder
@@ -189,8 +165,7 @@ def make_noise_cube(config, rng=None):
     in_memory = bool(config["NOISE"].get("IN_MEMORY", True))
     with calio.open_tree(config["IN"]) as f_in:
         base_tree = calio._materialise(f_in if isinstance(f_in, dict) else dict(f_in))
-    with calio.open_tree(config["OUT"]) as f_orig:
-        orig_data = np.asarray(f_orig["roman"]["data"])
+    orig_data = np.asarray(files.roman(config["OUT"])["data"])
     dark_ref = None   # L2 "data" of the dark cube itself
     for i_noise, cmd in enumerate(layers):
         mytree = {k: v for k, v in base_tree.items()}
@@ -205,12 +180,11 @@ def make_noise_cube(config, rng=None):
             noiseflags = _get_subscript(cmd, "R")
             ref_data = orig_data
             if "a" not in noiseflags:  # start from the dark instead of the data
-                with calio.open_tree(config["CALDIR"]["dark"]) as fb:
-                    dark = np.asarray(fb["roman"]["data"])
-                    de = dark.shape[0] - np.shape(mytree["roman"]["data"])[0]
-                    if de not in [0, 1]:
-                        raise ValueError("Dark date cube has the wrong shape.")
-                    mytree["roman"]["data"] = dark.astype(mytree["roman"]["data"].dtype)[de:, :, :]
+                dark = np.asarray(files.roman(config["CALDIR"]["dark"])["data"])
+                de = dark.shape[0] - np.shape(mytree["roman"]["data"])[0]
+                if de not in [0, 1]:
+                    raise ValueError("Dark date cube has the wrong shape.")
+                mytree["roman"]["data"] = dark.astype(mytree["roman"]["data"].dtype)[de:, :, :]
                 if in_memory:
                     if dark_ref is None:
                         dark_ref = np.asarray(calibrateimage(dict(config, IN=mytree, OUT=None))["roman"]["data"])
@@ -223,8 +197,7 @@ def make_noise_cube(config, rng=None):
                     calibrateimage(config3)
                     with calio.open_tree(config3["OUT"]) as f_ref:
                         ref_data = np.asarray(f_ref["roman"]["data"])
-            with calio.open_tree(config["CALDIR"]["read"]) as fr:
-                read = np.asarray(fr["roman"]["data"], dtype=np.float32)
+            read = np.asarray(files.roman(config["CALDIR"]["read"])["data"], dtype=np.float32)
             data = np.ascontiguousarray(mytree["roman"]["data"])
             normals = None
             if host_rng is not None:  # one draw per group, in the reference's order
@@ -232,18 +205,32 @@ def make_noise_cube(config, rng=None):
                 normals = np.stack([host_rng.standard_normal(na, dtype=np.float32) for _ in range(data.shape[0])])
             mytree["roman"]["data"] = inject_read_noise(data, read, read_pattern, nb=nb, normals=normals, seed=seed,
                                                         layer=i_noise)
-            # correlated noise: fresh reference pixels, reference output and 1/f noise (sim_to_isim.fill_in_refdata_and_1f)
+            # correlated noise: fresh reference pixels, reference output and 1/f noise (sim_to_isim.fill_in_refdata_and_1f), on the
+            # device (from_sim.sim_to_isim.L1Synth.fill: the white deviates of a host generator are handed in in the reference's
+            # order, otherwise everything is drawn there)
             if config["NOISE"].get("CORRELATED", True):
+                import torch
+
+                from ..from_sim.sim_to_isim import L1Synth
+
+                if synth_dev is None:
+                    cal_fill = {k: files.roman(config["CALDIR"][k]) for k in ("read", "gain", "dark")}
+                    synth_dev = L1Synth(cal_fill, read_pattern, 1.0, nb=nb)
                 cube = np.ascontiguousarray(mytree["roman"]["data"])
                 a33 = mytree["roman"].get("amp33")
-                if a33 is not None:
-                    a33 = np.ascontiguousarray(a33)
-                fill_in_refdata_and_1f(cube, config["CALDIR"], host_rng if host_rng is not None else
-                                       np.random.default_rng([int(seed) & 0xFFFFFFFF, i_noise]), read_pattern, amp33=a33,
-                                       seed=seed, stream=100000 * (i_noise + 1))
-                mytree["roman"]["data"] = cube
-                if a33 is not None:
-                    mytree["roman"]["amp33"] = a33
+                t_cube = torch.from_numpy(cube.view(np.int16)).to(synth_dev.dev)
+                t_a33 = None if a33 is None else torch.from_numpy(np.ascontiguousarray(a33).view(np.int16)).to(synth_dev.dev)
+                normals = white33 = None
+                if host_rng is not None:
+                    normals = host_rng.standard_normal((cube.shape[0] + 1,) + cube.shape[1:], dtype=np.float32)
+                    if t_a33 is not None:
+                        white33 = host_rng.standard_normal(tuple(t_a33.shape), dtype=np.float32)
+                synth_dev.fill(t_cube, t_a33, (int(seed) + 7919 * (i_noise + 1)) & (2**64 - 1), banding=True, normals=normals,
+                               white33=white33)
+                synth_dev.ctx.synchronize()
+                mytree["roman"]["data"] = t_cube.cpu().numpy().view(np.uint16)
+                if t_a33 is not None:
+                    mytree["roman"]["amp33"] = t_a33.cpu().numpy().view(np.uint16)
             if in_memory:
                 diff = np.asarray(calibrateimage(dict(config, IN=mytree, OUT=None))["roman"]["data"]) - ref_data
             else:
@@ -263,12 +250,11 @@ def make_noise_cube(config, rng=None):
         if "O" in cmd:
             # pseudo-Poisson layer (gen_noise_image.py:173-240): per end slice, the moment ratios of the ramp-fit slope under
             # Poisson noise (host), then one Pearson-family deviate per pixel (device) scaled by the pixel's gain * rate
-            with calio.open_tree(config["CALDIR"]["gain"]) as g_:
-                gain = np.clip(np.asarray(g_["roman"]["data"]), 1e-4, 1e4)
-            with calio.open_tree(config["OUT"]) as f_L2:
-                withsky = np.asarray(f_L2["roman"]["data_withsky"])
-                pinfo = calio._materialise(f_L2["processinfo"])
-                t_fr = f_L2["roman"]["meta"]["exposure"]["frame_time"]
+            gain = np.clip(np.asarray(files.roman(config["CALDIR"]["gain"])["data"]), 1e-4, 1e4)
+            f_L2 = files.tree(config["OUT"])
+            withsky = np.asarray(f_L2["roman"]["data_withsky"])
+            pinfo = f_L2["processinfo"]
+            t_fr = f_L2["roman"]["meta"]["exposure"]["frame_time"]
             d = (gain.shape[-1] - withsky.shape[-1]) // 2
             if d > 0:
                 gain = gain[d:-d, d:-d]
@@ -296,18 +282,17 @@ def make_noise_cube(config, rng=None):
             diff[:, :] += noise_array / gain
         if "P" in cmd:
             noiseflags = _get_subscript(cmd, "P")
-            with calio.open_tree(config["OUT"]) as f_L2:
-                withsky = np.asarray(f_L2["roman"]["data_withsky"], dtype=np.float32)
-                pinfo = calio._materialise(f_L2["processinfo"])
-                t_fr = mytree["roman"]["meta"]["exposure"]["frame_time"]
+            f_L2 = files.tree(config["OUT"])
+            withsky = np.asarray(f_L2["roman"]["data_withsky"], dtype=np.float32)
+            pinfo = f_L2["processinfo"]
+            t_fr = mytree["roman"]["meta"]["exposure"]["frame_time"]
             if "b" in noiseflags:  # background only: the low-order sky model
                 sky_order = int("0" + _get_subscript(noiseflags.upper(), "B"))
                 skylevel = sky.medfit(withsky, order=sky_order)[1]
             else:
                 skylevel = withsky.copy()
             if "r" in noiseflags:
-                with calio.open_tree(config["CALDIR"]["gain"]) as g_:
-                    gain = np.clip(np.asarray(g_["roman"]["data"]), 1e-4, 1e4)
+                gain = np.clip(np.asarray(files.roman(config["CALDIR"]["gain"])["data"]), 1e-4, 1e4)
                 d = (gain.shape[-1] - skylevel.shape[-1]) // 2
                 if d > 0:
                     gain = gain[d:-d, d:-d]
@@ -333,8 +318,9 @@ def generate_all_noise(config):
     noiseimage = make_noise_cube(config, None)
     print(np.shape(noiseimage))
     print("percentiles:")
-    for q in [5, 25, 50, 75, 95]:
-        print(q, np.percentile(noiseimage, q, axis=(1, 2)))
+    per_layer = [sky.nanpercentiles(layer, [5.0, 25.0, 50.0, 75.0, 95.0]) for layer in noiseimage]   # selection on the device
+    for i, q in enumerate([5, 25, 50, 75, 95]):
+        print(q, np.array([p[i] for p in per_layer]))
     if "NOISE_PRECISION" in config:
         if config["NOISE_PRECISION"] == 16:
             noiseimage = noiseimage.astype(np.float16)

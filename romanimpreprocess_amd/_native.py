@@ -145,6 +145,13 @@ def load_library():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C romanimpreprocess_amd/csrc`).  romanimpreprocess_amd has no CPU fallback."
         )
+    # PyTorch (used by the device-resident mirrors for device memory) ships its own HIP runtime under the same soname: whichever
+    # of the two is loaded first serves both, and only PyTorch's own copy leaves PyTorch with its devices.  So it goes first,
+    # whenever it is installed; without it the library runs on the system's runtime alone.
+    try:
+        import torch  # noqa: F401, PLC0415
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

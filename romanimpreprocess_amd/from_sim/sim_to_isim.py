@@ -86,14 +86,16 @@ class L1Synth:
         self._keep = []
 
         def up(a, dt=None):
-            t = torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.dev)
+            a = np.ascontiguousarray(a, dtype=dt)
+            if not a.flags.writeable:   # arrays served from a file's bytes: torch wants to own writable memory
+                a = a.copy()
+            t = torch.from_numpy(a).to(self.dev)
             self._keep.append(t)
             return t.data_ptr()
 
         d = _native.SynthCal()
         d.ny, d.nx, d.nb, d.channelwidth = self.ny, self.nx, nb, self.cw
-        lin = cal["linearitylegendre"]
-        d.nplanes = lin["data"].shape[0]
+        lin = cal.get("linearitylegendre")   # only the resultants need it; reference pixels / correlated noise do not
         d.gain, d.gain_dtype = up(gain), _native.dtype_code(gain)
         rd = cal["read"]
         d.read_noise, d.resetnoise = up(rd["data"], np.float32), up(rd["resetnoise"], np.float32)
@@ -101,8 +103,11 @@ class L1Synth:
         d.dark_slope = up(dark["dark_slope"], np.float32)
         dd = np.asarray(dark["data"])
         d.dark = up(dd[dd.shape[0] - self.ngrp:], np.float32)
-        d.lin_coefs, d.smin, d.smax = up(lin["data"], np.float32), up(lin["Smin"], np.float32), up(lin["Smax"], np.float32)
-        self.lin_dq = np.array(lin["dq"], dtype=np.uint32)
+        self.lin_dq = None
+        if lin is not None:
+            d.nplanes = lin["data"].shape[0]
+            d.lin_coefs, d.smin, d.smax = up(lin["data"], np.float32), up(lin["Smin"], np.float32), up(lin["Smax"], np.float32)
+            self.lin_dq = np.array(lin["dq"], dtype=np.uint32)
         if cal.get("ipc4d") is not None:
             k = np.ascontiguousarray(cal["ipc4d"]["data"])
             if k.dtype not in (np.float32, np.float64):
@@ -153,6 +158,8 @@ class L1Synth:
                    want_start=False):
         """dict of device tensors: "cube" (ngrp, ny, nx) int16 holding the u16 bits, "resultants" (ngrp, nya, nxa) f32, "start_e"."""
         torch = self.torch
+        if self.lin_dq is None:
+            raise KeyError("linearitylegendre")   # built for the reference-pixel / correlated-noise step only
         nr, nd = self._t(normals_reset, np.float32), self._t(normals_read, np.float32)
         out = {}
         if want_resultants:
