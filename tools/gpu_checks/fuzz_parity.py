@@ -43,7 +43,7 @@ def same(a, b, zero_sign_ok=False):
     return not bad.any()
 
 
-fails, forms = 0, {0: 0, 1: 0, 2: 0}
+fails, forms = 0, {0: 0, 1: 0, 2: 0, 3: 0}
 t0 = time.time()
 for case in range(ncases):
     rp = random_pattern()
@@ -69,6 +69,7 @@ for case in range(ncases):
         lines[g] = ref["refpix_diag"][g]["channels"][:nx // 128, 2:4]
     ctx.set_option("fused", int(rng.random() < 0.8))
     ctx.set_option("chain2", int(rng.random() < 0.8))
+    ctx.set_option("chain3", int(rng.integers(0, 3)))   # 0 only where required, 1 wherever instantiated, 2 the default rule
     cb.load_caldir(1, cal)
     got = cb.calibrate(1, ramp, exclude_first=excl, jump_pars=jump, want_cube=True, channel_lines=lines)
     forms[ctx.last_chain_form()] += 1
@@ -82,5 +83,6 @@ for case in range(ncases):
         print(f"{case + 1} cases, {fails} mismatches, forms {forms}, {time.time() - t0:.0f} s", flush=True)
 ctx.set_option("fused", 1)
 ctx.set_option("chain2", 1)
-print(f"done: {ncases} cases, {fails} mismatches; kernel forms used (0 stage, 1 general fused, 2 specialised): {forms}")
+ctx.set_option("chain3", 2)
+print(f"done: {ncases} cases, {fails} mismatches; kernel forms used (0 stage, 1 general fused, 2 wave-specialised, 3 wave-private): {forms}")
 sys.exit(1 if fails else 0)
