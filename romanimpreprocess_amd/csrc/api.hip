@@ -140,6 +140,7 @@ void rip_ctx_destroy(rip_ctx *ctx) {
             if (p->dev) (void)hipFree(p->dev);
             delete p;
         }
+    rip_pink_release(ctx);
     for (void *p : ctx->ws)   // every workspace slot, the Level-1 synthesis ones included
         if (p) (void)hipFree(p);
     for (void *p : ctx->batch_buf)

@@ -88,22 +88,18 @@ __global__ __launch_bounds__(256) void pink_out_kernel(const hipfftDoubleComplex
     out[(size_t)f * half + k] = (float)(z[(size_t)f * L + k].x / sqrt(2.0) - mean);
 }
 
-// out: host memory (frames copied back chunk by chunk, call synchronous) or, out_dev, device memory (asynchronous apart from the
-// release of the transform buffers at the end)
+// out: host memory (frames copied back chunk by chunk, call synchronous) or, out_dev, device memory (asynchronous: the transform
+// plan and buffers are kept with the context between calls of the same frame length and batch)
 int noise_1f_impl(rip_ctx *ctx, int rows, int width, int nframes, const double *normals, uint64_t seed, uint32_t stream_id, float *out,
                   bool out_dev) {
     if (rows < 1 || width < 1 || nframes < 1 || !out) return rip_fail(ctx, RIP_EINVAL, "noise_1f: bad arguments");
     RIP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t L = (size_t)2 * rows * width, half = L / 2;
-    hipfftDoubleComplex *z = nullptr;
-    double *d_n = nullptr, *d_s = nullptr;
+    double *d_n = nullptr;
     float *d_o = nullptr;
-    hipfftHandle plan = 0;
-    bool have_plan = false;
     int rc = RIP_OK;
-    auto done = [&]() {
-        if (have_plan) (void)hipfftDestroy(plan);
-        for (void *p : {(void *)z, (void *)d_n, (void *)d_s, (void *)d_o})
+    auto done = [&]() {   // per-call buffers; the plan and the transform buffers stay with the context
+        for (void *p : {(void *)d_n, (void *)d_o})
             if (p) (void)hipFree(p);
     };
 #define PK_HIP(call)                                                                   \
@@ -117,17 +113,28 @@ int noise_1f_impl(rip_ctx *ctx, int rows, int width, int nframes, const double *
     } while (0)
     // frames are transformed in chunks so that the complex buffer stays below ~1 GB
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nframes, ((size_t)1 << 30) / (L * sizeof(hipfftDoubleComplex))));
-    PK_HIP(hipMalloc((void **)&z, (size_t)chunk * L * sizeof(hipfftDoubleComplex)));
-    PK_HIP(hipMalloc((void **)&d_s, (size_t)chunk * 256 * sizeof(double)));
+    if (ctx->pink_L != L || ctx->pink_chunk != chunk) {   // another frame length or batch: new plan and buffers
+        PK_HIP(hipStreamSynchronize(ctx->stream));
+        rip_pink_release(ctx);
+        PK_HIP(hipMalloc(&ctx->pink_z, (size_t)chunk * L * sizeof(hipfftDoubleComplex)));
+        PK_HIP(hipMalloc(&ctx->pink_s, (size_t)chunk * 256 * sizeof(double)));
+        int n1 = (int)L;
+        hipfftHandle made = 0;
+        if (hipfftPlanMany(&made, 1, &n1, nullptr, 1, n1, nullptr, 1, n1, HIPFFT_Z2Z, chunk) != HIPFFT_SUCCESS) {
+            rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftPlanMany(%zu points x %d) failed", L, chunk);
+            rip_pink_release(ctx);
+            done();
+            return rc;
+        }
+        ctx->pink_plan = (void *)made;
+        ctx->pink_L = L;
+        ctx->pink_chunk = chunk;
+    }
+    hipfftDoubleComplex *z = (hipfftDoubleComplex *)ctx->pink_z;
+    double *d_s = (double *)ctx->pink_s;
+    hipfftHandle plan = (hipfftHandle)ctx->pink_plan;
     if (!out_dev) PK_HIP(hipMalloc((void **)&d_o, (size_t)chunk * half * sizeof(float)));
     if (normals) PK_HIP(hipMalloc((void **)&d_n, (size_t)chunk * 2 * L * sizeof(double)));
-    int n1 = (int)L;
-    if (hipfftPlanMany(&plan, 1, &n1, nullptr, 1, n1, nullptr, 1, n1, HIPFFT_Z2Z, chunk) != HIPFFT_SUCCESS) {
-        rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftPlanMany(%zu points x %d) failed", L, chunk);
-        done();
-        return rc;
-    }
-    have_plan = true;
     if (hipfftSetStream(plan, ctx->stream) != HIPFFT_SUCCESS) {
         rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftSetStream failed");
         done();
@@ -152,13 +159,21 @@ int noise_1f_impl(rip_ctx *ctx, int rows, int width, int nframes, const double *
         if (!out_dev) PK_HIP(hipMemcpyAsync(out + (size_t)f0 * half, d_o, (size_t)nf * half * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         if (!out_dev) PK_HIP(hipStreamSynchronize(ctx->stream));   // device output: the next chunk follows in stream order
     }
-    if (out_dev) PK_HIP(hipStreamSynchronize(ctx->stream));   // before the buffers go
 #undef PK_HIP
     done();
     return RIP_OK;
 }
 
 }   // namespace
+
+void rip_pink_release(rip_ctx *ctx) {
+    if (ctx->pink_plan) (void)hipfftDestroy((hipfftHandle)ctx->pink_plan);
+    if (ctx->pink_z) (void)hipFree(ctx->pink_z);
+    if (ctx->pink_s) (void)hipFree(ctx->pink_s);
+    ctx->pink_plan = ctx->pink_z = ctx->pink_s = nullptr;
+    ctx->pink_L = 0;
+    ctx->pink_chunk = 0;
+}
 
 extern "C" int rip_stage_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, const double *normals, uint64_t seed,
                                   uint32_t stream_id, float *out) {

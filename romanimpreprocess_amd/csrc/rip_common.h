@@ -141,11 +141,16 @@ struct rip_ctx {
     hipStream_t stream3 = nullptr;
     void *batch_buf[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t batch_bytes[4] = {0, 0, 0, 0};
+    // 1/f frames (pink.hip): transform plan and buffers of the last (length, batch) kept between calls
+    void *pink_plan = nullptr, *pink_z = nullptr, *pink_s = nullptr;
+    size_t pink_L = 0;
+    int pink_chunk = 0;
     int batch_completed = 0;  // of the last rip_calibrate_batch: ramps completed (all of them unless it returned an error)
 };
 
 // ---------------------------------------------------------------- host helpers
 int rip_fail(rip_ctx *ctx, int code, const char *fmt, ...);
+void rip_pink_release(rip_ctx *ctx);   // pink.hip: drops the cached transform plan and buffers
 void *rip_ws(rip_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error recorded)
 
 #define RIP_HIP(ctx, call)                                                                      \

@@ -94,7 +94,8 @@ __device__ inline int binomial(int n, double p, uint64_t seed, uint32_t a, uint3
         const double bb = 1.15 + 2.53 * sd, aa = -0.0873 + 0.0248 * bb + 0.01 * q, cc = nd * q + 0.5, vr = 0.92 - 4.2 / bb;
         const double alpha = (2.83 + 5.1 / bb) * sd, lr = log(q / (1.0 - q));
         const double m = floor((nd + 1.0) * q);
-        const double lpm = -lgamma(m + 1.0) - lgamma(nd - m + 1.0) + m * lr;   // log pmf(m) up to the common terms
+        double lpm = 0.0;        // log pmf(m) up to the common terms: only the ~14 % of attempts outside the squeeze need it
+        bool have_lpm = false;
         k = (int)m;
         for (uint32_t attempt = 0; attempt < 64; ++attempt) {
             uint32_t c[4] = {a, b, tag ^ (attempt << 24), 0x62747273u};
@@ -109,6 +110,10 @@ __device__ inline int binomial(int n, double p, uint64_t seed, uint32_t a, uint3
                 break;
             }
             v = log(v * alpha / (aa / (us * us) + bb));
+            if (!have_lpm) {
+                lpm = -lgamma(m + 1.0) - lgamma(nd - m + 1.0) + m * lr;
+                have_lpm = true;
+            }
             if (v <= -lgamma(kd + 1.0) - lgamma(nd - kd + 1.0) + kd * lr - lpm) {
                 k = (int)kd;
                 break;
