@@ -31,7 +31,7 @@ def counter(sub, name):
 fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
 dominant = max((k for k in fetch if "chain" in k), key=lambda k: sum(fetch[k]) / len(fetch[k]), default=None)
 out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) -- python3 bench.py "
-                  "--steps 5 --warmup 1 --no-cpu-baseline --no-extras",
+                  "--steps 20 --warmup 2 --clock-ramp-s 0 --no-cpu-baseline --no-extras",
        "kernel": dominant, "per_kernel": {}}
 for k in sorted(set(fetch) | set(write)):
     out["per_kernel"][k] = {"FETCH_SIZE_KB_mean": sum(fetch[k]) / max(len(fetch[k]), 1), "launches_FETCH_SIZE": len(fetch[k]),
