@@ -59,7 +59,9 @@ def caldir_arrays(caldir):
 
 
 class L1Synth:
-    """Calibration arrays of one CALDIR set resident on the device + the synthesis entry points on device tensors."""
+    """Calibration arrays of one CALDIR set resident on the device + the synthesis entry points on device tensors.
+    ``apportion`` / ``resultants`` / ``fill`` / ``extract_ref`` are asynchronous on the context's stream (not torch's): call
+    ``ctx.synchronize()`` before reading their results with torch or dropping their inputs; ``make`` does."""
 
     def __init__(self, cal, read_pattern, read_time, ctx=None, nb=pars.nborder, channelwidth=None):
         import torch
@@ -189,6 +191,7 @@ class L1Synth:
         cube = self.resultants(reads_e, seed)["cube"]
         amp33 = torch.zeros((self.ngrp, self.ny, self.cw), dtype=torch.int16, device=self.dev)
         self.fill(cube, amp33, seed, banding)
+        self.ctx.synchronize()   # the intermediate tensors (read electrons, deviates) may go once the kernels are done
         return cube, amp33
 
     def extract_ref(self, data, offset=0):
@@ -235,7 +238,7 @@ def fill_in_refdata_and_1f(im, caldir, rng, tij, fill_in_banding=True, amp33=Non
 
     cal = caldir_arrays(caldir)
     rp = [list(range(len(t))) for t in tij]   # only the number of reads per resultant enters
-    s = L1Synth(cal, rp, 1.0, ctx=ctx)
+    s = L1Synth(cal, rp, 1.0, ctx=ctx, channelwidth=None if amp33 is None else int(np.shape(amp33)[-1]))
     if im.dtype != np.uint16 or im.shape != (s.ngrp, s.ny, s.nx):
         raise ValueError(f"im must be uint16 of shape {(s.ngrp, s.ny, s.nx)}")
     cube = torch.from_numpy(np.ascontiguousarray(im).view(np.int16)).to(s.dev)

@@ -160,5 +160,12 @@ def test_reference_signatures_numpy_in_and_out(golden):
         sim_to_isim.make_l1_fullcal(g["counts"] + 0.5, rp, caldir, rng=1)
     with pytest.raises(ValueError, match="rng"):
         sim_to_isim.make_l1_fullcal(g["counts"], rp, caldir)
+    # fill_in_refdata_and_1f with the reference's signature: in place on numpy arrays, statistics of the border as in the model
+    im = g["im_before"].copy()
+    a33 = np.zeros(g["amp33_after"].shape, dtype=np.uint16)
+    tij = sim_to_isim.read_pattern_to_tij(rp, float(g["read_time"]))
+    sim_to_isim.fill_in_refdata_and_1f(im, caldir, np.random.default_rng(2), tij, fill_in_banding=True, amp33=a33)
+    assert np.all(im[:, :4] > 0) and abs(np.mean(a33.astype(np.float64) - cal["read"]["amp33"]["med"])) < 2.0
+    assert np.max(np.abs(im[:, 4:-4, 4:-4].astype(np.int32) - g["im_before"][:, 4:-4, 4:-4].astype(np.int32))) < 40
     frame = sim_to_isim.noise_1f_frame(7)
     assert frame.shape == (4096, 128) and frame.dtype == np.float32 and abs(frame.mean()) < 1e-3 and 1.5 < frame.std() < 5.0
