@@ -150,31 +150,34 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const uint16_t *__restric
 }
 
 __global__ __launch_bounds__(256) void sel_scan_kernel(SelState *__restrict__ st, uint32_t *__restrict__ ghist, int level) {
-    __shared__ uint32_t part[256];
-    __shared__ uint32_t found[2];
+    // bin holding the wanted rank: 8 bins per thread, wave prefix sums over the 256 partial sums, the owner walks its 8 bins
+    __shared__ uint32_t part[4];
     const int g = blockIdx.x, t = blockIdx.y;
     uint32_t *h = ghist + ((size_t)g * 2 + t) * SEL_BINS;
     const int per = SEL_BINS / 256;
-    uint32_t s = 0;
-    for (int k = 0; k < per; ++k) s += h[threadIdx.x * per + k];
-    part[threadIdx.x] = s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t rank = st[g].rank[t];
+    uint32_t own = 0;
+    for (int k = 0; k < per; ++k) own += h[tid * per + k];
+    uint32_t incl = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) part[w] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t rank = st[g].rank[t], cum = 0;
-        int c = 0;
-        while (c < 255 && cum + part[c] <= rank) cum += part[c++];
-        int b = c * per;
-        while (b < c * per + per - 1 && cum + h[b] <= rank) cum += h[b++];
-        found[0] = (uint32_t)b;
-        found[1] = rank - cum;
+    for (int k = 0; k < w; ++k) incl += part[k];
+    const uint32_t excl = incl - own;
+    if ((excl <= rank && rank < incl) || (tid == 255 && rank >= incl)) {
+        uint32_t cum = excl;
+        int b = tid * per;
+        while (b < tid * per + per - 1 && cum + h[b] <= rank) cum += h[b++];
+        st[g].prefix[t] |= (uint32_t)b << sel_shift(level);
+        st[g].rank[t] = rank - cum;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        st[g].prefix[t] |= found[0] << sel_shift(level);
-        st[g].rank[t] = found[1];
-    }
-    __syncthreads();
-    for (int k = 0; k < per; ++k) h[threadIdx.x * per + k] = 0;  // ready for the next level
+    for (int k = 0; k < per; ++k) h[tid * per + k] = 0;  // ready for the next level
 }
 
 __global__ void sel_init_kernel(SelState *st, uint32_t *ghist, int ngrp, uint32_t n) {
@@ -185,6 +188,61 @@ __global__ void sel_init_kernel(SelState *st, uint32_t *ghist, int ngrp, uint32_
         st[i].rank[0] = n / 2 - 1;
         st[i].rank[1] = n / 2;
     }
+}
+
+// np.median of vals[0..n) in LDS by a three-level radix selection inside one block (11 + 11 + 10 key bits, two LDS histograms:
+// one per middle element): 3 x (count, scan) instead of the 78 compare-exchange passes of a bitonic sort of 4096 values.
+// The median of an even count is the f32 mean of the two middle elements, as np.median forms it.  All threads of the block
+// call it; h: 2 x SEL_BINS words, tmp: 8 words of LDS.
+__device__ float block_median_select(const float *vals, int n, uint32_t (*h)[SEL_BINS], uint32_t *tmp) {
+    uint32_t prefix[2] = {0u, 0u};
+    uint32_t rank[2] = {(uint32_t)((n & 1) ? n / 2 : n / 2 - 1), (uint32_t)(n / 2)};
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (int lv = 0; lv < 3; ++lv) {
+        for (int i = t; i < 2 * SEL_BINS; i += blockDim.x) (&h[0][0])[i] = 0;
+        __syncthreads();
+        const int shift = sel_shift(lv), above = shift + sel_bits(lv);
+        const uint32_t mask = (1u << sel_bits(lv)) - 1u;
+        for (int i = t; i < n; i += blockDim.x) {
+            const uint32_t key = f2key(vals[i]);
+            const uint32_t bin = (key >> shift) & mask;
+            if (above >= 32 || ((key ^ prefix[0]) >> above) == 0) atomicAdd(&h[0][bin], 1u);
+            if (above >= 32 || ((key ^ prefix[1]) >> above) == 0) atomicAdd(&h[1][bin], 1u);
+        }
+        __syncthreads();
+        for (int q = 0; q < 2; ++q) {
+            // parallel scan of the 2048 bins: 8 per thread for the first 256 threads, wave prefix sums, then the owner walks its 8
+            const int per = SEL_BINS / 256;
+            uint32_t own = 0, incl = 0;
+            if (t < 256) {
+                for (int k = 0; k < per; ++k) own += h[q][t * per + k];
+                incl = own;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t y = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += y;
+                }
+                if (lane == 63) tmp[w] = incl;
+            }
+            __syncthreads();
+            if (t < 256) {
+                for (int k = 0; k < w; ++k) incl += tmp[k];
+                const uint32_t excl = incl - own;
+                if ((excl <= rank[q] && rank[q] < incl) || (t == 255 && rank[q] >= incl)) {
+                    uint32_t cum = excl;
+                    int b = t * per;
+                    while (b < t * per + per - 1 && cum + h[q][b] <= rank[q]) cum += h[q][b++];
+                    tmp[4] = (uint32_t)b;
+                    tmp[5] = rank[q] - cum;
+                }
+            }
+            __syncthreads();
+            prefix[q] |= tmp[4] << shift;
+            rank[q] = tmp[5];
+            __syncthreads();
+        }
+    }
+    return (key2f(prefix[0]) + key2f(prefix[1])) * 0.5f;
 }
 
 // ---- 3. per group: global median M, row medians, ctr, rowcorr ------------------------------------
@@ -200,8 +258,11 @@ __global__ __launch_bounds__(1024) void rowcorr_kernel(const SelState *__restric
         const float b = lohi[((size_t)g * ny + r) * 2 + 1] - M;
         return (a + b) * 0.5f;
     };
+    __shared__ uint32_t hsel[2][SEL_BINS];
+    __shared__ uint32_t tmp[8];
     for (int r = threadIdx.x; r < ny; r += blockDim.x) rm[r] = refmed(r);
-    const float ctr = block_median_sorted(rm, ny, npow2);
+    __syncthreads();
+    const float ctr = block_median_select(rm, ny, hsel, tmp);
     for (int r = threadIdx.x; r < ny; r += blockDim.x) {
         const float v = refmed(r);
         rowcorr[(size_t)g * ny + r] = slope * (double)(v - ctr);
