@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const uint16_t *__restric
     const int shift = sel_shift(level);
     const uint32_t mask = (1u << sel_bits(level)) - 1u;
     const int above = shift + sel_bits(level);  // bits above this level's field
-    const uint32_t p0 = st[g].prefix[0], p1 = st[g].prefix[1];
+    const uint32_t p0 = level ? st[g].prefix[0] : 0u, p1 = level ? st[g].prefix[1] : 0u;   // level 0: no prefix yet (st not read)
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const uint32_t key = f2key((float)amp33[(size_t)g * n + i] - med[i]);
         const uint32_t bin = (key >> shift) & mask;
@@ -149,14 +149,16 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const uint16_t *__restric
     }
 }
 
-__global__ __launch_bounds__(256) void sel_scan_kernel(SelState *__restrict__ st, uint32_t *__restrict__ ghist, int level) {
+__global__ __launch_bounds__(256) void sel_scan_kernel(SelState *__restrict__ st, uint32_t *__restrict__ ghist, int level, uint32_t n) {
     // bin holding the wanted rank: 8 bins per thread, wave prefix sums over the 256 partial sums, the owner walks its 8 bins
     __shared__ uint32_t part[4];
     const int g = blockIdx.x, t = blockIdx.y;
     uint32_t *h = ghist + ((size_t)g * 2 + t) * SEL_BINS;
     const int per = SEL_BINS / 256;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t rank = st[g].rank[t];
+    // level 0 starts the selection: the two middle elements of n values, empty prefix (no separate initialisation launch)
+    const uint32_t rank = level ? st[g].rank[t] : (t ? n / 2 : n / 2 - 1);
+    const uint32_t before = level ? st[g].prefix[t] : 0u;
     uint32_t own = 0;
     for (int k = 0; k < per; ++k) own += h[tid * per + k];
     uint32_t incl = own;
@@ -173,21 +175,11 @@ __global__ __launch_bounds__(256) void sel_scan_kernel(SelState *__restrict__ st
         uint32_t cum = excl;
         int b = tid * per;
         while (b < tid * per + per - 1 && cum + h[b] <= rank) cum += h[b++];
-        st[g].prefix[t] |= (uint32_t)b << sel_shift(level);
+        st[g].prefix[t] = before | ((uint32_t)b << sel_shift(level));
         st[g].rank[t] = rank - cum;
     }
     __syncthreads();
     for (int k = 0; k < per; ++k) h[tid * per + k] = 0;  // ready for the next level
-}
-
-__global__ void sel_init_kernel(SelState *st, uint32_t *ghist, int ngrp, uint32_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (size_t)ngrp * 2 * SEL_BINS) ghist[i] = 0;
-    if (i < (size_t)ngrp) {
-        st[i].prefix[0] = st[i].prefix[1] = 0;
-        st[i].rank[0] = n / 2 - 1;
-        st[i].rank[1] = n / 2;
-    }
 }
 
 // np.median of vals[0..n) in LDS by a three-level radix selection inside one block (11 + 11 + 10 key bits, two LDS histograms:
@@ -332,27 +324,29 @@ int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a) {
     if (a.ny < 8) return rip_fail(ctx, RIP_EINVAL, "refpix: ny=%d too small", a.ny);
     const int G = a.ngrp, ny = a.ny, nch = a.nx / RIP_CW;
     if (a.amp33) {
-        // scratch: lohi (G,ny,2) f32 | SelState[G] | ghist (G,2,2048) u32
+        // scratch: lohi (G,ny,2) f32 | SelState[G]
         const size_t lohi_b = (size_t)G * ny * 2 * sizeof(float);
         const size_t st_b = ((size_t)G * sizeof(SelState) + 255) / 256 * 256;
-        const size_t gh_b = (size_t)G * 2 * SEL_BINS * sizeof(uint32_t);
-        char *ws = (char *)rip_ws(ctx, 4, lohi_b + st_b + gh_b);
+        char *ws = (char *)rip_ws(ctx, 4, lohi_b + st_b);
         if (!ws) return RIP_ENOMEM;
         float *lohi = (float *)ws;
         SelState *st = (SelState *)(ws + lohi_b);
-        uint32_t *ghist = (uint32_t *)(ws + lohi_b + st_b);
+        // the selection histograms have a workspace slot of their own, of a fixed size: every level's scan leaves them zero, so
+        // they are cleared only when the slot is first allocated (no initialisation launch per call)
+        const size_t gh_b = (size_t)RIP_MAX_GROUPS * 2 * SEL_BINS * sizeof(uint32_t);
+        const void *had = ctx->ws[13];
+        uint32_t *ghist = (uint32_t *)rip_ws(ctx, 13, gh_b);
+        if (!ghist) return RIP_ENOMEM;
+        if ((const void *)ghist != had) RIP_HIP(ctx, hipMemsetAsync(ghist, 0, gh_b, ctx->stream));
         const uint32_t n = (uint32_t)ny * RIP_CW;
         hipLaunchKernelGGL(amp33_rows_kernel, dim3((unsigned)((G * ny + 3) / 4)), dim3(256), 0, ctx->stream, a.amp33,
                            a.amp33_med, lohi, ny, G * ny);
-        const size_t ninit = (size_t)G * 2 * SEL_BINS;
-        hipLaunchKernelGGL(sel_init_kernel, dim3((unsigned)((ninit + 255) / 256)), dim3(256), 0, ctx->stream, st, ghist,
-                           G, n);
         const int chunk = 8192;
         const unsigned nblk = (unsigned)((n + chunk - 1) / chunk);
         for (int level = 0; level < 3; ++level) {
             hipLaunchKernelGGL(sel_hist_kernel, dim3(nblk, G), dim3(256), 0, ctx->stream, a.amp33, a.amp33_med, st,
                                ghist, ny, level, chunk);
-            hipLaunchKernelGGL(sel_scan_kernel, dim3(G, 2), dim3(256), 0, ctx->stream, st, ghist, level);
+            hipLaunchKernelGGL(sel_scan_kernel, dim3(G, 2), dim3(256), 0, ctx->stream, st, ghist, level, n);
         }
         int npow2 = 1;
         while (npow2 < ny) npow2 <<= 1;

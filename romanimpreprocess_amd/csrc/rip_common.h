@@ -135,8 +135,9 @@ struct rip_ctx {
     double guard_band = 1e-5;  // relative half-width of the exact-order re-evaluation band of the jump test (rip_set_option_f64)
     bool prof = false;
     std::vector<hipEvent_t> prof_events;  // 6 per rip_calibrate call
-    void *ws[13] = {};          // 0-9: calibration path and stage entries; 10-12: Level-1 synthesis (synth.hip)
-    size_t ws_bytes[13] = {};
+    void *ws[14] = {};          // 0-9: calibration path and stage entries; 10-12: Level-1 synthesis (synth.hip); 13: the pre-pass's
+                                // selection histograms (zero between calls)
+    size_t ws_bytes[14] = {};
     // rip_calibrate_batch (batch.hip): download stream and the two sets of device buffers, kept between calls
     hipStream_t stream3 = nullptr;
     void *batch_buf[4] = {nullptr, nullptr, nullptr, nullptr};
