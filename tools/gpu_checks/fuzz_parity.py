@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 
 import oracle
+from oracle import saturation
 from romanimpreprocess_amd import _native, pipeline, synth
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -62,6 +63,24 @@ for case in range(ncases):
     cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=p, seed=seed, gain_dtype=gdt, ipc_dtype=kdt,
                             bias_amplitude=float(rng.uniform(0, 3)), bad_lin_frac=float(rng.uniform(0, 0.02)))
     ramp = synth.make_ramp(cal, read_pattern=rp, seed=seed + 1, cr_frac=float(rng.uniform(0, 0.08)))
+    # one case in three: dq-init + saturation flagging on the device (with or without the read-pattern rule) against the numpy
+    # restatement, thresholds lowered so that a few per cent of the pixels saturate at various groups
+    sat = rng.random() < 0.33
+    sat_kw = {}
+    if sat:
+        thr = np.quantile(ramp["data"].astype(np.float32), float(rng.uniform(0.6, 0.95)), axis=0).astype(np.float32)
+        thr[rng.random((ny, nx)) < 0.95] = 65535.0
+        sdq = np.where(rng.random((ny, nx)) < 0.01, np.uint32(1 << 21), np.uint32(0)).astype(np.uint32)   # NO_SAT_CHECK
+        cal = dict(cal)
+        cal["saturation"] = {"data": thr, "dq": sdq}
+        backup, use_rp = int(rng.integers(0, 3)), bool(rng.random() < 0.5)
+        h = {"data": ramp["data"], "groupdq": np.zeros(ramp["data"].shape, np.uint8), "pixeldq": ramp["pixeldq"].copy()}
+        saturation.flag_saturation(h, thr, backup=backup, skip_firstn=1, n_pix_grow_sat=1, sat_dq=sdq, read_pattern=rp if use_rp else None)
+        if excl:
+            h["groupdq"][0] |= np.uint8(1)
+        mask_dq = ramp["pixeldq"].copy()
+        ramp = dict(ramp, groupdq=h["groupdq"], pixeldq=h["pixeldq"])
+        sat_kw = dict(flag_saturation=True, saturation_backup=backup, saturation_read_pattern=use_rp)
     with np.errstate(all="ignore"):
         ref = oracle.calibrate_arrays(ramp, cal, exclude_first=excl, jump_pars=jump)
     lines = np.zeros((len(rp), nx // 128, 2))
@@ -71,14 +90,15 @@ for case in range(ncases):
     ctx.set_option("chain2", int(rng.random() < 0.8))
     ctx.set_option("chain3", int(rng.integers(0, 3)))   # 0 only where required, 1 wherever instantiated, 2 the default rule
     cb.load_caldir(1, cal)
-    got = cb.calibrate(1, ramp, exclude_first=excl, jump_pars=jump, want_cube=True, channel_lines=lines)
+    dev_ramp = dict(ramp, groupdq=None, pixeldq=mask_dq) if sat else ramp
+    got = cb.calibrate(1, dev_ramp, exclude_first=excl, jump_pars=jump, want_cube=True, channel_lines=lines, **sat_kw)
     forms[ctx.last_chain_form()] += 1
     ok = (same(got["cube"], ref["data"], True) and same(got["groupdq"], ref["groupdq"]) and same(got["pixeldq"], ref["pixeldq"])
           and all(same(got[k], ref[k], True) for k in ("slope", "err_read", "err_poisson")))
     if not ok:
         fails += 1
         print(f"MISMATCH case {case}: G={len(rp)} rp={rp} shape=({ny},{nx}) p={p} gain={gdt.__name__} ipc={kdt.__name__} excl={excl} "
-              f"jump={jump} seed={seed} form={ctx.last_chain_form()}", flush=True)
+              f"jump={jump} seed={seed} form={ctx.last_chain_form()} sat={sat_kw}", flush=True)
     if (case + 1) % 25 == 0:
         print(f"{case + 1} cases, {fails} mismatches, forms {forms}, {time.time() - t0:.0f} s", flush=True)
 ctx.set_option("fused", 1)
