@@ -177,7 +177,12 @@ int rip_plan_create(rip_ctx *ctx, const rip_plan_desc *desc, int *plan_id);
 int rip_plan_destroy(rip_ctx *ctx, int plan_id);
 
 /* the chain: replaces gen_cal_image.py:531-629 (stages selects a sub-chain).  Asynchronous with
-   respect to the host when location == RIP_DEVICE (use rip_synchronize / the stream). */
+   respect to the host when location == RIP_DEVICE (use rip_synchronize / the stream).
+   Device-resident INPUTS must be complete when the call is made: with the "overlap" option on (default) the
+   reference-pixel pre-pass reads data / amp33 on a second stream straight away, so that it runs beside the previous
+   call's main kernel -- work still queued on rip_stream() (rip_synth_*, rip_stats_*, a caller's own kernels) is not
+   ordered before it.  Synchronise first, or switch "overlap" off: then every kernel of a call runs on rip_stream() in
+   order.  Outputs are ordered on rip_stream() either way. */
 int rip_calibrate(rip_ctx *ctx, int sca_slot, int plan_id, unsigned stages, const rip_ramp_desc *in,
                   const rip_outputs *out);
 
