@@ -180,8 +180,9 @@ int rip_plan_destroy(rip_ctx *ctx, int plan_id);
    respect to the host when location == RIP_DEVICE (use rip_synchronize / the stream).
    Device-resident INPUTS must be complete when the call is made: with the "overlap" option on (default) the
    reference-pixel pre-pass reads data / amp33 on a second stream straight away, so that it runs beside the previous
-   call's main kernel -- work still queued on rip_stream() (rip_synth_*, rip_stats_*, a caller's own kernels) is not
-   ordered before it.  Synchronise first, or switch "overlap" off: then every kernel of a call runs on rip_stream() in
+   call's main kernel.  The library orders that pre-pass behind its OWN device-pointer entry points (rip_synth_*,
+   rip_stats_*: a call that follows one of them gives up the overlap), but not behind kernels a caller queues on
+   rip_stream() itself or on other streams.  Synchronise first, or switch "overlap" off: then every kernel of a call runs on rip_stream() in
    order.  Outputs are ordered on rip_stream() either way. */
 int rip_calibrate(rip_ctx *ctx, int sca_slot, int plan_id, unsigned stages, const rip_ramp_desc *in,
                   const rip_outputs *out);

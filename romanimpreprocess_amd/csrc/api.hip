@@ -141,6 +141,8 @@ void rip_ctx_destroy(rip_ctx *ctx) {
             delete p;
         }
     rip_pink_release(ctx);
+    for (hipEvent_t e : {ctx->ev_tab[0], ctx->ev_tab[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_in})
+        if (e) (void)hipEventDestroy(e);
     for (void *p : ctx->ws)   // every workspace slot, the Level-1 synthesis ones included
         if (p) (void)hipFree(p);
     for (void *p : ctx->batch_buf)
@@ -742,6 +744,11 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         hipStream_t main_stream = ctx->stream;
         if (overlap) {
             if (ctx->ev_done_valid[par]) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_done[par], 0));
+            if (ctx->stream_dirty) {   // device-pointer work of this library queued on the main stream since the last call
+                if (!ctx->ev_in) RIP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
+                RIP_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->stream));
+                RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_in, 0));
+            }
             ctx->stream = ctx->stream2;
         }
         mark();
@@ -906,6 +913,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     }
     mark();
     }  // unfused
+    ctx->stream_dirty = false;
     // the main-stream kernels of this call are the last readers of the tables / flag copies of parity `par`: the
     // pre-pass of call n+2 (same parity, second stream) waits for this event before it overwrites them
     if (overlap) {

@@ -181,5 +181,6 @@ extern "C" int rip_stage_noise_1f(rip_ctx *ctx, int rows, int width, int nframes
 }
 
 extern "C" int rip_synth_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, uint64_t seed, uint32_t stream_id, float *out) {
+    ctx->stream_dirty = true;
     return noise_1f_impl(ctx, rows, width, nframes, nullptr, seed, stream_id, out, true);
 }

@@ -146,6 +146,10 @@ struct rip_ctx {
     void *pink_plan = nullptr, *pink_z = nullptr, *pink_s = nullptr;
     size_t pink_L = 0;
     int pink_chunk = 0;
+    // set by the entry points that queue work on `stream` with device pointers (rip_synth_*, rip_stats_*): the next overlapped
+    // rip_calibrate then orders its second-stream pre-pass behind that work (it may have produced the call's inputs)
+    bool stream_dirty = false;
+    hipEvent_t ev_in = nullptr;
     int batch_completed = 0;  // of the last rip_calibrate_batch: ramps completed (all of them unless it returned an error)
 };
 

@@ -214,6 +214,7 @@ int grow_masks(rip_ctx *ctx, const uint8_t grow[32], uint32_t m[4]) {
 extern "C" {
 
 int rip_stats_l1_diff(rip_ctx *ctx, const uint16_t *cube, int ngrp, int ny, int nx, int ga, int gb, float *out) {
+    ctx->stream_dirty = true;
     if (!cube || !out || ny < 1 || nx < 1 || ga < 0 || gb < 0 || ga >= ngrp || gb >= ngrp)
         return rip_fail(ctx, RIP_EINVAL, "stats_l1_diff: bad arguments (groups %d, %d of %d)", ga, gb, ngrp);
     RIP_HIP(ctx, hipSetDevice(ctx->device));
@@ -227,6 +228,7 @@ int rip_stats_l1_diff(rip_ctx *ctx, const uint16_t *cube, int ngrp, int ny, int 
 int rip_stats_l2_pack(rip_ctx *ctx, const float *slope, const float *err_read, const float *err_poisson,
                       const uint32_t *pixeldq, int ny, int nx, int nb, const uint8_t grow[32], float *image, float *err,
                       uint8_t *good) {
+    ctx->stream_dirty = true;
     if (!slope || !err_read || !err_poisson || !pixeldq || !grow || !image || !err || !good || ny < 1 || nx < 1 || nb < 0 ||
         2 * nb >= ny || 2 * nb >= nx)
         return rip_fail(ctx, RIP_EINVAL, "stats_l2_pack: bad arguments");
@@ -242,6 +244,7 @@ int rip_stats_l2_pack(rip_ctx *ctx, const float *slope, const float *err_read, c
 
 int rip_stats_reduce(rip_ctx *ctx, int nseeds, const float *diffs, const float *images, const float *errs, const uint8_t *good,
                      const float *ideal, int y0, int nrows, int ny, int nx, int nb, int alias_err, float *out) {
+    ctx->stream_dirty = true;
     if (nseeds < 1 || !diffs || !images || !errs || !good || !ideal || !out || nrows < 1 || y0 < 0 || y0 + nrows > ny || nx < 1 ||
         nb < 0)
         return rip_fail(ctx, RIP_EINVAL, "stats_reduce: bad arguments (%d realisations, rows %d+%d of %d)", nseeds, y0, nrows, ny);

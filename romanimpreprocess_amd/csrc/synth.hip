@@ -243,6 +243,7 @@ int launch_resultants(rip_ctx *ctx, int np_, const ResArgs &a) {
 
 extern "C" int rip_synth_apportion(rip_ctx *ctx, const float *counts, int nya, int nxa, int poisson, int nreads, const double *t_reads,
                                    uint64_t seed, int32_t *reads_e) {
+    ctx->stream_dirty = true;
     if (!counts || !t_reads || !reads_e || nya < 1 || nxa < 1 || nreads < 1 || nreads > MAX_READS)
         return rip_fail(ctx, RIP_EINVAL, "synth_apportion: bad arguments (1..%d reads)", MAX_READS);
     RIP_HIP(ctx, hipSetDevice(ctx->device));
@@ -273,6 +274,7 @@ extern "C" int rip_synth_apportion(rip_ctx *ctx, const float *counts, int nya, i
 extern "C" int rip_synth_resultants(rip_ctx *ctx, const rip_synth_cal *cal, int ngrp, const int32_t *group_count, const int32_t *reads_e,
                                     const float *normals_reset, const float *normals_read, uint64_t seed, float *start_e,
                                     float *resultants, uint16_t *cube) {
+    ctx->stream_dirty = true;
     int rc = check_cal(ctx, cal, ngrp, group_count, "synth_resultants");
     if (rc) return rc;
     if (!reads_e || !cal->gain || !cal->read_noise || !cal->resetnoise || !cal->lin_coefs || !cal->smin || !cal->smax ||
@@ -326,6 +328,7 @@ extern "C" int rip_synth_resultants(rip_ctx *ctx, const rip_synth_cal *cal, int 
 
 extern "C" int rip_synth_fill(rip_ctx *ctx, const rip_synth_cal *cal, int ngrp, const int32_t *group_count, int banding, const float *normals,
                               const float *frames, const float *white33, uint64_t seed, uint16_t *cube, uint16_t *amp33) {
+    ctx->stream_dirty = true;
     int rc = check_cal(ctx, cal, ngrp, group_count, "synth_fill");
     if (rc) return rc;
     if (!cube || !cal->read_noise || !cal->resetnoise || !cal->dark) return rip_fail(ctx, RIP_EINVAL, "synth_fill: missing array");
@@ -375,6 +378,7 @@ extern "C" int rip_synth_fill(rip_ctx *ctx, const rip_synth_cal *cal, int ngrp, 
 }
 
 extern "C" int rip_synth_extract_ref(rip_ctx *ctx, uint16_t *data, int ngrp, size_t n, int offset, uint16_t *reference_read) {
+    ctx->stream_dirty = true;
     if (!data || ngrp < 1 || n < 1) return rip_fail(ctx, RIP_EINVAL, "synth_extract_ref: bad arguments");
     RIP_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(extract_ref_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, data, ngrp, n, offset, reference_read);

@@ -169,3 +169,48 @@ def test_reference_signatures_numpy_in_and_out(golden):
     assert np.max(np.abs(im[:, 4:-4, 4:-4].astype(np.int32) - g["im_before"][:, 4:-4, 4:-4].astype(np.int32))) < 40
     frame = sim_to_isim.noise_1f_frame(7)
     assert frame.shape == (4096, 128) and frame.dtype == np.float32 and abs(frame.mean()) < 1e-3 and 1.5 < frame.std() < 5.0
+
+
+def test_calibrate_right_behind_the_synthesis_without_a_sync():
+    """rip_calibrate's pre-pass runs on a second stream; it must still see an exposure that rip_synth_* kernels are only about
+    to write on the main stream (the library orders it behind its own device-pointer entry points): no synchronisation between
+    making the exposure and calibrating it, same results as with one."""
+    from romanimpreprocess_amd import pipeline
+
+    rp = synth.READ_PATTERN_8
+    ny, nx, nb = 520, 1024, 4
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=5)
+    cb = pipeline.Calibrator(ctx=_native.default_context(0))
+    cb.load_caldir(12, cal)
+    s = sim_to_isim.L1Synth(cal, rp, synth.FRAME_TIME, ctx=cb.ctx)
+    pid, _ = cb.plan_for(rp, synth.FRAME_TIME)
+    dev = s.dev
+    counts = torch.full((ny - 2 * nb, nx - 2 * nb), 3000.0, dtype=torch.float32, device=dev)
+    mask = torch.from_numpy(np.array(cal["mask"]["dq"], dtype=np.uint32).view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+
+    def run(seed, sync):
+        out = [torch.zeros((ny, nx), dtype=torch.float32, device=dev) for _ in range(3)] + [torch.zeros((ny, nx), dtype=torch.int32, device=dev)]
+        torch.cuda.synchronize()
+        reads_e = s.apportion(counts, seed, poisson=True)
+        cube = s.resultants(reads_e, seed)["cube"]
+        a33 = torch.zeros((len(rp), ny, s.cw), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()   # the zero fill above is torch's; everything below is the library's
+        s.fill(cube, a33, seed)
+        if sync:
+            cb.synchronize()
+        cb.calibrate_device(12, pid, len(rp), cube.data_ptr(), True, a33.data_ptr(), None, mask.data_ptr(), out[0].data_ptr(),
+                            out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), flag_saturation=True)
+        cb.synchronize()
+        return [o.cpu().numpy() for o in out]
+
+    # interleave so that a previous call's main kernel is in flight when the next exposure is made
+    try:
+        want = [run(31 + i, True) for i in range(3)]
+        got = [run(31 + i, False) for i in range(3)]
+    finally:
+        cb.ctx.drop_caldir(12)
+    for a, b in zip(want, got):
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert np.isfinite(want[0][0]).mean() > 0.9 and abs(np.median(want[0][0][8:-8, 8:-8])) < 50
