@@ -60,8 +60,10 @@ def caldir_arrays(caldir):
 
 class L1Synth:
     """Calibration arrays of one CALDIR set resident on the device + the synthesis entry points on device tensors.
-    ``apportion`` / ``resultants`` / ``fill`` / ``extract_ref`` are asynchronous on the context's stream (not torch's): call
-    ``ctx.synchronize()`` before reading their results with torch or dropping their inputs; ``make`` does."""
+    ``apportion`` / ``resultants`` / ``fill`` / ``extract_ref`` are asynchronous on the context's stream, which is NOT torch's and
+    does not synchronise with it: tensors handed in must be complete (``torch.cuda.synchronize()`` after the torch operations
+    that made them; numpy arrays are copied synchronously), and ``ctx.synchronize()`` comes before reading results with torch or
+    dropping inputs.  ``make`` takes care of both for what it allocates."""
 
     def __init__(self, cal, read_pattern, read_time, ctx=None, nb=pars.nborder, channelwidth=None):
         import torch
@@ -190,6 +192,7 @@ class L1Synth:
         reads_e = self.apportion(counts, seed, poisson)
         cube = self.resultants(reads_e, seed)["cube"]
         amp33 = torch.zeros((self.ngrp, self.ny, self.cw), dtype=torch.int16, device=self.dev)
+        torch.cuda.current_stream(self.dev).synchronize()   # torch's zero fill runs on torch's stream, the kernels below on the context's
         self.fill(cube, amp33, seed, banding)
         self.ctx.synchronize()   # the intermediate tensors (read electrons, deviates) may go once the kernels are done
         return cube, amp33
