@@ -7,6 +7,8 @@ launched by ``torch.distributed.run`` with one rank per GPU.  A "step" is one pa
 flat) over one 4096 x 4096 x 8-group ramp whose inputs are already resident in HBM.  Ramps are
 independent, so ranks share nothing on the data path: rank 0 scatters the work-item indices (RCCL
 broadcast of an int32 list) and every rank processes its own items (weak scaling).
+Defaults: 0.5 s of untimed calls first (``--clock-ramp-s``: an idle MI355X needs a few tenths of a second of load to reach
+its steady clock; recorded in ``config.clock_ramp_s_before_warmup``), then W = 100 warm-up steps and K = 1000 timed steps.
 
 Workloads (``--workload``):
   single   (default) BASELINE config 2: one seeded NON-PERIODIC full frame (sky + 25 Gaussian sources through IPC
