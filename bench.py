@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Throughput of the L1->L2 detector-calibration chain on MI355X: SCA ramps per second.
 
-Contract (see the task description): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is
-launched by ``torch.distributed.run`` with one rank per GPU.  A "step" is one pass of the whole chain
+Contract (see the task description): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it runs one rank per GPU
+under ``torch.distributed.run`` -- started that way by the driver, or by bench.py itself: a plain ``python bench.py --gpus N``
+(no WORLD_SIZE in the environment) re-launches itself under ``torch.distributed.run --nproc-per-node N`` before anything
+touches the GPU and passes the children's output and exit code on.  A "step" is one pass of the whole chain
 (reference pixels, bias, Legendre linearity, IPC deconvolution, ramp fit with jump detection, dark rate,
 flat) over one 4096 x 4096 x 8-group ramp whose inputs are already resident in HBM.  Ramps are
 independent, so ranks share nothing on the data path: rank 0 scatters the work-item indices (RCCL
@@ -28,6 +30,8 @@ import argparse
 import json
 import os
 import platform
+import socket
+import subprocess
 import sys
 import time
 
@@ -211,6 +215,70 @@ def run_steps(cb, calls, warmup, steps, fence, ramp_s=0.0):
     return elapsed, ms, ncalls
 
 
+def partition(n_items, rank, world):
+    """BASELINE config 4 / SURVEY 8e: item i belongs to rank i mod world."""
+    return [i for i in range(n_items) if i % world == rank]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started plainly: run the same command line as N ranks of one node (child process: nothing
+    in this process has touched the GPU, and no exec from a GPU-initialised process happens).  Returns the exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def dry_run(args, rank, world):
+    """--dry-run: the N-rank plumbing of this file (rendezvous, item scatter, barriers round the timed region, MAX all-reduce,
+    one JSON line from rank 0) with no GPU and no library: a step is a 1 ms sleep.  A rehearsal, never a measurement."""
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_items = 72 if args.workload == "batch72" else (args.steps + args.warmup) * world
+    items = torch.arange(n_items, dtype=torch.int32) if rank == 0 else torch.empty(n_items, dtype=torch.int32)
+    if world > 1:
+        dist.broadcast(items, src=0)
+    mine = items[rank::world].tolist()
+    assert len(mine) >= 1 and mine == partition(n_items, rank, world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    fence()
+    t_el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    all_items = [None] * world
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_gather_object(all_items, mine)
+    else:
+        all_items = [mine]
+    elapsed = float(t_el.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "SCA ramps/sec (dry run: no device work)", "value": world * args.steps / elapsed, "unit": "ramps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none", "dry_run": True,
+            "config": {"workload": f"dry run of --workload {args.workload}: a step is a 1 ms sleep",
+                       "sharding": f"items round-robin over {world} rank(s), index list broadcast over gloo",
+                       "items_per_rank": all_items}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,22 +296,41 @@ def main():
     ap.add_argument("--chain3", type=int, default=None, choices=(0, 1), help="A/B switch: 1 = wave-private fused kernel wherever instantiated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip pre-pass exclusive timing, variants and the 18-slot batch")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="collective backend of the N > 1 run (nccl = RCCL over xGMI; gloo: rehearsals on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal: rank r uses GPU r mod (GPUs present) instead of GPU r (needs --dist-backend gloo)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearsal of the N-rank plumbing without a GPU: item scatter, barriers, MAX all-reduce and the JSON line run "
+                         "as they are, a step is a 1 ms sleep; the line carries dry_run: true and is not a measurement")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.share_gpu and args.dist_backend != "gloo":
+        raise SystemExit("--share-gpu needs --dist-backend gloo (RCCL wants one GPU per rank)")
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     import torch
     import torch.distributed as dist
 
+    if args.share_gpu:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from romanimpreprocess_amd import pipeline, synth, synth_gpu
 
@@ -274,7 +361,7 @@ def main():
         o = res.outs
         return lambda: cb.calibrate_device(slot, pid, G, res.data.data_ptr(), True, res.a33.data_ptr(), res.gdq.data_ptr(),
                                            res.pdq.data_ptr(), o.slope.data_ptr(), o.er.data_ptr(), o.ep.data_ptr(),
-                                           o.pdq.data_ptr(), o.gdq.data_ptr())
+                                           o.pdq.data_ptr(), o.gdq.data_ptr(), inputs_complete=True)  # resident since the last sync
 
     def sane(res):
         good = (res.outs.pdq[nb:-nb, nb:-nb] == 0)
@@ -311,7 +398,7 @@ def main():
         # BASELINE config 4: 18 SCAs x 4 filters; item i = (filter i // 18, sca 1 + i % 18), seed 1000 * filter + sca
         rp = synth.READ_PATTERN_8 if G == 8 else synth.READ_PATTERN_16
         pid = None
-        my_items = [i for i in range(72) if i % world == rank]
+        my_items = partition(72, rank, world)
         slots = sorted({1 + i % 18 for i in my_items})
         cals = {}
         t_setup = time.perf_counter()
@@ -339,14 +426,14 @@ def main():
                     f"({len(slots) * 3.1:.0f} GB), item i on rank i mod {world}; a step is one item, the rank's items are walked round and round")
 
     # work-item scatter: rank 0 owns the list of (exposure, SCA) indices; item i goes to rank i % world
-    items = torch.arange(n_items, dtype=torch.int32, device=dev) if rank == 0 else torch.empty(n_items, dtype=torch.int32, device=dev)
+    items = torch.arange(n_items, dtype=torch.int32, device=cdev) if rank == 0 else torch.empty(n_items, dtype=torch.int32, device=cdev)
     if world > 1:
         dist.broadcast(items, src=0)
     mine = items[rank::world].tolist()
-    assert len(mine) >= 1
+    assert len(mine) >= 1 and mine == partition(n_items, rank, world)
 
     elapsed, ms, ncalls = run_steps(cb, calls, args.warmup, args.steps, fence, ramp_s=args.clock_ramp_s)
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
@@ -382,7 +469,10 @@ def main():
             "dtype": "f32" if args.ipc_dtype == "f32" else "f32 (IPC stage in f64)",
             "data": "synthetic",
             "config": {"workload": workload, "ramps_per_step_per_gpu": 1, "clock_ramp_s_before_warmup": args.clock_ramp_s,
-                       "sharding": f"ramps round-robin over {world} GPU(s), index list broadcast over RCCL"},
+                       "sharding": f"ramps round-robin over {world} GPU(s), index list broadcast over "
+                                   + ("RCCL" if args.dist_backend == "nccl" else "gloo (rehearsal)")
+                                   + ("; ranks share one GPU (rehearsal, not a scaling measurement)" if args.share_gpu else ""),
+                       "items_rank0": mine[:8]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "alg_bytes_kernel": per_kernel[dom], "kernel_ms": avg_ms[dom],

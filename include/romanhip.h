@@ -43,6 +43,8 @@ typedef struct rip_ctx rip_ctx;
 typedef enum { RIP_OK = 0, RIP_EINVAL = -1, RIP_ENOMEM = -2, RIP_EHIP = -3, RIP_ESTATE = -4 } rip_status;
 typedef enum { RIP_F32 = 0, RIP_F64 = 1, RIP_U16 = 2 } rip_dtype;
 typedef enum { RIP_HOST = 0, RIP_DEVICE = 1 } rip_location;
+/* rip_ramp_desc::inputs_ready: what the library may assume about DEVICE-resident inputs when rip_calibrate is called */
+typedef enum { RIP_INPUTS_STREAM_ORDERED = 0, RIP_INPUTS_COMPLETE = 1 } rip_inputs_ready;
 
 /* stages of the chain (bit mask), in the order of calibrateimage (gen_cal_image.py:531-629) */
 enum {
@@ -141,6 +143,21 @@ typedef struct {
        reference hands the read pattern over at gen_cal_image.py:172-185).  Host pointer to ngrp doubles (also for device
        ramps), or NULL = 1 for every group.  A NaN entry (0/0 for a group holding only read 0) never flags. */
     const double *sat_dilution;
+    /* When the DEVICE-resident inputs of this call (data, amp33, groupdq, pixeldq, area_factor, channel_lines) are valid.
+       The reference-pixel pre-pass of a call reads data / amp33 on a SECOND stream so that it can run beside the previous
+       call's main kernel; these two fields say what that stream has to wait for.  Ignored for location == RIP_HOST.
+         inputs_ready == RIP_INPUTS_STREAM_ORDERED (0, the default): the inputs are complete, or are written by work the
+             caller has ALREADY queued on rip_stream().  Every kernel of the call, the pre-pass included, is ordered behind
+             everything queued on rip_stream() at the time of the call (so the pre-pass cannot overlap the previous call's
+             main kernel: correct for every caller that uses one stream, ~0.03-0.06 ms per 4096^2 x 8 ramp slower).
+         inputs_ready == RIP_INPUTS_COMPLETE: the caller guarantees that the inputs are complete NOW (a ramp resident since
+             the last synchronisation, ...): the pre-pass starts at once.
+         ready_event != NULL (a hipEvent_t as void*, recorded by the caller behind the work that writes the inputs, on any
+             stream): the pre-pass and the main kernels wait for exactly that event; inputs_ready is not looked at.  This is
+             the form for inputs produced on another stream (a torch side stream, a copy engine) without giving up the
+             overlap.  The event must stay alive until the call returns (the wait is queued before that). */
+    int32_t inputs_ready;
+    void *ready_event;
 } rip_ramp_desc;
 
 typedef struct {
@@ -178,12 +195,11 @@ int rip_plan_destroy(rip_ctx *ctx, int plan_id);
 
 /* the chain: replaces gen_cal_image.py:531-629 (stages selects a sub-chain).  Asynchronous with
    respect to the host when location == RIP_DEVICE (use rip_synchronize / the stream).
-   Device-resident INPUTS must be complete when the call is made: with the "overlap" option on (default) the
-   reference-pixel pre-pass reads data / amp33 on a second stream straight away, so that it runs beside the previous
-   call's main kernel.  The library orders that pre-pass behind its OWN device-pointer entry points (rip_synth_*,
-   rip_stats_*: a call that follows one of them gives up the overlap), but not behind kernels a caller queues on
-   rip_stream() itself or on other streams.  Synchronise first, or switch "overlap" off: then every kernel of a call runs on rip_stream() in
-   order.  Outputs are ordered on rip_stream() either way. */
+   Device-resident INPUTS: by default the call is ordered behind everything already queued on rip_stream() (inputs written
+   by a kernel the caller queued there are safe without a synchronisation); rip_ramp_desc::inputs_ready / ready_event let a
+   caller whose inputs are complete, or guarded by an event of another stream, keep the overlap of the reference-pixel
+   pre-pass (second stream) with the previous call's main kernel.  Outputs are ordered on rip_stream() either way; with
+   "overlap" off every kernel of a call runs on rip_stream(). */
 int rip_calibrate(rip_ctx *ctx, int sca_slot, int plan_id, unsigned stages, const rip_ramp_desc *in,
                   const rip_outputs *out);
 
@@ -208,6 +224,27 @@ int rip_calibrate_batch_completed(rip_ctx *ctx);
 int rip_stage_refpix_image(rip_ctx *ctx, float *image, int ny, int nx, double slope, int do_row, int do_channel,
                            const double *lines, float *ref_med, float *ctr, float *bottom_top);
 
+/* reference_subtraction.ref_subtraction_row with ANY of its arguments (reference_subtraction.py:77-125) on one (ny, width) f32
+   image, in place.  nside = science columns (the reference hard-codes 4096): border pixels 0:4 and nside-4:nside, science
+   pixels 4:nside-4, reference output nside:nside+128.  use_ref_channel: the row medians are those of the reference output
+   (width >= nside+128), else of the 4+4 border pixels (:108-111).  mode:
+     RIP_ROW_MEDIANS_ONLY  no update: ref_med / sci_med / ctr out -- what the host needs for the np.polyfit of slope=None (:114)
+     RIP_ROW_SLOPE_F64     image = f32(f64(image) - slope * f64(f32(ref_med - ctr)))   (slope a numpy f64 scalar, :123)
+     RIP_ROW_SLOPE_F32     image = image - f32(slope) * (ref_med - ctr), every operation f32 (slope a Python float or a numpy
+                           f32 scalar, as np.polyfit returns it for f32 medians: numpy's promotion rules)
+   ref_med, sci_med (ny) f32 and ctr (1) f32 out, each may be NULL (sci_med costs a 4088-value selection per row). */
+enum { RIP_ROW_MEDIANS_ONLY = 0, RIP_ROW_SLOPE_F64 = 1, RIP_ROW_SLOPE_F32 = 2 };
+int rip_stage_refpix_row(rip_ctx *ctx, float *image, int ny, int width, int nside, int use_ref_channel, int mode, double slope,
+                         float *ref_med, float *sci_med, float *ctr);
+
+/* reference_subtraction.ref_subtraction_channel with ANY of its arguments (:16-74): nchan windows of columns
+   [channel_start + 128 k, channel_end + 128 k), k = 0 .. nchan-1 (32, or 33 with use_ref_channel), handled one after the
+   other as the reference's loop does (windows wider than 128 columns overlap and see each other's updates); per window
+   the medians of rows 0:4 and ny-4:ny, the line through (1.5, b), (ny-2.5, t) -- or lines (nchan,2) f64 (m,c) from the
+   caller's LAPACK -- subtracted from every row.  bottom_top (nchan,2) f32 out or NULL. */
+int rip_stage_refpix_channel(rip_ctx *ctx, float *image, int ny, int width, int channel_start, int channel_end, int nchan,
+                             const double *lines, float *bottom_top);
+
 /* ipc_linearity.multilin: S (ngrp,ny,nx) f32 -> phi (ngrp,ny,nx) f32, dq (ny,nx) u32.
    attempt_corr (ngrp,ny,nx) u8 nonzero = flag when extrapolated, or NULL = all. */
 int rip_stage_multilin(rip_ctx *ctx, const float *S, int ngrp, int ny, int nx, int nplanes, const float *coefs,
@@ -227,6 +264,15 @@ int rip_stage_correct_cube(rip_ctx *ctx, float *data, int ngrp, int ny, int nx, 
 int rip_stage_ramp_fit(rip_ctx *ctx, int plan_id, const float *data, uint8_t *rdq, uint32_t *pdq, int ny, int nx,
                        int nb, const void *gain, int g_dtype, const float *read_noise, float *slope,
                        float *err_read, float *err_poisson);
+
+/* fitting.jump_detect (fitting.py:89-255): ONE pass of slope fit + jump flagging over all ngrp groups of the plan with the
+   plan's weights K.  data (ngrp,ny,nx) f32; rdq (ngrp,ny,nx) u8 updated in place (JUMP_DET OR-ed into group i of a flagged
+   difference, active region only: the reference ORs into whatever flag cube it is handed); slope / err_read / err_poisson
+   (ny,nx) f32 out; smap (2*(ngrp-start)-3, ny, nx) f32 out: the significance of every tested difference, every pixel, in
+   the reference's exact operation order.  truncate_ramp = t of the reference is this call under a plan of t groups holding
+   the two-point weights of fitting.py:162-167 (the Python mirror builds it). */
+int rip_stage_jump_detect(rip_ctx *ctx, int plan_id, const float *data, uint8_t *rdq, int ny, int nx, int nb, const void *gain,
+                          int g_dtype, const float *read_noise, float *slope, float *err_read, float *err_poisson, float *smap);
 
 /* flatutils.get_flat: flat (ny,nx) f32, gain, kernel; pdq updated in place (may be NULL) */
 int rip_stage_get_flat(rip_ctx *ctx, const float *flat, int ny, int nx, int nb, const void *gain, int g_dtype,

@@ -55,9 +55,16 @@ def row_step(image, nside, use_ref_channel, slope):
         sci_med = np.median(image[:, 4 : nside - 4], axis=1)
         slope = _polyfit_slope(ref_med, sci_med)
     ctr = np.median(ref_med)
-    # (ref_med[r]-ctr) is rounded in the image dtype first, then multiplied in f64
-    corr = np.float64(slope) * (ref_med - ctr).astype(np.float64)
-    image[:, :] = (image.astype(np.float64) - corr[:, None]).astype(image.dtype)
+    if isinstance(slope, np.floating) and slope.dtype == np.float64 or isinstance(slope, np.ndarray) and slope.dtype == np.float64:
+        # a numpy f64 scalar (gen_cal_image.py:542-553, np.polyfit): (ref_med[r]-ctr) is rounded in the image dtype first,
+        # then multiplied and subtracted in f64, the row cast back on assignment
+        corr = np.float64(slope) * (ref_med - ctr).astype(np.float64)
+        image[:, :] = (image.astype(np.float64) - corr[:, None]).astype(image.dtype)
+    else:
+        # a Python float (weak under NEP 50) or a numpy f32 scalar: `m_med * (ref_medians[i] - ctr)` and the subtraction stay
+        # in the image dtype (reference_subtraction.py:123)
+        corr = image.dtype.type(slope) * (ref_med - ctr)
+        image[:, :] = image - corr[:, None]
     return image, ref_med, ctr
 
 
@@ -68,8 +75,9 @@ def channel_line(bottom_med, top_med, nrows):
     return m_cor, c_cor
 
 
-def channel_step(image, nside, use_ref_channel):
-    """Channel-wise correction, in place (``reference_subtraction.py:44-74``).
+def channel_step(image, nside, use_ref_channel, channel_start=0, channel_end=CHANNEL_WIDTH):
+    """Channel-wise correction, in place (``reference_subtraction.py:44-74``): windows of columns
+    ``[channel_start + 128 k, channel_end + 128 k)``, one after the other.
 
     Returns (image, table) with table[ch] = (bottom_med, top_med, m, c).
     """
@@ -78,7 +86,7 @@ def channel_step(image, nside, use_ref_channel):
     rows = np.arange(nrows, dtype=np.float64)
     table = np.zeros((nch, 4), dtype=np.float64)
     for ch in range(nch):
-        sl = slice(ch * CHANNEL_WIDTH, (ch + 1) * CHANNEL_WIDTH)
+        sl = slice(channel_start + ch * CHANNEL_WIDTH, channel_end + ch * CHANNEL_WIDTH)
         b = np.median(image[0:4, sl])
         t = np.median(image[nrows - 4 : nrows, sl])
         m_cor, c_cor = channel_line(b, t, nrows)

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("ROMANHIP_LIB") or os.path.join(_HERE, "libromanhip.so
 RIP_MAX_GROUPS = 64
 RIP_F32, RIP_F64, RIP_U16 = 0, 1, 2
 RIP_HOST, RIP_DEVICE = 0, 1
+RIP_INPUTS_STREAM_ORDERED, RIP_INPUTS_COMPLETE = 0, 1
 
 STAGE_REFPIX, STAGE_BIAS, STAGE_LIN, STAGE_IPC, STAGE_RAMPFIT, STAGE_DARK, STAGE_FLAT = (1 << i for i in range(7))
 STAGE_ALL = 0x7F
@@ -59,6 +60,7 @@ class RampDesc(C.Structure):
         ("channel_lines", C.c_void_p),
         ("flag_saturation", C.c_int32), ("sat_backup", C.c_int32), ("sat_skip_firstn", C.c_int32),
         ("sat_dilution", C.c_void_p),
+        ("inputs_ready", C.c_int32), ("ready_event", C.c_void_p),
     ]
 
 
@@ -101,6 +103,9 @@ SYMBOLS = {
     "rip_calibrate_batch_completed": (_I, [_VP]),
     "rip_stage_pearson": (_I, [_VP, C.c_size_t, _VP, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_uint32, _VP, _VP, _VP]),
     "rip_stage_refpix_image": (_I, [_VP, _VP, _I, _I, C.c_double, _I, _I, _VP, _VP, _VP, _VP]),
+    "rip_stage_refpix_row": (_I, [_VP, _VP, _I, _I, _I, _I, _I, C.c_double, _VP, _VP, _VP]),
+    "rip_stage_refpix_channel": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),
+    "rip_stage_jump_detect": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "rip_stage_multilin": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "rip_stage_ipc_image": (_I, [_VP, _I, _I, _VP, _I, _I, _I, _VP, _I, _VP, _I, _VP]),
     "rip_stage_correct_cube": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _I, _VP, _I]),

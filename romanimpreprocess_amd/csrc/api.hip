@@ -147,6 +147,7 @@ void rip_ctx_destroy(rip_ctx *ctx) {
         if (p) (void)hipFree(p);
     for (void *p : ctx->batch_buf)
         if (p) (void)hipFree(p);
+    if (ctx->chain_dbg_buf) (void)hipFree(ctx->chain_dbg_buf);
     if (ctx->stream3) {
         (void)hipStreamSynchronize(ctx->stream3);
         (void)hipStreamDestroy(ctx->stream3);
@@ -697,6 +698,8 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         o_cube = nullptr;  // taken from the workspace cube below
     }
 
+    // inputs guarded by a caller's event: the kernels on the main stream read them as well
+    if (!host && in->ready_event) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)in->ready_event, 0));
     int rc;
     auto mark = [&]() {
         if (!ctx->prof) return;
@@ -744,7 +747,12 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         hipStream_t main_stream = ctx->stream;
         if (overlap) {
             if (ctx->ev_done_valid[par]) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_done[par], 0));
-            if (ctx->stream_dirty) {   // device-pointer work of this library queued on the main stream since the last call
+            // what the pre-pass stream waits for before it reads the inputs (rip_ramp_desc::inputs_ready / ready_event):
+            // the caller's event, or -- unless the caller vouches for complete inputs -- everything queued on the main stream
+            // so far (work of the caller's own, or of this library's device-pointer entry points: stream_dirty)
+            if (in->ready_event) {
+                RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, (hipEvent_t)in->ready_event, 0));
+            } else if (in->inputs_ready != RIP_INPUTS_COMPLETE || ctx->stream_dirty) {
                 if (!ctx->ev_in) RIP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
                 RIP_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->stream));
                 RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_in, 0));
@@ -916,11 +924,14 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     ctx->stream_dirty = false;
     // the main-stream kernels of this call are the last readers of the tables / flag copies of parity `par`: the
     // pre-pass of call n+2 (same parity, second stream) waits for this event before it overwrites them
-    if (overlap) {
+    // EVERY call takes a parity and leaves its event, overlapped or not: a call whose pre-pass / flag pass ran on the main stream
+    // has used the buffers of `par` too, and the next overlapped call must neither reuse them (it takes the other parity)
+    // nor, two calls on, overwrite them before this call's main-stream kernels are done
+    if (ctx->ev_done[par]) {
         RIP_HIP(ctx, hipEventRecord(ctx->ev_done[par], ctx->stream));
         ctx->ev_done_valid[par] = true;
-        ctx->parity ^= 1;
     }
+    ctx->parity ^= 1;
     // ---- results back
     if (host) {
         if (do_fit) {
@@ -961,6 +972,47 @@ int rip_stage_refpix_image(rip_ctx *ctx, float *image, int ny, int nx, double sl
     if (ref_med && do_row) RIP_HIP(ctx, hipMemcpyAsync(ref_med, rm.p, (size_t)ny * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (ctr && do_row) RIP_HIP(ctx, hipMemcpyAsync(ctr, ct.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (bottom_top && do_channel) RIP_HIP(ctx, hipMemcpyAsync(bottom_top, bt.p, (size_t)nch * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RIP_OK;
+}
+
+int rip_stage_refpix_row(rip_ctx *ctx, float *image, int ny, int width, int nside, int use_ref_channel, int mode, double slope,
+                         float *ref_med, float *sci_med, float *ctr) {
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    if (!image || ny < 1 || width < 1) return rip_fail(ctx, RIP_EINVAL, "refpix row: image required");
+    if (mode < RIP_ROW_MEDIANS_ONLY || mode > RIP_ROW_SLOPE_F32) return rip_fail(ctx, RIP_EINVAL, "refpix row: mode %d", mode);
+    const size_t n = (size_t)ny * width;
+    DevBuf img, rm, sm, ct;
+    int rc;
+    if ((rc = img.upload(ctx, image, n * 4))) return rc;
+    if ((rc = rm.alloc(ctx, (size_t)ny * 4)) || (rc = ct.alloc(ctx, 4))) return rc;
+    if (sci_med && (rc = sm.alloc(ctx, (size_t)ny * 4))) return rc;
+    if ((rc = rip_refpix_row_general(ctx, img.as<float>(), ny, width, nside, use_ref_channel, mode, slope, rm.as<float>(),
+                                     sci_med ? sm.as<float>() : nullptr, ct.as<float>())))
+        return rc;
+    if (mode != RIP_ROW_MEDIANS_ONLY) RIP_HIP(ctx, hipMemcpyAsync(image, img.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ref_med) RIP_HIP(ctx, hipMemcpyAsync(ref_med, rm.p, (size_t)ny * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (sci_med) RIP_HIP(ctx, hipMemcpyAsync(sci_med, sm.p, (size_t)ny * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctr) RIP_HIP(ctx, hipMemcpyAsync(ctr, ct.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RIP_OK;
+}
+
+int rip_stage_refpix_channel(rip_ctx *ctx, float *image, int ny, int width, int channel_start, int channel_end, int nchan,
+                             const double *lines, float *bottom_top) {
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    if (!image || ny < 1 || width < 1 || nchan < 1) return rip_fail(ctx, RIP_EINVAL, "refpix channel: image required");
+    const size_t n = (size_t)ny * width;
+    DevBuf img, ln, bt;
+    int rc;
+    if ((rc = img.upload(ctx, image, n * 4))) return rc;
+    if (lines && (rc = ln.upload(ctx, lines, (size_t)nchan * 16))) return rc;
+    if ((rc = bt.alloc(ctx, (size_t)nchan * 8))) return rc;
+    if ((rc = rip_refpix_channel_general(ctx, img.as<float>(), ny, width, channel_start, channel_end, nchan,
+                                         lines ? ln.as<double>() : nullptr, bt.as<float>())))
+        return rc;
+    RIP_HIP(ctx, hipMemcpyAsync(image, img.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (bottom_top) RIP_HIP(ctx, hipMemcpyAsync(bottom_top, bt.p, (size_t)nchan * 8, hipMemcpyDeviceToHost, ctx->stream));
     RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RIP_OK;
 }
@@ -1081,6 +1133,34 @@ int rip_stage_ramp_fit(rip_ctx *ctx, int plan_id, const float *data, uint8_t *rd
     RIP_HIP(ctx, hipMemcpyAsync(err_poisson, dq2.p, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
     RIP_HIP(ctx, hipMemcpyAsync(rdq, dr2.p, (size_t)G * npix, hipMemcpyDeviceToHost, ctx->stream));
     RIP_HIP(ctx, hipMemcpyAsync(pdq, dp2.p, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RIP_OK;
+}
+
+int rip_stage_jump_detect(rip_ctx *ctx, int plan_id, const float *data, uint8_t *rdq, int ny, int nx, int nb, const void *gain,
+                          int g_dtype, const float *read_noise, float *slope, float *err_read, float *err_poisson, float *smap) {
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    RipPlan *plan = get_plan(ctx, plan_id);
+    if (!plan) return RIP_EINVAL;
+    if (!data || !rdq || !gain || !read_noise || !slope || !err_read || !err_poisson || !smap)
+        return rip_fail(ctx, RIP_EINVAL, "jump_detect: NULL array");
+    const int G = plan->h.ngrp, nd = plan->variants[0].ndiff;
+    const size_t npix = (size_t)ny * nx;
+    DevBuf dd, dr, dg, dn, ds, de, dp, dm;
+    int rc;
+    if ((rc = dd.upload(ctx, data, (size_t)G * npix * 4)) || (rc = dr.upload(ctx, rdq, (size_t)G * npix)) ||
+        (rc = dg.upload(ctx, gain, npix * dsize(g_dtype))) || (rc = dn.upload(ctx, read_noise, npix * 4)) ||
+        (rc = ds.alloc(ctx, npix * 4)) || (rc = de.alloc(ctx, npix * 4)) || (rc = dp.alloc(ctx, npix * 4)) ||
+        (rc = dm.alloc(ctx, (size_t)(nd > 0 ? nd : 1) * npix * 4)))
+        return rc;
+    if ((rc = rip_launch_jumpdetect(ctx, plan, dd.as<float>(), dr.as<uint8_t>(), dg.p, g_dtype, dn.as<float>(), ds.as<float>(),
+                                    de.as<float>(), dp.as<float>(), dm.as<float>(), ny, nx, nb)))
+        return rc;
+    RIP_HIP(ctx, hipMemcpyAsync(slope, ds.p, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipMemcpyAsync(err_read, de.p, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipMemcpyAsync(err_poisson, dp.p, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipMemcpyAsync(rdq, dr.p, (size_t)G * npix, hipMemcpyDeviceToHost, ctx->stream));
+    if (nd > 0) RIP_HIP(ctx, hipMemcpyAsync(smap, dm.p, (size_t)nd * npix * 4, hipMemcpyDeviceToHost, ctx->stream));
     RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RIP_OK;
 }

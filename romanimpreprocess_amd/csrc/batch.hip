@@ -119,8 +119,7 @@ extern "C" int rip_calibrate_batch(rip_ctx *ctx, int slot, int plan_id, unsigned
         }
         BATCH_HIP(hipEventRecord(b.ev_in, s_in));
         // chain: after its inputs have landed and the previous results of this set have left
-        BATCH_HIP(hipStreamWaitEvent(ctx->stream, b.ev_in, 0));
-        if (ctx->stream2) BATCH_HIP(hipStreamWaitEvent(ctx->stream2, b.ev_in, 0));
+        rd.ready_event = b.ev_in;   // the pre-pass stream and the main stream wait for the upload inside rip_calibrate
         if (b.used) BATCH_HIP(hipStreamWaitEvent(ctx->stream, b.ev_out, 0));
         rip_outputs od;
         od.location = RIP_DEVICE;

@@ -98,6 +98,16 @@ __device__ __forceinline__ uint32_t c2_ld_u8(__amdgpu_buffer_rsrc_t r, unsigned 
 #ifndef C2_XCD
 #define C2_XCD 1
 #endif
+// when the ingest role requests the IPC coefficients of the row whose first iterate follows the half-step barrier: 1 = at
+// the top of the step (landed by the barrier), 0 = at the end of the first half (ten registers fewer during A)
+#ifndef C2_KEARLY
+#define C2_KEARLY 1
+#endif
+// where the fit role reads the dense per-plan table of the jump test from: 1 = a copy staged in LDS (in-order returns, counted
+// waits), 0 = the device copy through scalar loads (every wait an lgkmcnt(0) round trip, eight per row step)
+#ifndef C2_FITLDS
+#define C2_FITLDS 1
+#endif
 __device__ __forceinline__ int c2_xcd_block(int b, int n) {
 #if C2_XCD
     const int q = n >> 3, r = n & 7, x = b & 7;
@@ -151,13 +161,20 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
     // group: 94 KB of LDS for 8 groups, one workgroup per CU (2 waves/SIMD, up to 256 VGPRs)
     constexpr bool K64 = sizeof(KT) == 8;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    f2 *X2 = reinterpret_cast<f2 *>(lds_raw);                       // [GP][4][C2_COLS]  x = gain*phi, pair-interleaved
-    f2 *O12 = X2 + GP * 4 * C2_COLS;                                // [GP][3][C2_COLS]  first Neumann iterate
+    constexpr int XR = 3;  // rows of the x ring
+    f2 *X2 = reinterpret_cast<f2 *>(lds_raw);                       // [GP][XR][C2_COLS]  x = gain*phi, pair-interleaved
+    f2 *O12 = X2 + GP * XR * C2_COLS;                               // [GP][3][C2_COLS]  first Neumann iterate
     double *O1d = reinterpret_cast<double *>(O12);                  // f64 ipc4d: [G][3][C2_COLS] instead
     uint32_t *DQ = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(O12) +
                                                 (size_t)G * 3 * C2_COLS * sizeof(KT));  // [4][C2_COLS] linearity dq of the row
     uint32_t *QS = DQ + 4 * C2_COLS;                                // [4][QW][C2_COLS] groupdq bytes of the pixel, packed
     double *LN = reinterpret_cast<double *>(QS + 4 * QW * C2_COLS);  // [3][G][2] channel lines of this strip
+    // K ring: the nine IPC coefficients of destination (row, col), loaded ONCE by the ingest thread of the column and handed to
+    // its fit thread (two rows live: C of row y runs two steps before O2 of row y)
+    f2 *KR2 = reinterpret_cast<f2 *>(LN + 3 * G * 2);               // f32 ipc4d: [2][4][C2_COLS] pairs (k0,k1)..(k6,k7)
+    float *KR1 = reinterpret_cast<float *>(KR2 + 2 * 4 * C2_COLS);  //            [2][C2_COLS] k8
+    double *KRd = reinterpret_cast<double *>(LN + 3 * G * 2);       // f64 ipc4d: [2][9][C2_COLS]
+    C3FitTab *const FT = reinterpret_cast<C3FitTab *>(KRd + (size_t)2 * 9 * C2_COLS * sizeof(KT) / 8);  // dense fit table
 
     // ChainArgs is the first kernel argument: it sits at offset 0 of the kernarg segment
     const RIP_K C2KernArgs *kargs = (const RIP_K C2KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -202,6 +219,21 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         const int ch = i / (G * 2), g = (i / 2) % G, w = i & 1;
         LN[i] = (ch0 + ch < nch) ? a.lines[(g * nch + ch0 + ch) * 2 + w] : 0.0;
     }
+#if C2_FITLDS
+    for (int i = tid; i < (int)(sizeof(C3FitTab) / 4); i += C2_THREADS) {
+        uint32_t v = 0;
+        constexpr int o_pairs = C3_MAXG, o_amin = o_pairs + C3_MAXG * 8;
+        if (i < o_pairs)
+            v = __float_as_uint(a.dense->K2[i]);
+        else if (i < o_amin)
+            v = reinterpret_cast<const uint32_t *>(a.dense->pairs)[i - o_pairs];
+        else if (i == o_amin)
+            v = __float_as_uint(a.dense->amin);
+        else if (i == o_amin + 1)
+            v = a.dense->valid;
+        reinterpret_cast<uint32_t *>(FT)[i] = v;
+    }
+#endif
     __syncthreads();
 
     // Addressing: every global access is (wave-uniform 64-bit base: array + plane + row, scalar ALU) + (per-lane
@@ -290,6 +322,12 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         }
         const unsigned um = (want && y >= ay0 && y < ay1) ? rowbits : 0u;
         return lane_mask & um;
+    };
+    // validity mask of destination (y, c) alone, for the role that receives the coefficients through the K ring
+    auto k_valid = [&](int y) -> unsigned {
+        const bool r0 = (y + 1) >= ay0 && (y + 1) < ay1, r1 = y >= ay0 && y < ay1, r2 = (y - 1) >= ay0 && (y - 1) < ay1;
+        const unsigned rowbits = (r0 ? 0x184u : 0u) | (r1 ? 0x019u : 0u) | (r2 ? 0x062u : 0u);
+        return r1 ? (lane_mask & rowbits) : 0u;
     };
     // forward IPC operator in f64 at one column: at_m / at_0 / at_p read rows y-1 / y / y+1 at a column offset; term order
     // and edge rule of ipc_linearity.py:69-94 (fwd_rows in chain_kernel.h)
@@ -394,14 +432,27 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
 #pragma unroll
                 for (int g = 0; g < G; ++g) rcn[g] = rt[g];
             }
+#if C2_KEARLY
+            // IPC coefficients of row yc, consumed by C after the barrier: requested at the top of the step so that they have
+            // landed by then (their ten registers are live during A)
+            f2 kC[5];
+            double kCd[9];
+            kC[4].y = 0.0f;
+            unsigned vC;
+            if constexpr (K64)
+                vC = load_kd(C2Keep{}, ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kCd);
+            else
+                vC = load_k(C2Keep{}, ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
+#endif
             const bool a_full = do_a && yi >= 0 && yi < ny;  // wave-uniform
             // A: two pairs of groups at a time -- reference-pixel/bias arithmetic and z of both pairs, then their two
             // Legendre recurrences interleaved (independent chains), then the raw loads of the same groups of the next
             // row.  The loads are issued UNCONDITIONALLY between the blocks (the wait-count pass is path-insensitive: a
             // load that exists on one side of a branch only forces vmcnt(0) at later uses).  All lanes compute (lanes
             // beyond the frame edge work on the clamped column and store zeros).
-            const int slot = yi & 3;
-            f2 *xs = X2 + slot * C2_COLS + col;
+            const int slot = yi & 3;                         // 4-row rings of the per-pixel words
+            const int xslot = (so_c == 2) ? 0 : so_c + 1;    // x ring (3 rows): row yi = r + 3 takes the slot of row r
+            f2 *xs = X2 + xslot * C2_COLS + col;
             const bool act = col_act && yi >= ay0 && yi < ay1;
             uint32_t dq = rr.dq;
             uint32_t w[QW];  // the pixel's groupdq bytes, packed
@@ -464,7 +515,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 fetch_groups(ka, r + 4, 2 * pb, 2 * (pb + PB), rr);
                 if (a_full && (dbg & 16)) {
 #pragma unroll
-                    for (int b = 0; b < PB; ++b) xs[(pb + b) * 4 * C2_COLS] = zz[b] + f2{1000.0f, 1100.0f};
+                    for (int b = 0; b < PB; ++b) xs[(pb + b) * XR * C2_COLS] = zz[b] + f2{1000.0f, 1100.0f};
                 } else if (a_full) {
                     const bool slow = __any(any_ex);
                     f2 phi[PB];
@@ -535,11 +586,11 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                         }
                         f2 xv = {vout[0], vout[1]};
                         if (act) xv = xv * rr.gain;
-                        xs[p * 4 * C2_COLS] = col_ok ? xv : f2{0.0f, 0.0f};
+                        xs[p * XR * C2_COLS] = col_ok ? xv : f2{0.0f, 0.0f};
                     }
                 } else if (do_a) {
 #pragma unroll
-                    for (int b = 0; b < PB; ++b) xs[(pb + b) * 4 * C2_COLS] = f2{0.0f, 0.0f};
+                    for (int b = 0; b < PB; ++b) xs[(pb + b) * XR * C2_COLS] = f2{0.0f, 0.0f};
                 }
             }
             if (do_a) {
@@ -548,6 +599,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
 #pragma unroll
                 for (int i = 0; i < QW; ++i) QS[(slot * QW + i) * C2_COLS + col] = keep ? w[i] : 0u;
             }
+#if !C2_KEARLY
             // IPC coefficients of row yc, consumed by C after the barrier; issued here so that their registers are not live
             // during A
             f2 kC[5];
@@ -558,6 +610,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 vC = load_kd(C2Keep{}, ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kCd);
             else
                 vC = load_k(C2Keep{}, ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
+#endif
             CH_T(2)
             C2_SYNC();
             CH_T(3)
@@ -568,8 +621,20 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 // every lane evaluates (lanes without valid terms produce values nobody reads); the coefficient planes of
                 // the next row are requested between the pairs, unconditionally (see above)
                 const bool all = __all(vC == 0x1ffu || vC == 0u);
-                const int sm = (yc - 1) & 3, s0 = yc & 3, sp = (yc + 1) & 3;
-                const int so = so_c;
+                const int so = so_c;  // slot of row yc in both 3-row rings
+                const int sm = (so == 0) ? 2 : so - 1, s0 = so, sp = (so == 2) ? 0 : so + 1;
+                // hand the coefficients of destination row yc to the fit thread of this column (O2 of row yc, two steps on)
+                {
+                    const int ks = yc & 1;
+                    if constexpr (K64) {
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) KRd[(ks * 9 + k) * C2_COLS + col] = kCd[k];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) KR2[(ks * 4 + i) * C2_COLS + col] = kC[i];
+                        KR1[ks * C2_COLS + col] = kC[4].x;
+                    }
+                }
                 if constexpr (K64) {
                     const float *Xf = reinterpret_cast<const float *>(X2);
 #pragma unroll
@@ -578,7 +643,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                         if (do_c) {
 #pragma unroll
                             for (int e = 0; e < 2; ++e) {
-                                const float *xb = Xf + (size_t)p0 * 4 * C2_COLS * 2 + e;  // scalar view of the pair-interleaved ring
+                                const float *xb = Xf + (size_t)p0 * XR * C2_COLS * 2 + e;  // scalar view of the pair-interleaved ring
                                 auto at_m = [&](int dx) { return xb[((sm * C2_COLS) + col + dx) * 2]; };
                                 auto at_0 = [&](int dx) { return xb[((s0 * C2_COLS) + col + dx) * 2]; };
                                 auto at_p = [&](int dx) { return xb[((sp * C2_COLS) + col + dx) * 2]; };
@@ -595,7 +660,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
 #pragma unroll
                     for (int p0 = 0; p0 < GP; ++p0) {
                         fetch_coefs(kb2, r + 4, p0 * CO_STEP, (p0 * CO_STEP + CO_STEP < NCO) ? p0 * CO_STEP + CO_STEP : NCO, rr);
-                        const f2 *xb = X2 + p0 * 4 * C2_COLS;
+                        const f2 *xb = X2 + p0 * XR * C2_COLS;
                         const f2 *xm[1] = {xb + sm * C2_COLS}, *x0[1] = {xb + s0 * C2_COLS}, *xp[1] = {xb + sp * C2_COLS};
                         f2 f[1], xc[1];
                         fwd_rows_batch<1, true>(xm, x0, xp, col, kC, vC, f, xc);
@@ -606,7 +671,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                     for (int p0 = 0; p0 < GP; ++p0) {
                         fetch_coefs(kb2, r + 4, p0 * CO_STEP, (p0 * CO_STEP + CO_STEP < NCO) ? p0 * CO_STEP + CO_STEP : NCO, rr);
                         if (do_c && !(dbg & 1)) {
-                            const f2 *xb = X2 + p0 * 4 * C2_COLS;
+                            const f2 *xb = X2 + p0 * XR * C2_COLS;
                             const f2 *xm[1] = {xb + sm * C2_COLS}, *x0[1] = {xb + s0 * C2_COLS}, *xp[1] = {xb + sp * C2_COLS};
                             f2 f[1], xc[1];
                             fwd_rows_batch<1, false>(xm, x0, xp, col, kC, vC, f, xc);
@@ -623,16 +688,16 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         }
     } else {
         // =========================================================================== fit waves
-        f2 kF[5];
-        double kFd[9];
-        unsigned vF = 0;
+        f2 xnext[GP];  // x of (row r + 1, own column), read from the ring at the end of the step before (the ring holds 3 rows)
 #pragma unroll
-        for (int k = 0; k < 5; ++k) kF[k] = f2{0.0f, 0.0f};
-#pragma unroll
-        for (int k = 0; k < 9; ++k) kFd[k] = 0.0;
+        for (int p0 = 0; p0 < GP; ++p0) xnext[p0] = f2{0.0f, 0.0f};
         const RipVariant v0 = rip_load_variant(vars, 0);
         const RipFitConst fc0 = rip_fit_const(h);
         constexpr int start = START;  // first group of the fit (exclude_first)
+#if C2_FITLDS
+        C2DenseLds<G> dtab;
+        dtab.t = FT;
+#endif
         float gain_next = 1.0f;
         int o0_r = (R0 - 5 + 3000) % 3;  // O1 ring slot of row r
         for (int r = R0 - 5; r <= R1; ++r, o0_r = (o0_r == 2) ? 0 : o0_r + 1) {
@@ -670,6 +735,22 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             CH_T(1)
             if (emit) {
                 const int sx = r & 3;
+                // the nine coefficients of destination (r, col) from the ingest thread of this column
+                f2 kF[5];
+                double kFd[9];
+                kF[4].y = 0.0f;
+                {
+                    const int ks = r & 1;
+                    if constexpr (K64) {
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) kFd[k] = KRd[(ks * 9 + k) * C2_COLS + col];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) kF[i] = KR2[(ks * 4 + i) * C2_COLS + col];
+                        kF[4].x = KR1[ks * C2_COLS + col];
+                    }
+                }
+                const unsigned vF = k_valid(r);
 #pragma unroll
                 for (int i = 0; i < QW; ++i) qw[i] = QS[(sx * QW + i) * C2_COLS + col];
                 lin_dq = DQ[sx * C2_COLS + col];
@@ -680,10 +761,9 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 constexpr int NB = (GP % 2 == 0) ? 2 : 1;
                 if constexpr (K64) {
                     // f64 iterate: (O1 + x) - fwd(O1) and the division by the gain in f64, one rounding to f32 at the end
-                    const float *Xf = reinterpret_cast<const float *>(X2);
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
-                        const float xc = Xf[(((g / 2) * 4 + sx) * C2_COLS + col) * 2 + (g & 1)];
+                        const float xc = (g & 1) ? xnext[g / 2].y : xnext[g / 2].x;
                         float val = xc;
                         if (act) {
                             const double *ob = O1d + (size_t)g * 3 * C2_COLS;
@@ -709,7 +789,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                         const f2 *om[NB], *o0[NB], *op[NB];
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
-                            xc[b] = X2[((p0 + b) * 4 + sx) * C2_COLS + col];
+                            xc[b] = xnext[p0 + b];
                             const f2 *ob = O12 + (p0 + b) * 3 * C2_COLS;
                             om[b] = ob + om_ * C2_COLS, o0[b] = ob + o0_ * C2_COLS, op[b] = ob + op_ * C2_COLS;
                         }
@@ -729,7 +809,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                     for (int p0 = 0; p0 < GP; p0 += NBG) {
                         f2 xc[NBG], val[NBG];
 #pragma unroll
-                        for (int b = 0; b < NBG; ++b) val[b] = xc[b] = X2[((p0 + b) * 4 + sx) * C2_COLS + col];
+                        for (int b = 0; b < NBG; ++b) val[b] = xc[b] = xnext[p0 + b];
                         if (act && !(dbg & 2)) {
                             const f2 *om[NBG], *o0[NBG], *op[NBG];
 #pragma unroll
@@ -763,23 +843,20 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 }
                 // first half of the ramp fit (registers only): slope, errors, approximate jump significances
                 const bool unsat = ((qw[(G - 1) / 4] >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
-                if (!(dbg & 4))
+                if (!(dbg & 4)) {
+#if C2_FITLDS
+                    fit_full_pk_a_t<G, rip_full_valid<G, START>(), C2DenseLds<G>>(dpair, fc0, v0, dtab, e_gain, e_read, unsat && act,
+                                                                                  kf->guard, fs);
+#else
                     fit_full_pk_a<G, rip_full_valid<G, START>()>(dpair, fc0, v0, kf->a.dense, e_gain, e_read, unsat && act, kf->guard, fs);
+#endif
+                }
             }
             CH_T(2)
             C2_SYNC();
             CH_T(3)
             const RIP_K C2KernArgs *kg = c2_args(kargs);  // S2 copy
             // ---- S2: coefficients and gain of the next row's O2, second half of the fit, tail of pixel (r, c)
-            f2 kN[5];
-            double kNd[9];
-            kN[4].y = 0.0f;
-            const bool next_on = (r + 1 >= R0) && (r + 1 < R1) && col >= 2 && col < C2_COLS - 2;
-            unsigned vN;
-            if constexpr (K64)
-                vN = load_kd(C2Last{}, kg->a.kern, r + 1, next_on, kNd);
-            else
-                vN = load_k(C2Last{}, kg->a.kern, r + 1, next_on, kN);
             gain_next = c2_ld_f32<C2_NT_F>(c2_rsrc(kg->a.planes), cc4, (unsigned)(NP + 4) * pl4 + (unsigned)min(max(r + 1, 0), ny - 1) * row4);
             CH_T(4)
             C2_DRAIN()
@@ -864,16 +941,15 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                     *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kg->a.pdq_out) + t_row4 + w4) = pdq;
                 }
             }
+            // x of (r + 1, own column) for the next step's O2: its ring slot is overwritten in S1 of that step (row r + 4)
+            {
+                const int sn = (o0_r == 2) ? 0 : o0_r + 1;
+#pragma unroll
+                for (int p0 = 0; p0 < GP; ++p0) xnext[p0] = X2[(p0 * XR + sn) * C2_COLS + col];
+            }
             CH_T(6)
             C2_SYNC();
             CH_T(7)
-            vF = vN;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) kF[k] = kN[k];
-            if constexpr (K64) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) kFd[k] = kNd[k];
-            }
         }
     }
 #ifdef CH_STAMP
@@ -885,8 +961,9 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
 }
 
 static inline size_t chain2_lds_bytes(int G, size_t ksize = 4) {
-    return (size_t)(G / 2) * C2_COLS * 8 * 4 + (size_t)G * C2_COLS * ksize * 3 + (size_t)C2_COLS * 4 * 4 * (1 + (G + 3) / 4) +
-           (size_t)3 * G * 2 * 8;
+    // x ring (3 rows) + O1 ring (3 rows) + linearity dq / packed groupdq rings (4 rows) + channel lines + K ring (2 rows)
+    return (size_t)(G / 2) * C2_COLS * 8 * 3 + (size_t)G * C2_COLS * ksize * 3 + (size_t)C2_COLS * 4 * 4 * (1 + (G + 3) / 4) +
+           (size_t)3 * G * 2 * 8 + (size_t)2 * 9 * C2_COLS * ksize + sizeof(C3FitTab);
 }
 
 template <int NP, int G, int START, typename KT = float>

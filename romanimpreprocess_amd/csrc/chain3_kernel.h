@@ -121,31 +121,6 @@ struct C3Int {
     static constexpr int value = N;
 };
 
-// the dense fit table of the plan, staged in LDS by the kernel (device_rampfit.h: fit_full_pk_a_t)
-#define C3_MAXG 16  // the kernel is instantiated for at most 16 groups
-struct __attribute__((aligned(16))) C3FitTab {
-    float k2[C3_MAXG];
-    RipDensePair pairs[C3_MAXG];
-    float amin;
-    uint32_t valid;
-    float pad_[2];
-};
-template <int G>
-struct C3DenseLds {
-    const C3FitTab *t;
-    float k2v[G];  // the slope weights: loop-invariant scalars, read once before the row loop
-    __device__ __forceinline__ float k2(int i) const { return k2v[i]; }
-    __device__ __forceinline__ uint32_t valid() const { return t->valid; }
-    __device__ __forceinline__ float amin() const { return t->amin; }
-    __device__ __forceinline__ void pair(RipDensePair &r, int ps) const {
-        typedef float f4_ __attribute__((ext_vector_type(4)));
-        const f4_ *p = reinterpret_cast<const f4_ *>(&t->pairs[ps]);  // 32 B, 16-byte aligned in C3FitTab
-        const f4_ a = p[0], b = p[1];
-        r.inv_dt[0] = a[0], r.inv_dt[1] = a[1], r.A[0] = a[2], r.A[1] = a[3];
-        r.B[0] = b[0], r.B[1] = b[1], r.k1[0] = b[2], r.k1[1] = b[3];
-    }
-};
-
 template <int NP, int G, int START, typename KT, int WPS>
 __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
                                                                   const RipVariant *__restrict__ vars,

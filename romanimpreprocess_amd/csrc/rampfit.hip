@@ -77,3 +77,90 @@ int rip_launch_rampfit(rip_ctx *ctx, const RipPlan *plan, const RampFitArgs &a, 
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
 }
+
+// ------------------------------------------------------------------ fitting.jump_detect as a callable (fitting.py:89-255)
+// One pass over the plan's full ramp (variant 0): slope, errors, the significance of every tested difference in the
+// reference's exact operation order (the cube `smap` is an OUTPUT here, so there is no approximate fast path), JUMP_DET OR-ed
+// into rdq[i] on the active region.  A ramp truncated at `truncate_ramp` is the same pass under a plan of that many groups
+// with the two-point weights of fitting.py:162-167 (built by the host mirror, romanimpreprocess_amd/utils/fitting.py).
+template <typename GT>
+__global__ __launch_bounds__(RF_THREADS) void jumpdetect_kernel(const float *__restrict__ cube, uint8_t *__restrict__ rdq,
+                                                                const void *__restrict__ gain_,
+                                                                const float *__restrict__ read_noise,
+                                                                float *__restrict__ slope, float *__restrict__ err_read,
+                                                                float *__restrict__ err_poisson, float *__restrict__ smap,
+                                                                const RipPlanHeader *__restrict__ h,
+                                                                const RipVariant *__restrict__ vars,
+                                                                const float *__restrict__ kvals,
+                                                                const RipDiff *__restrict__ diffs, int G, int ny, int nx,
+                                                                int nb) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    float *D = reinterpret_cast<float *>(lds_raw) + threadIdx.x;  // [G][RF_THREADS], this thread's column
+    const size_t npix = (size_t)ny * nx;
+    const size_t p = (size_t)blockIdx.x * RF_THREADS + threadIdx.x;
+    if (p >= npix) return;
+    const int y = (int)(p / nx), x = (int)(p % nx);
+    const bool active = (y >= nb) && (y < ny - nb) && (x >= nb) && (x < nx - nb);
+    for (int g = 0; g < G; ++g) D[g * RF_THREADS] = cube[(size_t)g * npix + p];
+    const RipVariant v = vars[0];
+    const float *kv = kvals + v.k_ofs;
+    const RipDiff *df = diffs + v.diff_ofs;
+    const GT gain = reinterpret_cast<const GT *>(gain_)[p];
+    const float rn = read_noise[p];
+    const float d1 = D[RF_THREADS];
+    float s = 0.0f;
+    for (int t = 0; t < v.g; ++t) {
+        const float diff = D[t * RF_THREADS] - d1;
+        const float prod = kv[t] * diff;
+        s = s + prod;
+    }
+    const GT gc = clip2<GT>(gain, GainConst<GT>::lo(), GainConst<GT>::hi());
+    const GT dv = clip_lo<GT>((GT)s / gc, (GT)0);
+    const GT pv = clip_lo<GT>((GT)v.coef * dv, (GT)0);
+    float ep;
+    if constexpr (sizeof(GT) == 4)
+        ep = sqrtf(pv);
+    else
+        ep = (float)sqrt(pv);
+    slope[p] = s;
+    err_read[p] = rn * v.rfac;
+    err_poisson[p] = ep;
+    const float xc = clip2<float>(s, h->ia, h->ib);
+    const float lx = log_f32(xc / h->ia);
+    const double sth = h->sa + h->dsb * ((double)lx / h->loglen);
+    const float s2 = rn * rn;
+    for (int k = 0; k < v.ndiff; ++k) {
+        const RipDiff r = df[k];
+        const float num = D[r.j * RF_THREADS] - D[r.i * RF_THREADS];
+        const float delta = num / r.dt - s;
+        const double var = exact_variance<GT>(h, kv, v.g, r.i, r.j, r.dt, dv, s2);
+        const float sme = delta / (float)sqrt(var);
+        smap[(size_t)k * npix + p] = sme;
+        if (active && (double)sme > sth) rdq[(size_t)r.i * npix + p] |= (uint8_t)DQ_JUMP_DET;
+    }
+}
+
+int rip_launch_jumpdetect(rip_ctx *ctx, const RipPlan *plan, const float *cube, uint8_t *rdq, const void *gain, int gain_dtype,
+                          const float *read_noise, float *slope, float *err_read, float *err_poisson, float *smap, int ny,
+                          int nx, int nb) {
+    const int G = plan->h.ngrp;
+    const size_t npix = (size_t)ny * nx;
+    const unsigned blocks = (unsigned)((npix + RF_THREADS - 1) / RF_THREADS);
+    const size_t lds = (size_t)G * RF_THREADS * 4;
+    const RipPlanHeader *h = reinterpret_cast<const RipPlanHeader *>(plan->dev);
+    if (gain_dtype == RIP_F64) {
+        if (lds > 48 * 1024)
+            RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(jumpdetect_kernel<double>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(jumpdetect_kernel<double>, dim3(blocks), dim3(RF_THREADS), lds, ctx->stream, cube, rdq, gain, read_noise,
+                           slope, err_read, err_poisson, smap, h, plan->d_variants, plan->d_k, plan->d_diffs, G, ny, nx, nb);
+    } else {
+        if (lds > 48 * 1024)
+            RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(jumpdetect_kernel<float>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(jumpdetect_kernel<float>, dim3(blocks), dim3(RF_THREADS), lds, ctx->stream, cube, rdq, gain, read_noise,
+                           slope, err_read, err_poisson, smap, h, plan->d_variants, plan->d_k, plan->d_diffs, G, ny, nx, nb);
+    }
+    RIP_HIP(ctx, hipGetLastError());
+    return RIP_OK;
+}

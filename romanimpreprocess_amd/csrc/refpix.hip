@@ -486,3 +486,168 @@ int rip_refpix_image(rip_ctx *ctx, float *d_image, int ny, int nx, double slope,
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
 }
+
+// ------------------------------------------------------------------ general forms of the image-level drop-ins
+// reference_subtraction.py with ANY of its arguments (the forms above are the configuration of calibrateimage):
+//   ref_subtraction_row(image, use_ref_channel=False, slope=None)      :77-125  row medians of the 4+4 border pixels or of
+//       the reference output, of the science pixels (for the np.polyfit of slope=None, done by the host mirror), update
+//       in the dtype numpy's promotion gives: f64 for a numpy f64 slope, f32 for a Python float / numpy f32 slope
+//   ref_subtraction_channel(image, channel_start, channel_end, use_ref_channel) :16-74  windows [start+128k, end+128k),
+//       one after the other as the reference's loop runs them (windows wider than 128 columns overlap)
+
+// median of the values of `nr` rows x (cols [c0, c0+n0) u [c1, c1+n1)) per block: block b starts at row row0 + b * rstep.
+// Dynamic LDS: npow2 floats.
+__global__ __launch_bounds__(1024) void img_window_median_kernel(const float *__restrict__ image, int w, int row0, int rstep,
+                                                                 int nr, int c0, int n0, int c1, int n1,
+                                                                 float *__restrict__ out, int npow2) {
+    extern __shared__ float mv[];
+    const int per = n0 + n1, n = nr * per;
+    const int rbase = row0 + (int)blockIdx.x * rstep;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int rr = i / per, cc = i % per;
+        const int col = cc < n0 ? c0 + cc : c1 + (cc - n0);
+        mv[i] = image[(size_t)(rbase + rr) * w + col];
+    }
+    __syncthreads();
+    const float m = block_median_sorted(mv, n, npow2);
+    if (threadIdx.x == 0) out[blockIdx.x] = m;
+}
+
+// ctr = median of the row medians; corr[r] = slope * f64(f32(ref_med[r] - ctr)) (f64 form) or f32(slope) * (ref_med[r] - ctr)
+// rounded to f32 (f32 form)
+__global__ __launch_bounds__(1024) void img_ctr2_kernel(const float *__restrict__ ref_med, double slope, int f32_form,
+                                                        double *__restrict__ rowcorr, float *__restrict__ ctr_out, int ny,
+                                                        int npow2) {
+    extern __shared__ float rm[];
+    for (int r = threadIdx.x; r < ny; r += blockDim.x) rm[r] = ref_med[r];
+    const float ctr = block_median_sorted(rm, ny, npow2);
+    const float s32 = (float)slope;
+    for (int r = threadIdx.x; r < ny; r += blockDim.x) {
+        const float d = ref_med[r] - ctr;
+        rowcorr[r] = f32_form ? (double)(s32 * d) : slope * (double)d;
+    }
+    if (threadIdx.x == 0 && ctr_out) *ctr_out = ctr;
+}
+
+__global__ void img_rowapply_f32_kernel(float *__restrict__ image, const double *__restrict__ rowcorr, int ny, int w) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ny * w) return;
+    image[i] = image[i] - (float)rowcorr[i / w];
+}
+
+// line through (1.5, b), (ny - 2.5, t) of one window (or the caller's), then the update of its columns
+__global__ void img_line1_kernel(const float *__restrict__ bt, const double *__restrict__ line_override,
+                                 double *__restrict__ line, float *__restrict__ bt_out, int ny) {
+    const float b = bt[0], t = bt[1];
+    double m, c;
+    if (line_override) {
+        m = line_override[0];
+        c = line_override[1];
+    } else {
+        m = ((double)t - (double)b) / (double)(ny - 4);
+        c = (double)b - 1.5 * m;
+    }
+    line[0] = m;
+    line[1] = c;
+    if (bt_out) {
+        bt_out[0] = b;
+        bt_out[1] = t;
+    }
+}
+
+__global__ void img_winapply_kernel(float *__restrict__ image, const double *__restrict__ line, int ny, int w, int c0,
+                                    int ncols) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ny * ncols) return;
+    const int r = (int)(i / ncols), c = c0 + (int)(i % ncols);
+    const double iel = line[0] * (double)r + line[1];
+    float *p = image + (size_t)r * w + c;
+    *p = (float)((double)*p - iel);
+}
+
+static int pow2_at_least(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+template <typename K>
+static int with_lds(rip_ctx *ctx, K kernel, size_t lds) {
+    if (lds > 48 * 1024)
+        RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return RIP_OK;
+}
+
+int rip_refpix_row_general(rip_ctx *ctx, float *d_image, int ny, int width, int nside, int use_ref_channel, int mode,
+                           double slope, float *d_ref_med, float *d_sci_med, float *d_ctr) {
+    if (nside < 16 || nside > width || (use_ref_channel && nside + RIP_CW > width))
+        return rip_fail(ctx, RIP_EINVAL, "refpix row: nside=%d does not fit an image %d wide", nside, width);
+    if (nside - 8 > 32768 || ny > 32768) return rip_fail(ctx, RIP_EINVAL, "refpix row: frame too large (%d x %d)", ny, nside);
+    char *ws = (char *)rip_ws(ctx, 4, (size_t)ny * (sizeof(double) + 2 * sizeof(float)) + 256);
+    if (!ws) return RIP_ENOMEM;
+    double *rowcorr = (double *)ws;
+    float *refmed = (float *)(rowcorr + ny), *scimed = refmed + ny;
+    int rc;
+    {   // reference medians: the reference output, or the 4 + 4 border pixels of the row (reference_subtraction.py:108-111)
+        const int n = use_ref_channel ? RIP_CW : 8, np2 = pow2_at_least(n);
+        if ((rc = with_lds(ctx, img_window_median_kernel, (size_t)np2 * 4))) return rc;
+        if (use_ref_channel)
+            hipLaunchKernelGGL(img_window_median_kernel, dim3(ny), dim3(1024), (size_t)np2 * 4, ctx->stream, d_image, width, 0, 1, 1,
+                               nside, RIP_CW, 0, 0, refmed, np2);
+        else
+            hipLaunchKernelGGL(img_window_median_kernel, dim3(ny), dim3(1024), (size_t)np2 * 4, ctx->stream, d_image, width, 0, 1, 1,
+                               0, 4, nside - 4, 4, refmed, np2);
+    }
+    if (d_sci_med) {   // science medians (:107), only needed for the polyfit of slope=None
+        const int n = nside - 8, np2 = pow2_at_least(n);
+        if ((rc = with_lds(ctx, img_window_median_kernel, (size_t)np2 * 4))) return rc;
+        hipLaunchKernelGGL(img_window_median_kernel, dim3(ny), dim3(1024), (size_t)np2 * 4, ctx->stream, d_image, width, 0, 1, 1, 4,
+                           n, 0, 0, scimed, np2);
+        RIP_HIP(ctx, hipMemcpyAsync(d_sci_med, scimed, (size_t)ny * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    {
+        const int np2 = pow2_at_least(ny);
+        if ((rc = with_lds(ctx, img_ctr2_kernel, (size_t)np2 * 4))) return rc;
+        hipLaunchKernelGGL(img_ctr2_kernel, dim3(1), dim3(1024), (size_t)np2 * 4, ctx->stream, refmed, slope, mode == 2 ? 1 : 0,
+                           rowcorr, d_ctr, ny, np2);
+    }
+    if (d_ref_med) RIP_HIP(ctx, hipMemcpyAsync(d_ref_med, refmed, (size_t)ny * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    const size_t n = (size_t)ny * width;
+    if (mode == 1)
+        hipLaunchKernelGGL(img_rowapply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_image, rowcorr, ny,
+                           width);
+    else if (mode == 2)
+        hipLaunchKernelGGL(img_rowapply_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_image, rowcorr,
+                           ny, width);
+    RIP_HIP(ctx, hipGetLastError());
+    return RIP_OK;
+}
+
+int rip_refpix_channel_general(rip_ctx *ctx, float *d_image, int ny, int width, int channel_start, int channel_end, int nchan,
+                               const double *d_lines, float *d_bottom_top) {
+    const int cw = channel_end - channel_start;
+    if (ny < 8 || cw < 1 || channel_start < 0 || nchan < 1 || channel_end + (nchan - 1) * RIP_CW > width)
+        return rip_fail(ctx, RIP_EINVAL, "refpix channel: windows [%d,%d) + 128 k, k < %d do not fit an image %d wide", channel_start,
+                        channel_end, nchan, width);
+    if (4 * cw > 32768) return rip_fail(ctx, RIP_EINVAL, "refpix channel: window of %d columns is too wide", cw);
+    char *ws = (char *)rip_ws(ctx, 4, 64);
+    if (!ws) return RIP_ENOMEM;
+    double *line = (double *)ws;
+    float *bt = (float *)(line + 2);
+    const int np2 = pow2_at_least(4 * cw);
+    int rc;
+    if ((rc = with_lds(ctx, img_window_median_kernel, (size_t)np2 * 4))) return rc;
+    const size_t n = (size_t)ny * cw;
+    for (int k = 0; k < nchan; ++k) {   // in the reference's order: a window sees the updates of the windows before it
+        const int c0 = channel_start + k * RIP_CW;
+        // two blocks: rows 0:4 and ny-4:ny
+        hipLaunchKernelGGL(img_window_median_kernel, dim3(2), dim3(1024), (size_t)np2 * 4, ctx->stream, d_image, width, 0, ny - 4, 4,
+                           c0, cw, 0, 0, bt, np2);
+        hipLaunchKernelGGL(img_line1_kernel, dim3(1), dim3(1), 0, ctx->stream, bt, d_lines ? d_lines + 2 * k : nullptr, line,
+                           d_bottom_top ? d_bottom_top + 2 * k : nullptr, ny);
+        hipLaunchKernelGGL(img_winapply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_image, line, ny,
+                           width, c0, cw);
+    }
+    RIP_HIP(ctx, hipGetLastError());
+    return RIP_OK;
+}

@@ -184,6 +184,10 @@ struct RampFitArgs {
     int ny, nx, nb, ngrp;
 };
 int rip_launch_rampfit(rip_ctx *ctx, const RipPlan *plan, const RampFitArgs &a, int gain_dtype);
+// one jump_detect pass over the plan's full ramp; rdq updated in place, smap (ndiff, ny, nx) out (device pointers)
+int rip_launch_jumpdetect(rip_ctx *ctx, const RipPlan *plan, const float *cube, uint8_t *rdq, const void *gain, int gain_dtype,
+                          const float *read_noise, float *slope, float *err_read, float *err_poisson, float *smap, int ny,
+                          int nx, int nb);
 
 // linearity.hip
 struct LinArgs {
@@ -269,6 +273,11 @@ struct RefpixArgs {
     int ny, nx, ngrp;
 };
 int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a);
+// the general forms (any argument of reference_subtraction.py's two functions); device pointers
+int rip_refpix_row_general(rip_ctx *ctx, float *d_image, int ny, int width, int nside, int use_ref_channel, int mode,
+                           double slope, float *d_ref_med, float *d_sci_med, float *d_ctr);
+int rip_refpix_channel_general(rip_ctx *ctx, float *d_image, int ny, int width, int channel_start, int channel_end, int nchan,
+                               const double *d_lines, float *d_bottom_top);
 int rip_refpix_image(rip_ctx *ctx, float *d_image, int ny, int nx, double slope, int do_row, int do_channel,
                      const double *d_lines, float *d_ref_med, float *d_ctr, float *d_bottom_top);
 

@@ -128,7 +128,8 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
             calibrator.synchronize()
             t1 = time.perf_counter()
             calibrator.calibrate_device(slot, pid, len(rp), cube.data_ptr(), True, a33.data_ptr(), None, t_pdq_hip.data_ptr(),
-                                        slope.data_ptr(), er.data_ptr(), ep.data_ptr(), pdq.data_ptr(), flag_saturation=True)
+                                        slope.data_ptr(), er.data_ptr(), ep.data_ptr(), pdq.data_ptr(), flag_saturation=True,
+                                        read_pattern=rp)   # the saturation rule calibrateimage applies (gen_cal_image.py:172-185)
             st.push(k, cube, slope, er, ep, pdq)
             calibrator.synchronize()
             t_gen += t1 - t0

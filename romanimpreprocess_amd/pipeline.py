@@ -140,17 +140,20 @@ class Calibrator:
 
     # ---- a batch of ramps in host memory, pipelined over PCIe --------------------------------
     def calibrate_many(self, slot, ramps, exclude_first=True, ramp_opt_pars=None, jump_pars=None, want_groupdq=False,
-                       flag_saturation=False, saturation_backup=1, saturation_skip_firstn=1, out=None):
+                       flag_saturation=False, saturation_backup=1, saturation_skip_firstn=1, out=None, saturation_read_pattern=False):
         """Run the whole chain on a list of ramps (dicts as for ``calibrate``; same read pattern, frame time and data
         dtype) with ``rip_calibrate_batch``: upload, chain and download of consecutive ramps overlap.  ``out``: optional
         list of dicts of preallocated result arrays (see ``calibrate``).  Returns the list of result dicts.  Page-locked
-        arrays (``pinned_empty``) on both sides give the full PCIe rate."""
+        arrays (``pinned_empty``) on both sides give the full PCIe rate.  ``saturation_read_pattern``: as in ``calibrate``
+        (the read-pattern rule of the saturation step; ``calibrateimage`` and the harness switch it on)."""
         ramps = list(ramps)
         if not ramps:
             return []
         ny, nx = self.shapes[slot]
         pid, meta = self.plan_for(ramps[0]["read_pattern"], ramps[0]["frame_time"], exclude_first, ramp_opt_pars, jump_pars)
         n = len(ramps)
+        # the read-pattern rule of the saturation step, as calibrateimage applies it (gen_cal_image.py:172-185)
+        dil = read_pattern_dilution(ramps[0]["read_pattern"]) if (flag_saturation and saturation_read_pattern) else None
         descs, outs, results, keep = (_native.RampDesc * n)(), (_native.Outputs * n)(), [], []
         for i, ramp in enumerate(ramps):
             if list(map(list, ramp["read_pattern"])) != list(map(list, ramps[0]["read_pattern"])):
@@ -179,6 +182,8 @@ class Calibrator:
             rd.groupdq, rd.pixeldq = (None if gdq is None else gdq.ctypes.data), pdq.ctypes.data
             rd.flag_saturation = 1 if flag_saturation else 0
             rd.sat_backup, rd.sat_skip_firstn = int(saturation_backup), int(saturation_skip_firstn)
+            if dil is not None:
+                rd.sat_dilution = dil.ctypes.data
             given = None if out is None else out[i]
 
             def result(name, shape, dtype, given=given):
@@ -208,14 +213,26 @@ class Calibrator:
     def calibrate_device(self, slot, plan_id, ngrp, data_ptr, data_is_u16, amp33_ptr, groupdq_ptr, pixeldq_ptr,
                          slope_ptr, err_read_ptr, err_poisson_ptr, pixeldq_out_ptr, groupdq_out_ptr=None,
                          area_ptr=None, stages=STAGE_ALL, flag_saturation=False, saturation_backup=1,
-                         saturation_skip_firstn=1):
-        """``groupdq_ptr`` may be None with ``flag_saturation`` (dq-init + saturation flagging on the device)."""
+                         saturation_skip_firstn=1, read_pattern=None, inputs_complete=False, ready_event=None):
+        """``groupdq_ptr`` may be None with ``flag_saturation`` (dq-init + saturation flagging on the device).
+        ``read_pattern``: with ``flag_saturation``, the exposure's read pattern for the read-pattern rule of the saturation
+        step (groups averaging several reads are compared with a diluted threshold, as ``calibrateimage`` does: the reference
+        hands the pattern to stcal at gen_cal_image.py:172-185); None = every group against the full threshold.
+        Ordering of the inputs (``rip_ramp_desc::inputs_ready`` / ``ready_event``): by default the call is ordered behind
+        everything queued on the context's stream; ``inputs_complete=True`` = the caller vouches that the device arrays are
+        complete now (keeps the overlap of the reference-pixel pre-pass with the previous call's kernel); ``ready_event`` =
+        a raw ``hipEvent_t`` (e.g. ``torch.cuda.Event.cuda_event``) recorded behind the work that writes them."""
         rd = _native.RampDesc()
         rd.location, rd.ngrp = _native.RIP_DEVICE, int(ngrp)
         rd.data, rd.data_dtype = data_ptr, (_native.RIP_U16 if data_is_u16 else _native.RIP_F32)
         rd.amp33, rd.groupdq, rd.pixeldq, rd.area_factor = amp33_ptr, groupdq_ptr, pixeldq_ptr, area_ptr
         rd.flag_saturation = 1 if flag_saturation else 0
         rd.sat_backup, rd.sat_skip_firstn = int(saturation_backup), int(saturation_skip_firstn)
+        dil = read_pattern_dilution(read_pattern) if (flag_saturation and read_pattern is not None) else None
+        if dil is not None:
+            rd.sat_dilution = dil.ctypes.data   # host pointer, read during the call
+        rd.inputs_ready = _native.RIP_INPUTS_COMPLETE if inputs_complete else _native.RIP_INPUTS_STREAM_ORDERED
+        rd.ready_event = ready_event
         out = _native.Outputs()
         out.location = _native.RIP_DEVICE
         out.slope, out.err_read, out.err_poisson = slope_ptr, err_read_ptr, err_poisson_ptr

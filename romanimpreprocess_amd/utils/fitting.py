@@ -2,7 +2,8 @@
 
 ``construct_weights`` is host numpy (a <= 64x64 f64 inverse, ``fitting.py:20-86``); ``ramp_fit``
 (``fitting.py:258-355``: slope + read/Poisson errors, jump detection, saturation-truncated refits,
-flag propagation) runs in ``rampfit.hip`` through ``rip_stage_ramp_fit``.
+flag propagation) runs in ``rampfit.hip`` through ``rip_stage_ramp_fit``; ``jump_detect`` (``fitting.py:89-255``: one
+pass, significance cube returned) through ``rip_stage_jump_detect``.
 """
 
 import numpy as np
@@ -45,3 +46,50 @@ def ramp_fit(data, rdq, pdq, meta, caldir, mylog, exclude_first=True, ctx=None):
     if mylog is not None:
         mylog.append(f"ramp fit on device {ctx.device}: {G} groups, {desc.nvariants} fit variants, K = {meta['K']}\n")
     return slope, er, ep
+
+
+def jump_detect(data, rdq, pdq, meta, caldir, mylog, exclude_first=True, truncate_ramp=None, ctx=None):
+    """One pass of slope fit + jump flagging (``fitting.py:89-255``).  ``data`` (ngrp,ny,nx) f32; ``rdq`` (uint8 cube of
+    at least the fitted groups) gets JUMP_DET OR-ed in place on the active region; ``pdq`` only gives the frame shape, as
+    in the reference.  ``truncate_ramp=t``: groups [0, t) with the two-point weights of ``fitting.py:162-167``.
+    Returns (slope, slope_err_read, slope_err_poisson, smap); ``smap`` is (2*(g-start)-3, ny, nx) float32."""
+    ctx = ctx or _native.default_context()
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    ny, nx = np.shape(pdq)
+    start = 1 if exclude_first else 0
+    g = int(meta["ngrp"]) if truncate_ramp is None else int(truncate_ramp)
+    if data.shape[0] < g or data.shape[1:] != (ny, nx):
+        raise ValueError(f"data {data.shape} does not hold {g} groups of {(ny, nx)}")
+    if 2 * (g - start) - 3 < 0 or g > int(meta["ngrp"]):
+        raise ValueError(f"cannot fit {g} groups (exclude_first={exclude_first}, ngrp={meta['ngrp']})")
+    if rdq.dtype != np.uint8 or not rdq.flags.c_contiguous or rdq.shape[0] < g or rdq.shape[1:] != (ny, nx):
+        raise TypeError("rdq must be a C-contiguous uint8 cube of at least the fitted groups (updated in place)")
+    if truncate_ramp is None:
+        K = np.asarray(meta["K"], dtype=np.float32)
+    else:   # fitting.py:162-167, float32 as there
+        K = np.zeros(g, dtype=np.float32)
+        K[-1] = 1.0 / (meta["tbar"][g - 1] - meta["tbar"][start])
+        K[start] = -K[-1]
+    sub = {"ngrp": g, "tbar": np.asarray(meta["tbar"])[:g], "tau": np.asarray(meta["tau"])[:g], "N": np.asarray(meta["N"])[:g]}
+    with calio.open_tree(caldir["gain"]) as f:
+        gain = np.ascontiguousarray(f["roman"]["data"])
+    with calio.open_tree(caldir["read"]) as f:
+        read = np.ascontiguousarray(f["roman"]["data"], dtype=np.float32)
+    if gain.dtype not in (np.float32, np.float64):
+        gain = gain.astype(np.float64)
+    desc = planmod.plan_desc(sub, K, exclude_first, True, meta.get("jump_detect_pars"))
+    pid = ctx.create_plan(desc)
+    try:
+        cube = np.ascontiguousarray(data[:g])
+        flags = np.ascontiguousarray(rdq[:g])
+        slope, er, ep = (np.empty((ny, nx), np.float32) for _ in range(3))
+        smap = np.zeros((2 * (g - start) - 3, ny, nx), np.float32)
+        ctx.check(ctx.lib.rip_stage_jump_detect(
+            ctx.h, pid, cube.ctypes.data, flags.ctypes.data, ny, nx, int(meta["nborder"]), gain.ctypes.data,
+            _native.dtype_code(gain), read.ctypes.data, slope.ctypes.data, er.ctypes.data, ep.ctypes.data, smap.ctypes.data))
+        rdq[:g] = flags
+    finally:
+        ctx.destroy_plan(pid)
+    if mylog is not None:
+        mylog.append(f"truncate at {truncate_ramp}, K = {K}\n")
+    return slope, er, ep, smap

@@ -481,7 +481,8 @@ def test_unusual_group_counts_vs_oracle(name, rp, exclude_first):
 
 @pytest.mark.parametrize("flag_sat", [False, True])
 def test_batch_of_host_ramps_equals_single_calls(flag_sat):
-    """rip_calibrate_batch (upload / chain / download of consecutive ramps overlapped) against one call per ramp."""
+    """rip_calibrate_batch (upload / chain / download of consecutive ramps overlapped) against one call per ramp; with device-side
+    saturation flagging also with the read-pattern rule of calibrateimage on (it changes several hundred flags of these ramps)."""
     rp = synth.READ_PATTERN_8
     ny, nx = 72, 256
     cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=41, bias_amplitude=2.0)
@@ -494,20 +495,26 @@ def test_batch_of_host_ramps_equals_single_calls(flag_sat):
             r["groupdq"] = None
             r["pixeldq"] = cal["mask"]["dq"].copy()
         ramps.append(r)
-    singles = [cb.calibrate(2, r, flag_saturation=flag_sat) for r in ramps]
-    pinned_out = [{k: cb.pinned_empty((ny, nx), np.float32) for k in ("slope", "err_read", "err_poisson")} for _ in ramps]
-    many = cb.calibrate_many(2, ramps, want_groupdq=True, flag_saturation=flag_sat, out=pinned_out)
-    assert len(many) == len(ramps)
-    for i, (a, b) in enumerate(zip(many, singles)):
-        assert a["slope"] is pinned_out[i]["slope"]
-        for k in ("slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
-            assert_same_bits(a[k], b[k], f"ramp {i}: {k}")
+    kept = {}
+    for rule in ((False, True) if flag_sat else (False,)):
+        singles = [cb.calibrate(2, r, flag_saturation=flag_sat, saturation_read_pattern=rule) for r in ramps]
+        pinned_out = [{k: cb.pinned_empty((ny, nx), np.float32) for k in ("slope", "err_read", "err_poisson")} for _ in ramps]
+        many = cb.calibrate_many(2, ramps, want_groupdq=True, flag_saturation=flag_sat, out=pinned_out, saturation_read_pattern=rule)
+        assert len(many) == len(ramps)
+        for i, (a, b) in enumerate(zip(many, singles)):
+            assert a["slope"] is pinned_out[i]["slope"]
+            for k in ("slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
+                assert_same_bits(a[k], b[k], f"ramp {i}: {k} (read-pattern rule {rule})")
+        kept[rule] = many[0]["groupdq"].copy()
+    if flag_sat:   # the rule does act on these ramps
+        assert np.count_nonzero(kept[False] != kept[True]) > 100
     assert cb.calibrate_many(2, []) == []
     cb.ctx.drop_caldir(2)
 
 
+@pytest.mark.parametrize("inputs_complete", [True, False])
 @pytest.mark.parametrize("flag_sat", [False, True])
-def test_back_to_back_device_calls_without_sync(flag_sat):
+def test_back_to_back_device_calls_without_sync(flag_sat, inputs_complete):
     """Different device-resident ramps issued back to back with no synchronisation in between (the reference-pixel pre-pass and
     the saturation pass of call n+1 run ahead on the second stream while the chain of call n is still reading ITS tables and
     flag copies: they are double-buffered by call parity, api.hip): results must equal those of synchronised single calls."""
@@ -547,7 +554,7 @@ def test_back_to_back_device_calls_without_sync(flag_sat):
         t = ramps[i]
         cb.calibrate_device(9, pid, 8, t[0].data_ptr(), True, t[1].data_ptr(), None if t[2] is None else t[2].data_ptr(),
                             t[3].data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(),
-                            flag_saturation=flag_sat)
+                            flag_saturation=flag_sat, inputs_complete=inputs_complete)   # True: the pre-pass runs ahead
 
     try:
         for i in range(n):          # reference: one call at a time
@@ -562,6 +569,129 @@ def test_back_to_back_device_calls_without_sync(flag_sat):
                     assert torch.equal(outs[i][k], outs[n + i][k]), f"ramp {i} {name}: queued call differs (repeat {rep})"
         # the ramps do differ from one another (otherwise the test could not see a stale table)
         assert not torch.equal(outs[0][0], outs[1][0])
+    finally:
+        cb.ctx.drop_caldir(9)
+
+
+def _small_resident_set(slot, n, ny=512, nx=512, sat=True):
+    """a CALDIR set in `slot` and n different device-resident ramps (tensors: data, amp33, groupdq, pixeldq)"""
+    dev = torch.device("cuda", 0)
+    rp = synth.READ_PATTERN_8
+    cal, _ = synth.make_tiled_inputs(ny, nx, read_pattern=rp, p_order=8, seed=3, strip_rows=64)
+    cal = dict(cal)
+    if sat:
+        cal["saturation"] = {"data": np.full((ny, nx), 50000.0, np.float32), "dq": np.zeros((ny, nx), np.uint32)}
+    ctx = gpu_context()
+    _default_form(ctx)
+    cb = pipeline.Calibrator(ctx=ctx)
+    cb.load_caldir(slot, cal)
+    pid, _meta = cb.plan_for(rp, synth.FRAME_TIME)
+
+    def to_dev(a):
+        a = np.ascontiguousarray(a)
+        view = {np.dtype(np.uint16): np.int16, np.dtype(np.uint32): np.int32}.get(a.dtype)
+        return torch.from_numpy(a.view(view) if view else a).to(dev)
+
+    ramps = []
+    for i in range(n):
+        _, r = synth.make_tiled_inputs(ny, nx, read_pattern=rp, p_order=8, seed=3, strip_rows=64, ramp_seed=200 + i)
+        g = r["groupdq"].copy()
+        g[0] |= 1
+        a33 = (r["amp33"].astype(np.int32) + 40 * i * (np.arange(ny)[None, :, None] % 7)).astype(np.uint16)
+        ramps.append([to_dev(r["data"]), to_dev(a33), to_dev(g), to_dev(r["pixeldq"])])
+
+    def outputs():
+        return [torch.empty((ny, nx), dtype=torch.float32, device=dev) for _ in range(3)] + [
+            torch.empty((ny, nx), dtype=torch.int32, device=dev), torch.empty((8, ny, nx), dtype=torch.uint8, device=dev)]
+
+    torch.cuda.synchronize()
+    return cb, pid, ramps, outputs
+
+
+def test_mixed_overlap_modes_back_to_back():
+    """Calls that run their pre-pass / saturation pass on the MAIN stream (overlap off, or a sub-chain without the reference-pixel
+    step that flags saturation) queued between overlapped calls, no synchronisation: every call takes a parity of the
+    double-buffered tables and flag copies and leaves its completion event, so a following overlapped call can neither reuse
+    nor overwrite buffers a queued kernel still reads (round-2 advisor finding on api.hip)."""
+    n = 6
+    cb, pid, ramps, outputs = _small_resident_set(9, n)
+    no_ref = pipeline.STAGE_ALL & ~pipeline.STAGE_REFPIX
+    # (overlap option, stage mask, flag saturation on the device) per call
+    modes = [(1, pipeline.STAGE_ALL, True), (0, pipeline.STAGE_ALL, True), (1, pipeline.STAGE_ALL, True),
+             (1, no_ref, True), (1, pipeline.STAGE_ALL, True), (0, no_ref, False)]
+
+    def call(i, o):
+        t = ramps[i]
+        ov, stages, fs = modes[i]
+        cb.ctx.set_option("overlap", ov)
+        cb.calibrate_device(9, pid, 8, t[0].data_ptr(), True, t[1].data_ptr(), None if fs else t[2].data_ptr(), t[3].data_ptr(),
+                            o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(), stages=stages,
+                            flag_saturation=fs, inputs_complete=True)
+
+    ref = [outputs() for _ in range(n)]
+    got = [outputs() for _ in range(n)]
+    try:
+        for i in range(n):
+            call(i, ref[i])
+            cb.synchronize()
+        for rep in range(3):
+            for i in range(n):
+                call(i, got[i])
+            cb.synchronize()
+            for i in range(n):
+                for k, name in enumerate(("slope", "err_read", "err_poisson", "pixeldq", "groupdq")):
+                    assert torch.equal(ref[i][k], got[i][k]), f"call {i} {modes[i]} {name}: queued call differs (repeat {rep})"
+        assert not torch.equal(ref[0][0], ref[2][0])
+    finally:
+        cb.ctx.set_option("overlap", 1)
+        cb.ctx.drop_caldir(9)
+
+
+@pytest.mark.parametrize("producer", ["side_stream_event", "library_stream_default"])
+def test_inputs_written_by_queued_work_no_sync(producer):
+    """The cube and the reference output of a call are written by kernels that are still QUEUED when rip_calibrate is called:
+    on a torch side stream, guarded by rip_ramp_desc::ready_event, or on rip_stream() itself with the default
+    (stream-ordered) contract.  No host synchronisation anywhere; the result must be that of the synchronised call -- the
+    second-stream pre-pass would otherwise read the stale previous contents and produce other row corrections."""
+    cb, pid, ramps, outputs = _small_resident_set(9, 3, sat=False)
+    dev = torch.device("cuda", 0)
+    ref, got = outputs(), outputs()
+    stale, fresh = ramps[0], ramps[1]
+    work = [torch.empty_like(stale[0]), torch.empty_like(stale[1])]   # the buffers the calls read
+    junk = torch.empty((4096, 4096), dtype=torch.float32, device=dev)
+    try:
+        def call(o, **kw):
+            cb.calibrate_device(9, pid, 8, work[0].data_ptr(), True, work[1].data_ptr(), fresh[2].data_ptr(), fresh[3].data_ptr(),
+                                o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(), **kw)
+
+        work[0].copy_(fresh[0]); work[1].copy_(fresh[1])
+        torch.cuda.synchronize()
+        call(ref)
+        cb.synchronize()
+        for rep in range(3):
+            work[0].copy_(stale[0]); work[1].copy_(stale[1])
+            torch.cuda.synchronize()
+            call(outputs())          # a call in flight in front (its main kernel is what an unordered pre-pass would run beside)
+            if producer == "side_stream_event":
+                side = torch.cuda.Stream(device=dev)
+                ev = torch.cuda.Event()
+                with torch.cuda.stream(side):
+                    for _ in range(20):
+                        junk.normal_()      # ~ a millisecond of queued work in front of the copies
+                    work[0].copy_(fresh[0]); work[1].copy_(fresh[1])
+                    ev.record(side)
+                call(got, ready_event=ev.cuda_event)
+            else:
+                ext = torch.cuda.ExternalStream(cb.ctx.stream(), device=dev)
+                with torch.cuda.stream(ext):
+                    for _ in range(20):
+                        junk.normal_()
+                    work[0].copy_(fresh[0]); work[1].copy_(fresh[1])
+                call(got)             # default: ordered behind everything queued on rip_stream()
+            cb.synchronize()
+            torch.cuda.synchronize()
+            for k, name in enumerate(("slope", "err_read", "err_poisson", "pixeldq", "groupdq")):
+                assert torch.equal(ref[k], got[k]), f"{name}: inputs written by queued work were read too early (repeat {rep})"
     finally:
         cb.ctx.drop_caldir(9)
 

@@ -224,3 +224,113 @@ def test_linearity_of_one_image(name):
     assert_same_bits(phi, g["lin_phi"], "linearity phi")
     assert_same_bits(dq, g["lin_out_dq"], "linearity dq")
     assert np.count_nonzero(dq & (1 << 20)) > 10
+
+
+@pytest.mark.parametrize("name", RAMPFIT)
+def test_jump_detect_returns_smap(name):
+    """fitting.jump_detect as a callable: slope, errors, the significance cube and the flags of ONE pass, against the arrays the
+    reference's own jump_detect returned for the same inputs (tools/make_goldens.py rampfit)."""
+    g = load_golden(name)
+    meta, caldir, ef = _rampfit_inputs(g)
+    loc = np.zeros_like(g["groupdq"])
+    s, er, ep, smap = fitting.jump_detect(g["data"], loc, g["pixeldq"], meta, caldir, ProcessLog(), exclude_first=ef, ctx=gpu_context())
+    assert_same_bits(s, g["jd_slope"], "slope", zero_sign_ok=True)
+    assert_same_bits(er, g["jd_err_read"], "err_read", zero_sign_ok=True)
+    assert_same_bits(ep, g["jd_err_poisson"], "err_poisson", zero_sign_ok=True)
+    assert_same_bits(smap, g["jd_smap"], "smap", zero_sign_ok=True)
+    assert_same_bits(loc, g["jd_flags"], "flags")
+
+
+@pytest.mark.parametrize("name,t", [("rampfit_g8", 4), ("rampfit_g8", 6), ("rampfit_g8", 8), ("rampfit_g8_include_first", 3),
+                                    ("rampfit_g8_include_first", 7), ("rampfit_g16", 5), ("rampfit_g16", 12)])
+def test_jump_detect_truncate_ramp(name, t):
+    """truncate_ramp: two-point weights over groups [0, t) (fitting.py:162-167), against the reference's own output"""
+    g, gt = load_golden(name), load_golden("jump_detect_trunc")
+    meta, caldir, ef = _rampfit_inputs(g)
+    loc = np.zeros_like(g["groupdq"])
+    s, er, ep, smap = fitting.jump_detect(g["data"], loc, g["pixeldq"], meta, caldir, None, exclude_first=ef, truncate_ramp=t,
+                                          ctx=gpu_context())
+    for k, v in (("slope", s), ("err_read", er), ("err_poisson", ep), ("smap", smap), ("flags", loc)):
+        assert_same_bits(v, gt[f"{name}_t{t}_{k}"], f"truncate {t}: {k}", zero_sign_ok=(k != "flags"))
+    with pytest.raises(ValueError):
+        fitting.jump_detect(g["data"], loc, g["pixeldq"], meta, caldir, None, exclude_first=ef, truncate_ramp=1, ctx=gpu_context())
+
+
+def _variants_base(seed):
+    c = gc.refpix_fullframe_inputs(seed)
+    n = 4096
+    base = np.zeros((n, n + 128), dtype=np.float32)
+    base[:, :n] = c["data"] - c["dark"]
+    base[:, -128:] = c["amp33"] - c["med"]
+    base[:, -128:] -= np.median(base[:, -128:])
+    return base
+
+
+def test_reference_unit_test_of_ref_subtraction_row():
+    """/root/reference/tests/romanimpreprocess/test_ref.py:7-21 against the HIP mirror: the same artificial image, the same call
+    (border-pixel medians, fitted slope), the same three assertions -- and the image equal to what the reference's function
+    made of it (tests/golden/refpix_variants.npz), bit for bit."""
+    g = load_golden("refpix_variants")
+    im = np.zeros((4096, 4224), dtype=np.float32)
+    im[:, :] = np.cos(np.linspace(0, 2000, 4096))[:, None]
+    im[:, -128:] *= 2.0
+    for x in range(4224):
+        im[:, x] += np.sin(0.1 * x) * np.sin(np.linspace(0, 2000, 4096)) ** 3
+    im[:, :-128] += 1.0
+    im_old = np.copy(im)
+    out = reference_subtraction.ref_subtraction_row(im, use_ref_channel=False, ctx=gpu_context())
+    assert out is im
+    assert np.std(im) < 0.75 * np.std(im_old)
+    assert 0.4 < np.std(im[:, :-128]) < 0.5
+    assert 0.99 < np.mean(im[:, :-128]) < 1.01
+    assert_same_bits(im[::257], g["test_row_rows"], "sampled rows")
+    assert hashlib.sha256(im.tobytes()).hexdigest() == str(g["test_row_sha256"])
+
+
+def test_ref_subtraction_default_arguments():
+    """ref_subtraction_row / ref_subtraction_channel with the arguments calibrateimage does not use (border-pixel medians,
+    fitted slope, float32 update for a Python-float / float32 slope, 32 channels, shifted and overlapping windows) on a full
+    4096 x 4224 frame, against the reference's outputs.  Channel lines: LAPACK's through `lines` where the comparison is
+    bit for bit (channel line fit); the device's own two-point line within the north-star tolerance."""
+    g = load_golden("refpix_variants")
+    ctx = gpu_context()
+    base = _variants_base(int(g["seed"]))
+    # the fixture of round 1 (polyfit on the border pixels, no reference output in the image)
+    g0 = load_golden("refpix_row_polyfit")
+    c0 = gc.refpix_fullframe_inputs(int(g0["seed"]))
+    im0 = np.zeros((4096, 4224), dtype=np.float32)
+    im0[:, :4096] = c0["data"] - c0["dark"]
+    reference_subtraction.ref_subtraction_row(im0, use_ref_channel=False, ctx=ctx)
+    assert hashlib.sha256(im0.tobytes()).hexdigest() == str(g0["image_sha256"])
+    for tag, kw in (("row_refout_fit", dict(use_ref_channel=True)), ("row_border_pyfloat", dict(use_ref_channel=False, slope=0.7)),
+                    ("row_refout_f32", dict(use_ref_channel=True, slope=np.float32(0.83)))):
+        im = reference_subtraction.ref_subtraction_row(base.copy(), ctx=ctx, **kw)
+        assert_same_bits(im[::257], g[f"{tag}_rows"], f"{tag}: sampled rows")
+        assert hashlib.sha256(im.tobytes()).hexdigest() == str(g[f"{tag}_sha256"]), tag
+    from romanimpreprocess_amd.pipeline import lapack_channel_lines
+    for tag, kw in (("chan_32", dict()), ("chan_window", dict(channel_start=4, channel_end=124, use_ref_channel=True)),
+                    ("chan_overlap", dict(channel_start=0, channel_end=192, use_ref_channel=False))):
+        # (a) the device's own line: a few pixels may differ by one f32 ulp from LAPACK's (north-star tolerance)
+        im = reference_subtraction.ref_subtraction_channel(base.copy(), ctx=ctx, **kw)
+        ref_rows = g[f"{tag}_rows"]
+        np.testing.assert_allclose(im[::257], ref_rows, rtol=1e-5, atol=1e-4)
+        # (b) LAPACK's lines from the exact medians of every window, in the reference's order: bit for bit
+        nchan = 33 if kw.get("use_ref_channel") else 32
+        s0, e0 = kw.get("channel_start", 0), kw.get("channel_end", 128)
+        work = base.copy()
+        lines = np.zeros((nchan, 2))
+        for k in range(nchan):   # a window sees the updates of the windows before it, so the medians are taken as it goes
+            sl = slice(s0 + 128 * k, e0 + 128 * k)
+            bt = np.array([np.median(work[0:4, sl]), np.median(work[4092:4096, sl])], np.float32)
+            lines[k] = lapack_channel_lines(bt, 4096)
+            one = np.ascontiguousarray(lines[k:k + 1])
+            ctx.check(ctx.lib.rip_stage_refpix_channel(ctx.h, work.ctypes.data, 4096, 4224, sl.start, sl.stop, 1, one.ctypes.data, None))
+        assert_same_bits(work[::257], ref_rows, f"{tag}: sampled rows (LAPACK lines)")
+        assert hashlib.sha256(work.tobytes()).hexdigest() == str(g[f"{tag}_sha256"]), tag
+        # and in one call with all the lines handed in
+        im2 = reference_subtraction.ref_subtraction_channel(base.copy(), lines=lines, ctx=ctx, **kw)
+        assert hashlib.sha256(im2.tobytes()).hexdigest() == str(g[f"{tag}_sha256"]), tag
+    with pytest.raises(ValueError):
+        reference_subtraction.ref_subtraction_channel(base[:, :4096].copy(), use_ref_channel=True, ctx=ctx)
+    with pytest.raises(TypeError):
+        reference_subtraction.ref_subtraction_row(base.astype(np.float64), ctx=ctx)

@@ -249,3 +249,30 @@ def test_level1_synthesis_host_helpers():
     tij = sim_to_isim.read_pattern_to_tij(rp, 3.04)
     assert [len(t) for t in tij] == [1, 2, 4, 1] and tij[2][-1] == 3.04 * 6
     assert all(np.array_equal(a, b) for a, b in zip(tij, l1sim.read_pattern_to_tij(rp, 3.04)))
+
+
+def _bench_json(cmd, env=None, timeout=600):
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, lines
+
+
+def test_bench_gpus_n_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` started plainly (no WORLD_SIZE) launches two ranks before anything touches a GPU; the
+    rehearsal mode runs the item scatter (i mod R), the barriers, the MAX all-reduce and the single JSON line with no device."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out, lines = _bench_json([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "batch72",
+                              "--steps", "4", "--warmup", "1"], env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["dry_run"] is True and d["scaling"] == "weak"
+    per_rank = d["config"]["items_per_rank"]
+    assert per_rank == [[i for i in range(72) if i % 2 == r] for r in range(2)]
+    # two ranks sleeping 4 x 1 ms side by side: the job's time is the slower rank's, not the sum
+    assert 4.0 <= d["ms_per_step"] * 4 < 400.0 and abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+    # a single process that is told --gpus 2 but runs as a world of one must refuse, not report n_gpus 1
+    out1, lines1 = _bench_json([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run"],
+                               env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert out1.returncode != 0 and not lines1 and "WORLD_SIZE=1" in (out1.stderr + out1.stdout)

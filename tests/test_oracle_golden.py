@@ -6,6 +6,7 @@ utils/fitting.py, utils/ipc_linearity.py, utils/flatutils.py, utils/reference_su
 
 import hashlib
 import json
+import os
 
 import numpy as np
 import pytest
@@ -15,6 +16,8 @@ import golden_cases as gc
 import oracle
 from oracle import finish, ipc, linearity, rampfit, refpix
 from romanimpreprocess_amd import synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_lin_known_answer():
@@ -326,3 +329,89 @@ def test_l1_synthesis_matches_the_reference_functions():
     # reference pixels really changed, the active region moved by the 1/f noise only
     assert np.all(g["im_before"][:, :4] == 0) and np.all(im[:, :4] > 0)
     assert np.max(np.abs(im[:, 4:-4, 4:-4].astype(np.int32) - g["im_before"][:, 4:-4, 4:-4].astype(np.int32))) < 40
+
+
+def _refpix_variants_base(seed):
+    c = gc.refpix_fullframe_inputs(seed)
+    n = 4096
+    base = np.zeros((n, n + 128), dtype=np.float32)
+    base[:, :n] = c["data"] - c["dark"]
+    base[:, -128:] = c["amp33"] - c["med"]
+    base[:, -128:] -= np.median(base[:, -128:])
+    return base
+
+
+def reference_test_row_image():
+    """the artificial image of the reference's unit test, tests/romanimpreprocess/test_ref.py:10-15"""
+    im = np.zeros((4096, 4224), dtype=np.float32)
+    im[:, :] = np.cos(np.linspace(0, 2000, 4096))[:, None]
+    im[:, -128:] *= 2.0
+    for x in range(4224):
+        im[:, x] += np.sin(0.1 * x) * np.sin(np.linspace(0, 2000, 4096)) ** 3
+    im[:, :-128] += 1.0
+    return im
+
+
+REFPIX_VARIANTS = {
+    # tag: (function, keyword arguments of the reference's call)
+    "row_refout_fit": ("row", dict(use_ref_channel=True, slope=None)),
+    "row_border_pyfloat": ("row", dict(use_ref_channel=False, slope=0.7)),
+    "row_refout_f32": ("row", dict(use_ref_channel=True, slope=np.float32(0.83))),
+    "chan_32": ("chan", dict()),
+    "chan_window": ("chan", dict(channel_start=4, channel_end=124, use_ref_channel=True)),
+    "chan_overlap": ("chan", dict(channel_start=0, channel_end=192, use_ref_channel=False)),
+}
+
+
+@pytest.mark.parametrize("tag", list(REFPIX_VARIANTS) + ["test_row"])
+def test_refpix_variants(tag):
+    """ref_subtraction_row / ref_subtraction_channel with the arguments calibrateimage does not use, and the image of the
+    reference's own unit test (test_ref.py) with its assertions"""
+    g = load_golden("refpix_variants")
+    if tag == "test_row":
+        im = reference_test_row_image()
+        old_std = np.std(im)
+        im, _, _ = refpix.row_step(im, 4096, False, None)
+        assert np.std(im) < 0.75 * old_std and 0.4 < np.std(im[:, :-128]) < 0.5 and 0.99 < np.mean(im[:, :-128]) < 1.01
+    else:
+        kind, kw = REFPIX_VARIANTS[tag]
+        im = _refpix_variants_base(int(g["seed"]))
+        if kind == "row":
+            im, _, _ = refpix.row_step(im, 4096, kw["use_ref_channel"], kw["slope"])
+        else:
+            im, _ = refpix.channel_step(im, 4096, kw.get("use_ref_channel", False), kw.get("channel_start", 0),
+                                        kw.get("channel_end", 128))
+    assert_same_bits(im[::257], g[f"{tag}_rows"], f"{tag}: sampled rows")
+    assert hashlib.sha256(im.tobytes()).hexdigest() == str(g[f"{tag}_sha256"])
+
+
+JD_TRUNC = [("rampfit_g8", 4), ("rampfit_g8", 6), ("rampfit_g8", 8), ("rampfit_g8_include_first", 3),
+            ("rampfit_g8_include_first", 7), ("rampfit_g16", 5), ("rampfit_g16", 12)]
+
+
+@pytest.mark.parametrize("name,t", JD_TRUNC)
+def test_jump_detect_truncated(name, t):
+    """fitting.jump_detect(truncate_ramp=t): two-point weights over groups [0, t) (fitting.py:162-167)"""
+    g, gt = load_golden(name), load_golden("jump_detect_trunc")
+    rp = json.loads(str(g["read_pattern"]))
+    ef = bool(g["exclude_first"])
+    meta = rampfit.ma_table_meta(rp, synth.FRAME_TIME)
+    meta["nborder"] = 4
+    meta["K"] = rampfit.construct_weights(0.4 / 1.8 / 6.5**2, meta, ef)
+    loc = np.zeros_like(g["groupdq"])
+    s, er, ep, smap = rampfit.fit_and_flag(g["data"], loc, g["gain"], g["read"], meta, 4, ef, t, None)
+    for k, v in (("slope", s), ("err_read", er), ("err_poisson", ep), ("smap", smap), ("flags", loc)):
+        assert_same_bits(v, gt[f"{name}_t{t}_{k}"], f"{name} truncate {t}: {k}")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree is only present in the build container")
+def test_golden_recipe_reproduces_the_fixtures():
+    """tools/make_goldens.py --check on the fast cases, several of them in ONE process (the cases that execute reference
+    scripts leave stand-in packages in sys.modules, which the recipe now restores): regenerated arrays == committed ones."""
+    import subprocess
+    import sys
+    cases = ["weights", "lin_known_answer", "flat", "il_example", "pearson", "noise1f", "jump_detect_trunc"]
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "make_goldens.py"), "--check"] + cases,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert "identical" in out.stdout.splitlines()[-1]

@@ -12,7 +12,11 @@ replaced by in-memory stand-ins before import:
                                        (bit values: SURVEY.md Appendix C).
 Inputs come from ``tests/golden_cases.py``; fixtures store inputs AND outputs.
 
-Usage:  python tools/make_goldens.py [case-prefix ...]
+Usage:  python tools/make_goldens.py [--check] [--out DIR] [case ...]
+  no case            every case, in one process (each case leaves sys.modules as it found it)
+  --out DIR          write the fixtures there instead of tests/golden/
+  --check            regenerate into a scratch directory and compare with tests/golden/ array by array (names, dtypes,
+                     shapes, bytes); exit status 1 on any difference.  tests/test_oracle_golden.py runs it for the fast cases.
 """
 
 import enum
@@ -287,6 +291,70 @@ def case_refpix():
     image = ref_rs.ref_subtraction_row(image, use_ref_channel=False)
     save("refpix_row_polyfit", seed=53, image_sha256=hashlib.sha256(image.tobytes()).hexdigest(),
          sample_rows=image[::257].copy())
+
+
+def ref_test_row_image():
+    """the artificial image of the reference's own unit test (tests/romanimpreprocess/test_ref.py:10-15), rebuilt here"""
+    im = np.zeros((4096, 4224), dtype=np.float32)
+    im[:, :] = np.cos(np.linspace(0, 2000, 4096))[:, None]
+    im[:, -128:] *= 2.0
+    for x in range(4224):
+        im[:, x] += np.sin(0.1 * x) * np.sin(np.linspace(0, 2000, 4096)) ** 3
+    im[:, :-128] += 1.0
+    return im
+
+
+def case_refpix_variants():
+    """ref_subtraction_row / ref_subtraction_channel with the arguments calibrateimage does not use: border-pixel medians,
+    fitted slope, a Python-float slope (float32 update under numpy's promotion), 32 channels, shifted / narrowed windows.
+    Full 4096 x 4224 frames regenerated from the seed; outputs reduced to hashes + sampled rows."""
+    c = gc.refpix_fullframe_inputs(54)
+    n = 4096
+    base = np.zeros((n, n + 128), dtype=np.float32)
+    base[:, :n] = c["data"] - c["dark"]
+    base[:, -128:] = c["amp33"] - c["med"]
+    base[:, -128:] -= np.median(base[:, -128:])
+    out = {"seed": 54}
+
+    def keep(tag, image):
+        out[f"{tag}_sha256"] = hashlib.sha256(image.tobytes()).hexdigest()
+        out[f"{tag}_rows"] = image[::257].copy()
+
+    keep("row_refout_fit", ref_rs.ref_subtraction_row(base.copy(), use_ref_channel=True))               # slope=None
+    keep("row_border_pyfloat", ref_rs.ref_subtraction_row(base.copy(), use_ref_channel=False, slope=0.7))
+    keep("row_refout_f32", ref_rs.ref_subtraction_row(base.copy(), use_ref_channel=True, slope=np.float32(0.83)))
+    keep("chan_32", ref_rs.ref_subtraction_channel(base.copy()))                                        # defaults
+    keep("chan_window", ref_rs.ref_subtraction_channel(base.copy(), channel_start=4, channel_end=124, use_ref_channel=True))
+    keep("chan_overlap", ref_rs.ref_subtraction_channel(base.copy(), channel_start=0, channel_end=192, use_ref_channel=False))
+    # the reference's own unit test image: its assertions are re-run in the tests, the output is pinned here
+    im = ref_test_row_image()
+    old_std = float(np.std(im))
+    ref_rs.ref_subtraction_row(im, use_ref_channel=False)
+    assert np.std(im) < 0.75 * old_std and 0.4 < np.std(im[:, :-128]) < 0.5 and 0.99 < np.mean(im[:, :-128]) < 1.01
+    keep("test_row", im)
+    save("refpix_variants", **out)
+
+
+def case_jump_detect_trunc():
+    """fitting.jump_detect with truncate_ramp (fitting.py:162-167: two-point weights) on the inputs of rampfit_g8 /
+    rampfit_g8_include_first / rampfit_g16; outputs only (the inputs are those fixtures')."""
+    u_def = 0.4 / 1.8 / 6.5**2
+    out = {}
+    for name, rp, seed, ef, truncs in (("rampfit_g8", synth.READ_PATTERN_8, 31, True, (4, 6, 8)),
+                                       ("rampfit_g8_include_first", synth.READ_PATTERN_8, 34, False, (3, 7)),
+                                       ("rampfit_g16", synth.READ_PATTERN_16, 33, True, (5, 12))):
+        c = gc.rampfit_case(rp, seed, exclude_first=ef, gain_dtype=np.float32)
+        meta = ref_meta(rp, synth.FRAME_TIME)
+        meta["nborder"] = 4
+        meta["K"] = ref_fit.construct_weights(u_def, meta, exclude_first=ef)
+        caldir = {"gain": register(f"/mem/jdt_{name}_gain.asdf", {"data": c["gain"]}),
+                  "read": register(f"/mem/jdt_{name}_read.asdf", {"data": c["read"]})}
+        for t in truncs:
+            loc = np.zeros_like(c["groupdq"])
+            s, er, ep, smap = ref_fit.jump_detect(c["data"], loc, c["pixeldq"].copy(), meta, caldir, _Log(), ef, truncate_ramp=t)
+            out[f"{name}_t{t}_slope"], out[f"{name}_t{t}_err_read"], out[f"{name}_t{t}_err_poisson"] = s, er, ep
+            out[f"{name}_t{t}_smap"], out[f"{name}_t{t}_flags"] = smap, loc
+    save("jump_detect_trunc", **out)
 
 
 def case_chain():
@@ -784,10 +852,76 @@ CASES = {
     "weights": case_weights, "rampfit": case_rampfit, "flat": case_flat, "refpix": case_refpix,
     "chain": case_chain, "post": case_post, "harness": case_harness, "il": case_il, "il_example": case_il_example,
     "pearson": case_pearson, "noise1f": case_noise1f, "l1sim": case_l1sim,
+    "refpix_variants": case_refpix_variants, "jump_detect_trunc": case_jump_detect_trunc,
 }
 
-if __name__ == "__main__":
-    want = sys.argv[1:] or list(CASES)
-    for k in want:
-        print(k)
+
+def run_case(k):
+    """One case with sys.modules restored afterwards: the cases that EXECUTE reference scripts put stand-in packages
+    (romanimpreprocess.L1_to_L2, ...) there, which a later import of the real sub-packages would trip over."""
+    before = dict(sys.modules)
+    try:
         CASES[k]()
+    finally:
+        for name in list(sys.modules):
+            if name not in before:
+                del sys.modules[name]
+            elif sys.modules[name] is not before[name]:
+                sys.modules[name] = before[name]
+        for name, mod in before.items():
+            sys.modules.setdefault(name, mod)
+
+
+def compare_dirs(new, old, names):
+    """array-by-array comparison of the fixtures `names` (file stems); returns the list of differences"""
+    diffs = []
+    for stem in names:
+        a_path, b_path = os.path.join(new, stem + ".npz"), os.path.join(old, stem + ".npz")
+        if not os.path.exists(b_path):
+            diffs.append(f"{stem}: not in {old}")
+            continue
+        with np.load(a_path, allow_pickle=False) as a, np.load(b_path, allow_pickle=False) as b:
+            if sorted(a.files) != sorted(b.files):
+                diffs.append(f"{stem}: arrays {sorted(set(a.files) ^ set(b.files))} on one side only")
+            for key in sorted(set(a.files) & set(b.files)):
+                x, y = a[key], b[key]
+                if x.dtype != y.dtype or x.shape != y.shape or x.tobytes() != y.tobytes():
+                    diffs.append(f"{stem}[{key}]: {x.dtype}{x.shape} vs {y.dtype}{y.shape}, contents differ")
+    return diffs
+
+
+def main(argv):
+    global OUT
+    args = list(argv)
+    check = "--check" in args
+    if check:
+        args.remove("--check")
+    if "--out" in args:
+        i = args.index("--out")
+        OUT = os.path.abspath(args[i + 1])
+        del args[i:i + 2]
+    unknown = [k for k in args if k not in CASES]
+    if unknown:
+        raise SystemExit(f"unknown case(s) {unknown}; known: {' '.join(CASES)}")
+    want = args or list(CASES)
+    golden = os.path.join(REPO, "tests", "golden")
+    if check:
+        import tempfile
+        OUT = tempfile.mkdtemp(prefix="goldens_check_")
+    for k in want:
+        print(k, flush=True)
+        run_case(k)
+    if check:
+        import shutil
+        made = sorted(f[:-4] for f in os.listdir(OUT) if f.endswith(".npz"))
+        diffs = compare_dirs(OUT, golden, made)
+        shutil.rmtree(OUT, ignore_errors=True)
+        for d in diffs:
+            print("DIFFERENT", d)
+        print(f"checked {len(made)} fixture(s) of {len(want)} case(s): {'%d difference(s)' % len(diffs) if diffs else 'identical'}")
+        return 1 if diffs else 0
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
