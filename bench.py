@@ -65,6 +65,18 @@ def alg_bytes(G, ny, nx, nb, nplanes, gain_size=4, ipc_size=4, data_size=2):
     return inputs + outputs, per_kernel
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) of the sources the fused kernel is compiled from: a committed PMC profile is quoted in the
+    bench line only while it belongs to the kernel that ran."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("chain2_kernel.h", "chain_kernel.h", "device_rampfit.h", "rip_common.h", "Makefile"):
+        with open(os.path.join(REPO, "romanimpreprocess_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 # --------------------------------------------------------------------------------------------- CPU baseline
 def _cpu_info():
     model = platform.processor() or ""
@@ -108,21 +120,72 @@ def _cpu_strip(cal, ramp, rows, timings=None):
     return frac, dt, rows + 2 * nb
 
 
-def cpu_baseline(cal, ramp, target_s=7.0):
+def cpu_baseline(cal, ramp, target_s=4.0, repeats=3):
     """numpy oracle (bit-identical to the reference by tests/golden) on a strip of the same ramp sized for about
-    `target_s` seconds of single-thread CPU work (a 128-row probe first, then the sized sample)."""
+    `target_s` seconds of CPU work (a 128-row probe first, then the sized sample), best of `repeats`: once with the
+    thread variables of numpy's libraries as they are (normally unset), once in a child process with them set to 1."""
     ny = ramp["data"].shape[1]
     probe = _cpu_strip(cal, ramp, min(128, ny - 8))
     per_row = probe[1] / probe[2]
     rows = int(max(128, min(ny - 8, target_s / per_row)))
-    stages = {}
-    frac, dt, nrows = _cpu_strip(cal, ramp, rows, timings=stages)
+    best = None
+    times = []
+    for _ in range(repeats):
+        stages = {}
+        frac, dt, nrows = _cpu_strip(cal, ramp, rows, timings=stages)
+        times.append(dt)
+        if best is None or dt < best[1]:
+            best = (frac, dt, nrows, stages)
+    frac, dt, nrows, stages = best
     out = {"value": frac / dt, "unit": "ramps/s", "cores": 1, "kind": "port",
            "sample": f"{nrows}x{ramp['data'].shape[2]}x{ramp['data'].shape[0]} strip of the same ramp "
-                     f"({frac:.4f} ramp) through the numpy oracle, {dt:.1f} s, single thread",
+                     f"({frac:.4f} ramp) through the numpy oracle, best of {repeats} ({', '.join(f'{t:.2f}' for t in times)} s), "
+                     f"thread variables as found (see threads_env)",
            "per_stage_s_per_ramp": {k: v / frac for k, v in stages.items()}}
     out.update(_cpu_info())
+    out["threads_1"] = cpu_threads_one(nrows - 8, ramp["data"].shape[0], repeats)
     return out
+
+
+def _one_thread_worker(args):
+    rows, groups, repeats = args
+    import numpy as _np
+
+    import oracle
+    from romanimpreprocess_amd import synth
+
+    rp = synth.READ_PATTERN_8 if groups == 8 else synth.READ_PATTERN_16
+    cal = synth.make_caldir(rows + 8, 4096, read_pattern=rp, p_order=8, seed=1777)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=77)
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        with _np.errstate(all="ignore"):
+            oracle.calibrate_arrays(ramp, cal)
+        ts.append(time.perf_counter() - t0)
+    return ts
+
+
+def cpu_threads_one(rows, groups, repeats):
+    """the same oracle on a numpy-made strip of the same size in a child process started with OMP / OPENBLAS / MKL_NUM_THREADS = 1"""
+    import multiprocessing as mp
+
+    names = ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")
+    saved = {k: os.environ.get(k) for k in names}
+    try:
+        os.environ.update({k: "1" for k in names})
+        with mp.get_context("spawn").Pool(1) as pool:
+            ts = pool.map(_one_thread_worker, [(rows, groups, repeats)])[0]
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    frac = (rows + 8) / 4096.0
+    return {"value": frac / min(ts), "unit": "ramps/s", "cores": 1,
+            "sample": f"{rows + 8}x4096x{groups} numpy-made strip ({frac:.4f} ramp), best of {repeats} "
+                      f"({', '.join(f'{t:.2f}' for t in ts)} s), OMP/OPENBLAS/MKL_NUM_THREADS=1"}
 
 
 def _replica_worker(args):
@@ -144,7 +207,7 @@ def _replica_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_replicas(rows, groups, p_order, ipc64, max_procs=16):
+def cpu_replicas(rows, groups, p_order, ipc64, max_procs=16):   # 16 = the CPU share of a one-GPU box of the pool
     """The same oracle as independent single-thread processes, one strip each, started together: ramps/s of C host cores
     (numpy's elementwise work does not thread, so this is what the host can do with the reference's kind of code)."""
     import multiprocessing as mp
@@ -445,16 +508,19 @@ def main():
         # HBM traffic of the dominant kernel: PMC measurement of the SAME command, committed under profiles/ (not measured by
         # this run: counters need rocprofv3); null when no profile of this configuration and kernel build is there
         traffic, traffic_source = None, None
-        for tag in ("r02", "r01"):
-            tpath = os.path.join(REPO, "profiles", f"{tag}_hbm_traffic.json")
-            if dom == "chain_fused" and (G, N, args.p_order, args.ipc_dtype, args.workload) == (8, 4096, 8, "f32", "single") \
-                    and os.path.exists(tpath):
-                with open(tpath) as tf:
-                    tj = json.load(tf)
+        tpath = os.path.join(REPO, "profiles", "r03_hbm_traffic.json")
+        if dom == "chain_fused" and (G, N, args.p_order, args.ipc_dtype, args.workload) == (8, 4096, 8, "f32", "single") \
+                and os.path.exists(tpath):
+            with open(tpath) as tf:
+                tj = json.load(tf)
+            if tj.get("kernel_source_sha16") == kernel_source_hash():
                 traffic = tj.get("traffic_bytes_per_launch")
-                traffic_source = (f"profiles/{tag}_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                  f"(tools/profile_round.sh), kernel {tj.get('kernel')}; not re-measured by this run")
-                break
+                traffic_source = ("profiles/r03_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                  f"(tools/profile_round.sh), kernel {tj.get('kernel')}, kernel sources {tj.get('kernel_source_sha16')}; "
+                                  "not re-measured by this run")
+            else:
+                traffic_source = ("profiles/r03_hbm_traffic.json belongs to other kernel sources "
+                                  f"({tj.get('kernel_source_sha16')} != {kernel_source_hash()}): traffic not quoted")
         out = {
             "metric": "SCA ramps/sec (4096x4096x8grp full L1->L2 chain)" if (G, N) == (8, 4096) else f"SCA ramps/sec ({N}x{N}x{G}grp full L1->L2 chain)",
             "value": world * args.steps / elapsed,

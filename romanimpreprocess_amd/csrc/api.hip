@@ -141,7 +141,7 @@ void rip_ctx_destroy(rip_ctx *ctx) {
             delete p;
         }
     rip_pink_release(ctx);
-    for (hipEvent_t e : {ctx->ev_tab[0], ctx->ev_tab[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_in})
+    for (hipEvent_t e : {ctx->ev_tab[0], ctx->ev_tab[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_in, ctx->ev_pre})
         if (e) (void)hipEventDestroy(e);
     for (void *p : ctx->ws)   // every workspace slot, the Level-1 synthesis ones included
         if (p) (void)hipFree(p);
@@ -735,6 +735,18 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         d_pdq = p2;
         return rcs;
     };
+    // pre-passes of consecutive calls share workspaces: one that runs on another stream than its predecessor waits for it
+    auto pre_order = [&]() -> int {
+        if (ctx->ev_pre_valid && ctx->pre_stream != ctx->stream) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pre, 0));
+        return RIP_OK;
+    };
+    auto pre_done = [&]() -> int {
+        if (!ctx->ev_pre) RIP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pre, hipEventDisableTiming));
+        RIP_HIP(ctx, hipEventRecord(ctx->ev_pre, ctx->stream));
+        ctx->pre_stream = ctx->stream;
+        ctx->ev_pre_valid = true;
+        return RIP_OK;
+    };
     if (do_ref) {
         if (nx % RIP_CW) return rip_fail(ctx, RIP_EINVAL, "calibrate: nx=%d is not a multiple of 128", nx);
         if (!ws3) return RIP_ENOMEM;
@@ -760,8 +772,10 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
             ctx->stream = ctx->stream2;
         }
         mark();
-        rc = rip_launch_refpix_prepass(ctx, ra);
+        rc = pre_order();   // (no early return here: ctx->stream may be the second stream at this point)
+        if (!rc) rc = rip_launch_refpix_prepass(ctx, ra);
         if (!rc && do_sat) rc = sat_pass();  // same stream as the pre-pass: overlaps the previous ramp's main kernel
+        if (!rc) rc = pre_done();
         mark();
         if (overlap) {
             if (!rc) {
@@ -775,7 +789,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         if (rc) return rc;
     } else {
         mark();
-        if (do_sat && (rc = sat_pass())) return rc;
+        if (do_sat && ((rc = pre_order()) || (rc = sat_pass()) || (rc = pre_done()))) return rc;
         mark();
     }
     mark();

@@ -101,12 +101,7 @@ __device__ __forceinline__ uint32_t c2_ld_u8(__amdgpu_buffer_rsrc_t r, unsigned 
 // when the ingest role requests the IPC coefficients of the row whose first iterate follows the half-step barrier: 1 = at
 // the top of the step (landed by the barrier), 0 = at the end of the first half (ten registers fewer during A)
 #ifndef C2_KEARLY
-#define C2_KEARLY 1
-#endif
-// where the fit role reads the dense per-plan table of the jump test from: 1 = a copy staged in LDS (in-order returns, counted
-// waits), 0 = the device copy through scalar loads (every wait an lgkmcnt(0) round trip, eight per row step)
-#ifndef C2_FITLDS
-#define C2_FITLDS 1
+#define C2_KEARLY 0   // same-box A/B (profiles/r03_summary.md): 0.949 (early) against 0.945 ms -- the latency is not on the critical path
 #endif
 __device__ __forceinline__ int c2_xcd_block(int b, int n) {
 #if C2_XCD
@@ -174,7 +169,6 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
     f2 *KR2 = reinterpret_cast<f2 *>(LN + 3 * G * 2);               // f32 ipc4d: [2][4][C2_COLS] pairs (k0,k1)..(k6,k7)
     float *KR1 = reinterpret_cast<float *>(KR2 + 2 * 4 * C2_COLS);  //            [2][C2_COLS] k8
     double *KRd = reinterpret_cast<double *>(LN + 3 * G * 2);       // f64 ipc4d: [2][9][C2_COLS]
-    C3FitTab *const FT = reinterpret_cast<C3FitTab *>(KRd + (size_t)2 * 9 * C2_COLS * sizeof(KT) / 8);  // dense fit table
 
     // ChainArgs is the first kernel argument: it sits at offset 0 of the kernarg segment
     const RIP_K C2KernArgs *kargs = (const RIP_K C2KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -219,21 +213,6 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         const int ch = i / (G * 2), g = (i / 2) % G, w = i & 1;
         LN[i] = (ch0 + ch < nch) ? a.lines[(g * nch + ch0 + ch) * 2 + w] : 0.0;
     }
-#if C2_FITLDS
-    for (int i = tid; i < (int)(sizeof(C3FitTab) / 4); i += C2_THREADS) {
-        uint32_t v = 0;
-        constexpr int o_pairs = C3_MAXG, o_amin = o_pairs + C3_MAXG * 8;
-        if (i < o_pairs)
-            v = __float_as_uint(a.dense->K2[i]);
-        else if (i < o_amin)
-            v = reinterpret_cast<const uint32_t *>(a.dense->pairs)[i - o_pairs];
-        else if (i == o_amin)
-            v = __float_as_uint(a.dense->amin);
-        else if (i == o_amin + 1)
-            v = a.dense->valid;
-        reinterpret_cast<uint32_t *>(FT)[i] = v;
-    }
-#endif
     __syncthreads();
 
     // Addressing: every global access is (wave-uniform 64-bit base: array + plane + row, scalar ALU) + (per-lane
@@ -357,7 +336,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         // =========================================================================== ingest waves
         // plane p of the calibration slab at row yl: scalar offset p*pl4 + yl*row4; groups likewise in their arrays
         auto fetch_groups = [&](const RIP_K ChainArgs *ka, int y, int g0, int g1, RowRegs<NP, G> &rr) {
-            if (dbg & 64) return;
+            if ((dbg & 64) && y > R0 - 2) return;   // timing experiment: every row works on the first row's (valid) values
             __builtin_amdgcn_sched_barrier(0);
             const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
             const __amdgpu_buffer_rsrc_t rs = c2_rsrc(ka->data), rq = c2_rsrc(ka->gdq), rd = c2_rsrc(ka->dark_data),
@@ -378,7 +357,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         };
         // planes i0..i1-1 of [cf[0..NP-1], Smin, Smax, Sref, dq, gain]
         auto fetch_coefs = [&](const RIP_K ChainArgs *ka, int y, int i0, int i1, RowRegs<NP, G> &rr) {
-            if (dbg & 64) return;
+            if ((dbg & 64) && y > R0 - 2) return;
             __builtin_amdgcn_sched_barrier(0);
             const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
             const __amdgpu_buffer_rsrc_t rp = c2_rsrc(ka->planes);
@@ -694,10 +673,6 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         const RipVariant v0 = rip_load_variant(vars, 0);
         const RipFitConst fc0 = rip_fit_const(h);
         constexpr int start = START;  // first group of the fit (exclude_first)
-#if C2_FITLDS
-        C2DenseLds<G> dtab;
-        dtab.t = FT;
-#endif
         float gain_next = 1.0f;
         int o0_r = (R0 - 5 + 3000) % 3;  // O1 ring slot of row r
         for (int r = R0 - 5; r <= R1; ++r, o0_r = (o0_r == 2) ? 0 : o0_r + 1) {
@@ -708,19 +683,20 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             // ---- S1: read noise of the pixel (used by the fit), then the second IPC iterate of row r
             const __amdgpu_buffer_rsrc_t rpl = c2_rsrc(kf->a.planes);
             const unsigned t_row = rc_ * row4;  // byte offset of row r in an f32 plane (uniform)
-            const float e_read = c2_ld_f32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 5) * pl4 + t_row);
+            const unsigned t_ld = (dbg & 256) ? 0u : t_row;   // timing experiment: the fit role's loads all hit row 0 (cached)
+            const float e_read = c2_ld_f32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 5) * pl4 + t_ld);
             const float e_gain = gain_next;
             // calibration planes of the tail (finish) of the same pixel, consumed after the barrier
             const size_t t_row4 = (size_t)t_row;
             const size_t pe_row = (size_t)(rc_ * (unsigned)nx);   // element offset of row r
-            const float e_dark = c2_ld_f32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_row);
-            const uint32_t e_ff = c2_ld_u32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 8) * pl4 + t_row);
-            const uint32_t e_pdq = c2_ld_u32<C2_NT_F>(c2_rsrc(kf->a.pdq), cc4, t_row);
+            const float e_dark = c2_ld_f32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_ld);
+            const uint32_t e_ff = c2_ld_u32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 8) * pl4 + t_ld);
+            const uint32_t e_pdq = c2_ld_u32<C2_NT_F>(c2_rsrc(kf->a.pdq), cc4, t_ld);
             // flat / dark_dq == null: read the first slab plane instead (value unused), keeps the loads in one block
-            const float e_flat_raw = c2_ld_f32<C2_NT_F>(c2_rsrc(kf->a.flat ? (const void *)kf->a.flat : (const void *)kf->a.planes), cc4, t_row);
+            const float e_flat_raw = c2_ld_f32<C2_NT_F>(c2_rsrc(kf->a.flat ? (const void *)kf->a.flat : (const void *)kf->a.planes), cc4, t_ld);
             const float e_flat = kf->a.flat ? e_flat_raw : 1.0f;
             const uint32_t e_ddq_raw =
-                c2_ld_u32<C2_NT_F>(c2_rsrc(kf->a.dark_dq ? (const void *)kf->a.dark_dq : (const void *)kf->a.planes), cc4, t_row);
+                c2_ld_u32<C2_NT_F>(c2_rsrc(kf->a.dark_dq ? (const void *)kf->a.dark_dq : (const void *)kf->a.planes), cc4, t_ld);
             const uint32_t e_ddq = kf->a.dark_dq ? e_ddq_raw : 0u;
             float d[G];
             f2 dpair[GP];
@@ -843,21 +819,16 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 }
                 // first half of the ramp fit (registers only): slope, errors, approximate jump significances
                 const bool unsat = ((qw[(G - 1) / 4] >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
-                if (!(dbg & 4)) {
-#if C2_FITLDS
-                    fit_full_pk_a_t<G, rip_full_valid<G, START>(), C2DenseLds<G>>(dpair, fc0, v0, dtab, e_gain, e_read, unsat && act,
-                                                                                  kf->guard, fs);
-#else
+                if (!(dbg & 4))
                     fit_full_pk_a<G, rip_full_valid<G, START>()>(dpair, fc0, v0, kf->a.dense, e_gain, e_read, unsat && act, kf->guard, fs);
-#endif
-                }
             }
             CH_T(2)
             C2_SYNC();
             CH_T(3)
             const RIP_K C2KernArgs *kg = c2_args(kargs);  // S2 copy
             // ---- S2: coefficients and gain of the next row's O2, second half of the fit, tail of pixel (r, c)
-            gain_next = c2_ld_f32<C2_NT_F>(c2_rsrc(kg->a.planes), cc4, (unsigned)(NP + 4) * pl4 + (unsigned)min(max(r + 1, 0), ny - 1) * row4);
+            gain_next = c2_ld_f32<C2_NT_F>(c2_rsrc(kg->a.planes), cc4,
+                                          (unsigned)(NP + 4) * pl4 + ((dbg & 256) ? 0u : (unsigned)min(max(r + 1, 0), ny - 1) * row4));
             CH_T(4)
             C2_DRAIN()
             CH_T(5)
@@ -890,7 +861,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 }
                 // ---- T: flag propagation (fitting.py:339-353), finish and stores of pixel (r, c)
                 if (!(dbg & 8)) {
-                    uint8_t *gq = kg->a.gdq_out ? kg->a.gdq_out + pe_row : nullptr;
+                    uint8_t *gq = (kg->a.gdq_out && !(dbg & 512)) ? kg->a.gdq_out + pe_row : nullptr;
                     uint32_t pdq = propagate_flags_packed<G>(qw, jmask, start, e_pdq | lin_dq, gq, npix, c2_opaque(cc1));
                     if (kg->a.finish) {
                         // gen_cal_image.py:458-475, 213-229, 607-629.  One wave vote selects the straight-line form built
@@ -935,10 +906,13 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                         }
                     }
                     const unsigned w4 = c2_opaque(cc4);
-                    *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.slope) + t_row4 + w4) = s;
-                    *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_read) + t_row4 + w4) = er;
-                    *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_poisson) + t_row4 + w4) = ep;
-                    *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kg->a.pdq_out) + t_row4 + w4) = pdq;
+                    // (dbg & 512: timing experiment without the plane stores; the test keeps the four values live)
+                    if (!(dbg & 512) || (s + er + ep == 12345.678f && pdq == 0xdeadbeefu)) {
+                        *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.slope) + t_row4 + w4) = s;
+                        *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_read) + t_row4 + w4) = er;
+                        *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_poisson) + t_row4 + w4) = ep;
+                        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kg->a.pdq_out) + t_row4 + w4) = pdq;
+                    }
                 }
             }
             // x of (r + 1, own column) for the next step's O2: its ring slot is overwritten in S1 of that step (row r + 4)
@@ -963,7 +937,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
 static inline size_t chain2_lds_bytes(int G, size_t ksize = 4) {
     // x ring (3 rows) + O1 ring (3 rows) + linearity dq / packed groupdq rings (4 rows) + channel lines + K ring (2 rows)
     return (size_t)(G / 2) * C2_COLS * 8 * 3 + (size_t)G * C2_COLS * ksize * 3 + (size_t)C2_COLS * 4 * 4 * (1 + (G + 3) / 4) +
-           (size_t)3 * G * 2 * 8 + (size_t)2 * 9 * C2_COLS * ksize + sizeof(C3FitTab);
+           (size_t)3 * G * 2 * 8 + (size_t)2 * 9 * C2_COLS * ksize;
 }
 
 template <int NP, int G, int START, typename KT = float>

@@ -412,22 +412,6 @@ struct C3DenseLds {
     }
 };
 
-// the same with the slope weights read from the table too (no loop-invariant scalar registers at all)
-template <int G>
-struct C2DenseLds {
-    const C3FitTab *t;
-    __device__ __forceinline__ float k2(int i) const { return t->k2[i]; }
-    __device__ __forceinline__ uint32_t valid() const { return t->valid; }
-    __device__ __forceinline__ float amin() const { return t->amin; }
-    __device__ __forceinline__ void pair(RipDensePair &r, int ps) const {
-        typedef float f4_ __attribute__((ext_vector_type(4)));
-        const f4_ *p = reinterpret_cast<const f4_ *>(&t->pairs[ps]);
-        const f4_ a = p[0], b = p[1];
-        r.inv_dt[0] = a[0], r.inv_dt[1] = a[1], r.A[0] = a[2], r.A[1] = a[3];
-        r.B[0] = b[0], r.B[1] = b[1], r.k1[0] = b[2], r.k1[1] = b[3];
-    }
-};
-
 // first half: slope, errors, threshold, approximate significance of every tested difference
 // VALID != 0: the tested differences are known at compile time (no plan-uniform branches: the eight difference
 // slots become one basic block the scheduler can interleave)

@@ -149,6 +149,12 @@ struct rip_ctx {
     // set by the entry points that queue work on `stream` with device pointers (rip_synth_*, rip_stats_*): the next overlapped
     // rip_calibrate then orders its second-stream pre-pass behind that work (it may have produced the call's inputs)
     bool stream_dirty = false;
+    // the pre-pass / saturation pass share workspaces (selection histograms, row tables in the making, exceed bits): when two
+    // consecutive calls run them on different streams (a non-overlapped call between overlapped ones), the later waits for the
+    // earlier through this event
+    hipEvent_t ev_pre = nullptr;
+    hipStream_t pre_stream = nullptr;
+    bool ev_pre_valid = false;
     hipEvent_t ev_in = nullptr;
     int batch_completed = 0;  // of the last rip_calibrate_batch: ramps completed (all of them unless it returned an error)
 };

@@ -682,7 +682,7 @@ def test_inputs_written_by_queued_work_no_sync(producer):
                     ev.record(side)
                 call(got, ready_event=ev.cuda_event)
             else:
-                ext = torch.cuda.ExternalStream(cb.ctx.stream(), device=dev)
+                ext = torch.cuda.ExternalStream(cb.ctx.stream, device=dev)
                 with torch.cuda.stream(ext):
                     for _ in range(20):
                         junk.normal_()

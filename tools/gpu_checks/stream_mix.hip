@@ -18,7 +18,10 @@ struct Args {
     float *o0, *o1, *o2, *o3; uint8_t *gout;
 };
 
-template <int W>
+// L = 0: every array planar (group / plane, row, column), as the caller's arrays and today's CALDIR copies are laid out;
+// L = 1: the CALDIR arrays (dark, bias, the 29 planes) row-interleaved (row, group / plane, column): a row step of a strip then
+//        touches ~45 pieces within one 0.7 MB region instead of 45 regions 67 MB apart (address-translation reach, DRAM pages)
+template <int W, int L>
 __global__ __launch_bounds__(256) void mix_kernel(Args a, int rows_per) {
     const size_t npix = (size_t)N * N;
     const int col = (blockIdx.x % (N / (256 * W))) * 256 * W + threadIdx.x * W;
@@ -32,9 +35,9 @@ __global__ __launch_bounds__(256) void mix_kernel(Args a, int rows_per) {
         if constexpr (W == 1) {
             unsigned s[G], qq[G]; float dk[G], bs[G], pl[NPL];
 #pragma unroll
-            for (int g = 0; g < G; ++g) { s[g] = a.cube[g * npix + p]; qq[g] = a.gdq[g * npix + p]; dk[g] = a.dark[g * npix + p]; bs[g] = a.bias[g * npix + p]; }
+            for (int g = 0; g < G; ++g) { s[g] = a.cube[g * npix + p]; qq[g] = a.gdq[g * npix + p]; dk[g] = a.dark[L ? ((size_t)r * G + g) * N + col : g * npix + p]; bs[g] = a.bias[L ? ((size_t)r * G + g) * N + col : g * npix + p]; }
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) pl[i] = a.planes[i * npix + p];
+            for (int i = 0; i < NPL; ++i) pl[i] = a.planes[L ? ((size_t)r * NPL + i) * N + col : i * npix + p];
 #pragma unroll
             for (int g = 0; g < G; ++g) { acc[0] += (float)s[g] - dk[g] + bs[g]; q[0] |= qq[g] << (g & 3); }
 #pragma unroll
@@ -45,11 +48,11 @@ __global__ __launch_bounds__(256) void mix_kernel(Args a, int rows_per) {
             for (int g = 0; g < G; ++g) {
                 s[g] = *reinterpret_cast<const uint2 *>(a.cube + g * npix + p);
                 qq[g] = *reinterpret_cast<const unsigned *>(a.gdq + g * npix + p);
-                dk[g] = *reinterpret_cast<const float4 *>(a.dark + g * npix + p);
-                bs[g] = *reinterpret_cast<const float4 *>(a.bias + g * npix + p);
+                dk[g] = *reinterpret_cast<const float4 *>(a.dark + (L ? ((size_t)r * G + g) * N + col : g * npix + p));
+                bs[g] = *reinterpret_cast<const float4 *>(a.bias + (L ? ((size_t)r * G + g) * N + col : g * npix + p));
             }
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) pl[i] = *reinterpret_cast<const float4 *>(a.planes + i * npix + p);
+            for (int i = 0; i < NPL; ++i) pl[i] = *reinterpret_cast<const float4 *>(a.planes + (L ? ((size_t)r * NPL + i) * N + col : i * npix + p));
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 acc[0] += (float)(s[g].x & 0xffff) - dk[g].x + bs[g].x; acc[1] += (float)(s[g].x >> 16) - dk[g].y + bs[g].y;
@@ -76,24 +79,58 @@ __global__ __launch_bounds__(256) void mix_kernel(Args a, int rows_per) {
     }
 }
 
+// L = 2: the CALDIR arrays as PLANES OF FLOAT4 (four scalar planes interleaved per pixel): 45 dword streams become 11 streams of
+// 16 bytes per lane -- one contiguous KiB per wave instruction, the float4-copy access shape; the caller's cube / groupdq and
+// the outputs stay planar.  One pixel per lane.
+__global__ __launch_bounds__(256) void quad_kernel(Args a, int rows_per) {
+    const size_t npix = (size_t)N * N;
+    constexpr int NQ = 11;   // 16 dark / bias + 29 planes = 45 words -> 11 float4 planes (44 words: main() allocates exactly that)
+    const int col = (blockIdx.x % (N / 256)) * 256 + threadIdx.x;
+    const int r0 = (blockIdx.x / (N / 256)) * rows_per;
+    const float4 *qp = reinterpret_cast<const float4 *>(a.planes);
+    for (int r = r0; r < r0 + rows_per && r < N; ++r) {
+        const size_t p = (size_t)r * N + col;
+        unsigned s[G], qq[G];
+        float4 q4[NQ];
+#pragma unroll
+        for (int g = 0; g < G; ++g) { s[g] = a.cube[g * npix + p]; qq[g] = a.gdq[g * npix + p]; }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) q4[i] = qp[i * npix + p];
+        float acc = 0.f;
+        unsigned q = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) { acc += (float)s[g]; q |= qq[g] << (g & 3); }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) acc += q4[i].x + q4[i].y + q4[i].z + q4[i].w;
+        a.o0[p] = acc; a.o1[p] = acc * 2.f; a.o2[p] = acc * 3.f; a.o3[p] = __uint_as_float(q);
+#pragma unroll
+        for (int g = 0; g < G; ++g) a.gout[g * npix + p] = (uint8_t)(q >> g);
+    }
+}
+
 int main() {
     const size_t npix = (size_t)N * N;
     Args a;
     void *p;
     auto mk = [&](size_t bytes) { CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 1, bytes)); return p; };
     a.cube = (const uint16_t *)mk(G * npix * 2); a.gdq = (const uint8_t *)mk(G * npix); a.dark = (const float *)mk(G * npix * 4);
-    a.bias = (const float *)mk(G * npix * 4); a.planes = (const float *)mk(NPL * npix * 4);
+    a.bias = (const float *)mk(G * npix * 4);
+    a.planes = (const float *)mk((size_t)44 * npix * 4);   // 29 scalar planes, or the 11 float4 planes of quad_kernel (44 words per pixel)
     a.o0 = (float *)mk(npix * 4); a.o1 = (float *)mk(npix * 4); a.o2 = (float *)mk(npix * 4); a.o3 = (float *)mk(npix * 4);
     a.gout = (uint8_t *)mk(G * npix);
     const double bytes = (double)npix * (G * (2 + 1 + 4 + 4) + NPL * 4 + 16 + G);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int rows_per : {8, 32, 128}) {
-        for (int W : {1, 4}) {
+    for (int rows_per : {8, 128}) {
+        for (int WL : {10, 11, 40, 41}) {
+            const int W = WL / 10, L = WL % 10;
+            if (W == 4 && rows_per == 128) continue;   // 128 blocks: not enough parallelism, measured once (2.3 ms)
             const int strips = N / (256 * W), ranges = (N + rows_per - 1) / rows_per;
             auto launch = [&]() {
-                if (W == 1) hipLaunchKernelGGL(mix_kernel<1>, dim3(strips * ranges), dim3(256), 0, 0, a, rows_per);
-                else hipLaunchKernelGGL(mix_kernel<4>, dim3(strips * ranges), dim3(256), 0, 0, a, rows_per);
+                if (WL == 10) hipLaunchKernelGGL((mix_kernel<1, 0>), dim3(strips * ranges), dim3(256), 0, 0, a, rows_per);
+                if (WL == 11) hipLaunchKernelGGL((mix_kernel<1, 1>), dim3(strips * ranges), dim3(256), 0, 0, a, rows_per);
+                if (WL == 40) hipLaunchKernelGGL((mix_kernel<4, 0>), dim3(strips * ranges), dim3(256), 0, 0, a, rows_per);
+                if (WL == 41) hipLaunchKernelGGL((mix_kernel<4, 1>), dim3(strips * ranges), dim3(256), 0, 0, a, rows_per);
             };
             for (int i = 0; i < 300; ++i) launch();   // warm-up incl. the clock ramp
             CK(hipEventRecord(e0, 0));
@@ -103,9 +140,24 @@ int main() {
             CK(hipEventSynchronize(e1));
             float ms;
             CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("W=%d rows_per=%3d blocks=%6d : %.4f ms per pass, %.2f TB/s (%.0f B/pixel)\n", W, rows_per, strips * ranges, ms / reps,
+            printf("W=%d L=%d rows_per=%3d blocks=%6d : %.4f ms per pass, %.2f TB/s (%.0f B/pixel)\n", W, L, rows_per, strips * ranges, ms / reps,
                    bytes / (ms / reps * 1e-3) / 1e12, bytes / npix);
         }
+    }
+    for (int rows_per : {8, 128}) {
+        const int strips = N / 256, ranges = (N + rows_per - 1) / rows_per;
+        auto launch = [&]() { hipLaunchKernelGGL(quad_kernel, dim3(strips * ranges), dim3(256), 0, 0, a, rows_per); };
+        for (int i = 0; i < 300; ++i) launch();
+        CK(hipEventRecord(e0, 0));
+        const int reps = 200;
+        for (int i = 0; i < reps; ++i) launch();
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double qbytes = (double)npix * (G * 3 + 11 * 16 + 16 + G);
+        printf("quad planes rows_per=%3d blocks=%6d : %.4f ms per pass, %.2f TB/s (%.0f B/pixel) -> %.4f ms at 228 B/pixel\n", rows_per,
+               strips * ranges, ms / reps, qbytes / (ms / reps * 1e-3) / 1e12, qbytes / npix, ms / reps * 228.0 / (qbytes / npix));
     }
     return 0;
 }

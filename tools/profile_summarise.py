@@ -9,7 +9,10 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+sys.path.insert(0, REPO)
+from bench import kernel_source_hash  # noqa: E402  (hash of the fused kernel's sources: bench.py only quotes a matching profile)
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(REPO, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -44,5 +47,6 @@ if dominant:
                          "amp33_rows_kernel (10.5 MB read once expected, FETCH_SIZE reports half).  64-B requests (the u8 groupdq "
                          "loads) may be tallied in full, so the true read traffic lies slightly below 2 x FETCH_SIZE.")
     out["traffic_bytes_per_launch"] = 2.0 * f_b + w_b
+    out["kernel_source_sha16"] = kernel_source_hash()
 json.dump(out, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}, indent=1))
