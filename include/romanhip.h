@@ -278,7 +278,12 @@ int rip_stage_jump_detect(rip_ctx *ctx, int plan_id, const float *data, uint8_t 
 int rip_stage_get_flat(rip_ctx *ctx, const float *flat, int ny, int nx, int nb, const void *gain, int g_dtype,
                        const void *kernel, int k_dtype, int ipc_deconvolve, uint32_t *pdq, float *out);
 
-/* ---- post-path 2-D reductions: between the chain's outputs and the L2 file; host arrays ------ */
+/* ---- post-path 2-D reductions: between the chain's outputs and the L2 file -------------------
+   Array arguments of this section, of the noise-layer section (rip_stage_noise_inject, rip_stage_poisson_resample) and of
+   rip_stage_pearson may be host arrays OR device pointers (each is copied with hipMemcpyDefault): a driver that keeps its
+   planes in HBM (the noise-layer loop, romanimpreprocess_amd/L1_to_L2/gen_noise_image.py) hands them over without a PCIe
+   round trip.  The calls stay synchronous: they return when the result is complete.  Small tables (ranks, counts, Legendre
+   tables, coefficients, weights) are host arrays. */
 
 /* maskhandling.CombinedMask.build (maskhandling.py:82-117): grow[bit] in {0, 1, 5, 9, 25} = how the layer of that dq bit
    is grown (copy, plus, 3x3, 5x5; zero padded); mask (ny,nx) u8 = 1 where masked.  Exact. */
@@ -440,7 +445,9 @@ typedef struct rip_synth_cal {
    (nya,nxa) f32 holds integers, or -- poisson != 0 -- the MEAN, of which a Poisson deviate is drawn first (what
    Image2D.simulate :660-662 adds before it calls make_l1_fullcal).  t_reads: nreads times, HOST array, ascending.
    Deviates from the device generator (Philox; inversion / BTRS binomial, inversion / PTRS Poisson) keyed by (seed, read,
-   pixel).  The distribution is what is reproduced, not romanisim's numpy stream. */
+   pixel).  The distribution is what is reproduced, not romanisim's numpy stream.  Asynchronous like the other rip_synth_*
+   entries when t_reads equals those of the previous call (the device copy of the share table is kept); a NEW table first
+   waits for the work queued on the stream. */
 int rip_synth_apportion(rip_ctx *ctx, const float *counts, int nya, int nxa, int poisson, int nreads, const double *t_reads,
                         uint64_t seed, int32_t *reads_e);
 
@@ -469,6 +476,13 @@ int rip_synth_fill(rip_ctx *ctx, const rip_synth_cal *cal, int ngrp, const int32
 
 /* rip_stage_noise_1f with the frames left on the device: out (nframes,rows,width) f32 DEVICE memory. */
 int rip_synth_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, uint64_t seed, uint32_t stream_id, float *out);
+/* The 1/f frames of the NEXT rip_synth_fill(frames = NULL, banding != 0, the same seed and geometry: rows = ny, width =
+   channelwidth, nframes = ngrp * (nx / channelwidth + 2)) made AHEAD on the context's second stream, so that the Fourier
+   transforms (HBM-bound) run beside the apportioning / inverse-linearity kernels (arithmetic-bound) queued on rip_stream()
+   between this call and the fill: same frames, same bits, 17 ms of a 4096^2 x 8 exposure's 74 ms hidden.  The fill waits for
+   them; a fill with another seed or geometry, or any other 1/f call, waits too and makes its own.  No-op without a second
+   stream. */
+int rip_synth_frames_ahead(rip_ctx *ctx, int rows, int width, int nframes, uint64_t seed);
 
 /* EXTRACT_REF (:711-730) on n-element planes: reference_read = data[0]; data[k] = clip(i32(data[k]) - (i32(data[0]) -
    offset), 0, 65535) for k = 1..ngrp-1, in place (the caller drops plane 0).  Used for the cube and for amp33.  Exact. */

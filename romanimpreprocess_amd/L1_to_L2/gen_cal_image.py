@@ -193,7 +193,9 @@ def calibrateimage(config, verbose=True, calibrator=None):
         "ramp_opt_pars": dict(uopt), "weights": K, "log": mylog.output,
         "config": {k: v for k, v in config.items() if not (k == "IN" and isinstance(v, dict))},
         "exclude_first": bool(exclude_first),
-        "meta": {k: (v if not isinstance(v, np.ndarray) else v) for k, v in meta.items() if k != "read_pattern"},
+        # the full meta, read_pattern included (a list of lists): the reference's noise driver reads it from the L2 file
+        # (gen_noise_image.py:208-212), so files written here can be fed to it
+        "meta": {k: ([list(map(int, g)) for g in v] if k == "read_pattern" else v) for k, v in meta.items()},
     }
     if config.get("SLICEOUT"):
         endslice = sky.endslice(rdq, nb, ctx=cb.ctx)  # raises ValueError("too many groups") for >= 128 groups

@@ -33,6 +33,7 @@ import numpy as np
 from .. import _native, calio, pars
 from ..utils import sky
 from .GalPoisson.draw_with_tilnus import draw_from_Pearson
+from .GalPoisson.draw_with_tilnus import _seed_from as draw_seed
 from .GalPoisson.find_tilnus import get_tilde_nus
 from .gen_cal_image import calibrateimage
 
@@ -104,7 +105,9 @@ def poisson_resample(diff, skylevel, gain, frame_time, read_pattern, weights, ha
     """Adds a resampled-Poisson realisation to ``diff`` (f32, in place; gen_noise_image.py:262-331).  ``gain`` already
     clipped; ``samples`` (nsamp, ny, nx) f64 Poisson deviates of mean clip(skylevel*gain*frame_time, 0) or None (device)."""
     ctx = ctx or _native.default_context()
-    if not (isinstance(diff, np.ndarray) and diff.dtype == np.float32 and diff.flags.c_contiguous):
+    from ..devarray import is_dev   # every array may be a DevArray (resident in HBM): the entry point takes either kind of pointer
+
+    if not ((isinstance(diff, np.ndarray) or is_dev(diff)) and diff.dtype == np.float32 and diff.flags.c_contiguous):
         raise TypeError("diff must be a C-contiguous float32 array (updated in place)")
     ngrp = len(read_pattern)
     first = np.array([g[0] for g in read_pattern], dtype=np.int32)
@@ -113,13 +116,17 @@ def poisson_resample(diff, skylevel, gain, frame_time, read_pattern, weights, ha
         if list(g) != list(range(g[0], g[0] + len(g))):
             raise ValueError("groups must hold consecutive reads")
     nsamp = int(read_pattern[-1][-1]) + 1
-    sky_ = np.ascontiguousarray(skylevel, dtype=np.float32)
-    g_ = np.ascontiguousarray(gain)
+    sky_ = skylevel if is_dev(skylevel) else np.ascontiguousarray(skylevel, dtype=np.float32)
+    g_ = gain if is_dev(gain) else np.ascontiguousarray(gain)
     if g_.dtype not in (np.float32, np.float64):
         g_ = g_.astype(np.float64)
+    if sky_.dtype != np.float32 or sky_.size != diff.size or g_.size != diff.size:
+        raise ValueError("skylevel (float32) and gain must have the shape of diff")
     w = np.ascontiguousarray(weights, dtype=np.float32)
     hw = np.ascontiguousarray(has_weights, dtype=np.uint8)
-    es = np.ascontiguousarray(endslice, dtype=np.int8)
+    es = endslice if is_dev(endslice) else np.ascontiguousarray(endslice, dtype=np.int8)
+    if es.dtype != np.int8 or es.size != diff.size:
+        raise ValueError("endslice must be int8 of the shape of diff")
     if samples is not None:
         samples = np.ascontiguousarray(samples, dtype=np.float64)
         if samples.shape != (nsamp,) + diff.shape:
@@ -150,10 +157,196 @@ class _Files:
         return self.tree(src)["roman"]
 
 
+def _device_path_applies(config, rng):
+    """The HBM-resident layer loop runs when the exposures stay in memory, the deviates are the device's and nothing asks for a
+    host-side ingredient (pixel-area map)."""
+    if not bool(config["NOISE"].get("IN_MEMORY", True)) or not bool(config["NOISE"].get("DEVICE_RESIDENT", True)):
+        return False
+    if isinstance(rng, np.random.Generator) or "AREAFACTOR" in config or not config["NOISE"].get("CORRELATED", True):
+        return False
+    return "saturation" in config["CALDIR"]
+
+
+def _make_noise_cube_device(config, seed, files, base_tree):
+    """``make_noise_cube`` with every full-frame array resident in HBM across the layers ("natural batch for
+    the GPU"): the Level-1 cube and its dark-based counterpart, the L2 planes the layers refer to, the masks and weights are
+    uploaded ONCE; a layer is then injection -> fresh reference pixels + correlated noise -> the fused chain -> sky model ->
+    difference -> clip / resampled Poisson / pseudo-Poisson -> sky model, all through the same kernels as the host-array path
+    (whose results it reproduces bit for bit: tests/test_gpu_noise.py), with only the finished layer (67 MB) going back to the
+    host.  The few scalar steps (percentile interpolation, the 6 x 6 normal equations of the sky model, the moment ratios of the
+    pseudo-Poisson layers) stay on the host as in the mirrors."""
+    import torch
+
+    from .. import pipeline
+    from ..devarray import DevArray
+    from ..from_sim.sim_to_isim import L1Synth
+    from .gen_cal_image import _caldir_slot
+
+    layers = config["NOISE"]["LAYER"]
+    nb = pars.nborder
+    caldir = config["CALDIR"]
+    cb = pipeline.Calibrator()
+    ctx = cb.ctx
+    slot = _caldir_slot(cb, caldir)
+    dev = torch.device("cuda", ctx.device)
+    roman = base_tree["roman"]
+    read_pattern = [list(map(int, g)) for g in roman["meta"]["exposure"]["read_pattern"]]
+    frame_time = float(roman["meta"]["exposure"]["frame_time"])
+    exclude_first = config.get("EXCLUDE_FIRST", True)
+    pid, _meta = cb.plan_for(read_pattern, frame_time, exclude_first, config.get("RAMP_OPT_PARS"), config.get("JUMP_DETECT_PARS"))
+    backup = config.get("SATURATION_BACKUP", 1)
+    skyorder = int(config["SKYORDER"]) if "SKYORDER" in config else None
+
+    def up(a, view=None):
+        a = np.ascontiguousarray(a)
+        return torch.from_numpy(a.view(view) if view is not None else a).to(dev)
+
+    base_cube = np.ascontiguousarray(roman["data"])
+    if base_cube.dtype != np.uint16:
+        return None   # the chain's u16 path is what this loop drives; anything else takes the host-array path
+    G, ny, nx = base_cube.shape
+    t_base = up(base_cube, np.int16)
+    t_a33_base = up(roman["amp33"], np.int16) if roman.get("amp33") is not None else None
+    if "mask" in caldir:
+        t_mask = up(np.array(files.roman(caldir["mask"])["dq"], dtype=np.uint32), np.int32)
+    else:
+        t_mask = torch.zeros((ny, nx), dtype=torch.int32, device=dev)
+    read = np.asarray(files.roman(caldir["read"])["data"], dtype=np.float32)
+    t_read = up(read)
+    nreads = np.array([len(g) for g in read_pattern], dtype=np.int32)
+    l2 = files.tree(config["OUT"])
+    t_orig = up(np.asarray(l2["roman"]["data"], dtype=np.float32))
+    na = tuple(t_orig.shape)
+    outs = [torch.empty((ny, nx), dtype=torch.float32, device=dev) for _ in range(3)] + [torch.empty((ny, nx), dtype=torch.int32, device=dev)]
+    synth_dev = None
+    t_dark = t_dark_ref = None
+    t_gain_act = t_withsky = t_endslice = None
+    sky_models = {}
+    noiseimage = np.zeros((len(layers),) + na, dtype=np.float32)
+
+    def tsync():
+        torch.cuda.current_stream(dev).synchronize()
+
+    def l2_data(t_cube, t_a33):
+        """roman.data of calibrateimage for a device-resident exposure: the chain, the active region, minus the sky model"""
+        tsync()
+        cb.calibrate_device(slot, pid, G, t_cube.data_ptr(), True, None if t_a33 is None else t_a33.data_ptr(), None, t_mask.data_ptr(),
+                            outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), flag_saturation=True,
+                            saturation_backup=backup, read_pattern=read_pattern)
+        cb.synchronize()
+        data = outs[0][nb:ny - nb, nb:nx - nb].contiguous()
+        if skyorder is not None:
+            tsync()
+            sky.medfit(DevArray(data), order=skyorder, subtract=True, ctx=ctx, want_model=False)
+        return data
+
+    for i_noise, cmd in enumerate(layers):
+        diff = torch.zeros(na, dtype=torch.float32, device=dev)
+        if "R" in cmd:
+            noiseflags = _get_subscript(cmd, "R")
+            t_ref = t_orig
+            t_cube = t_base.clone()
+            t_a33 = None if t_a33_base is None else t_a33_base.clone()
+            if "a" not in noiseflags:   # start from the dark instead of the data
+                if t_dark is None:
+                    dark = np.asarray(files.roman(caldir["dark"])["data"])
+                    de = dark.shape[0] - G
+                    if de not in [0, 1]:
+                        raise ValueError("Dark date cube has the wrong shape.")
+                    t_dark = up(dark.astype(np.uint16)[de:], np.int16)
+                    t_dark_ref = l2_data(t_dark, t_a33_base)
+                t_cube = t_dark.clone()
+                t_ref = t_dark_ref
+            tsync()
+            ctx.check(ctx.lib.rip_stage_noise_inject(ctx.h, t_cube.data_ptr(), G, ny, nx, nb, t_read.data_ptr(), nreads.ctypes.data, None,
+                                                     int(seed) & (2**64 - 1), int(i_noise), t_cube.data_ptr()))
+            if synth_dev is None:
+                cal_fill = {k: files.roman(caldir[k]) for k in ("read", "gain", "dark")}
+                synth_dev = L1Synth(cal_fill, read_pattern, 1.0, ctx=ctx, nb=nb)
+            synth_dev.fill(t_cube, t_a33, (int(seed) + 7919 * (i_noise + 1)) & (2**64 - 1), banding=True)
+            diff = l2_data(t_cube, t_a33) - t_ref
+            if "z" in noiseflags:
+                zclip = float(_get_subscript(noiseflags.upper(), "Z"))
+                tsync()
+                p25, med, p75 = sky.nanpercentiles(DevArray(diff), [25.0, 50.0, 75.0], ctx=ctx)
+                iqr = p75 - p25
+                print("***", noiseflags, zclip, iqr, med)
+                diff = torch.clamp(diff, float(med - zclip * iqr / 1.34896), float(med + zclip * iqr / 1.34896))
+        if "O" in cmd or "P" in cmd:
+            pinfo = l2["processinfo"]
+            if t_withsky is None:
+                gain = np.clip(np.asarray(files.roman(caldir["gain"])["data"]), 1e-4, 1e4)
+                withsky = np.asarray(l2["roman"]["data_withsky"], dtype=np.float32)
+                d = (gain.shape[-1] - withsky.shape[-1]) // 2
+                gain_act = np.ascontiguousarray(gain[d:-d, d:-d] if d > 0 else gain)
+                t_gain_act, t_withsky = up(gain_act), up(withsky)
+                w_all, has_all, endslice = ramp_weight_vectors(pinfo, G)
+                t_endslice = up(endslice)
+        if "O" in cmd:
+            # pseudo-Poisson layer (gen_noise_image.py:173-240): the moment ratios per end slice on the host, one Pearson deviate per
+            # pixel of that end slice on the device, scaled by the pixel's gain * rate
+            t_fr = l2["roman"]["meta"]["exposure"]["frame_time"]
+            gI = t_gain_act.to(torch.float64) * t_withsky.to(torch.float64) if t_gain_act.dtype == torch.float64 else \
+                (t_gain_act * t_withsky).to(torch.float64)
+            start = 1 if pinfo["exclude_first"] else 0
+            rp_l2 = pinfo["meta"].get("read_pattern", read_pattern)
+            a_beta = np.array([rp_l2[k][0] for k in range(G)], dtype=int)
+            N_beta = np.array([len(rp_l2[k]) for k in range(G)], dtype=int)
+            noise_array = torch.zeros(na, dtype=torch.float32, device=dev)
+            for k in range(start + 1, G):
+                tilnu21, tilnu31, tilnu41, _tilnu42 = get_tilde_nus(N_beta, a_beta, w_all[k])
+                tilnu21 *= t_fr
+                tilnu31 *= t_fr**2
+                tilnu41 *= t_fr**3
+                sel = torch.nonzero(t_endslice == k, as_tuple=True)
+                npx = int(sel[0].numel())
+                print("n pix", npx, "tilnus", tilnu21, tilnu31, tilnu41)
+                sys.stdout.flush()
+                if npx:
+                    t_I = gI[sel].contiguous()
+                    t_draw = torch.empty_like(t_I)
+                    tsync()
+                    ctx.check(ctx.lib.rip_stage_pearson(
+                        ctx.h, npx, t_I.data_ptr(), float(tilnu21), float(tilnu31), float(tilnu41),
+                        draw_seed(np.random.default_rng([int(seed) & 0xFFFFFFFF, i_noise, k])), (100 * (i_noise + 1) + k) & 0xFFFFFFFF,
+                        t_draw.data_ptr(), None, None))
+                    noise_array[sel] = t_draw.to(torch.float32)
+            diff = (diff + noise_array / t_gain_act).to(torch.float32)   # numpy: f32 array += (f32 / gain dtype), cast back
+        if "P" in cmd:
+            noiseflags = _get_subscript(cmd, "P")
+            t_fr = roman["meta"]["exposure"]["frame_time"]
+            if "b" in noiseflags:   # background only: the low-order sky model (one per order for the whole list)
+                sky_order = int("0" + _get_subscript(noiseflags.upper(), "B"))
+                if sky_order not in sky_models:
+                    sky_models[sky_order] = up(sky.medfit(DevArray(t_withsky), order=sky_order, ctx=ctx)[1])
+                skylevel = sky_models[sky_order]
+            else:
+                skylevel = t_withsky.clone()
+            if "r" in noiseflags:
+                diff = diff.contiguous()
+                tsync()
+                poisson_resample(DevArray(diff), DevArray(skylevel), DevArray(t_gain_act), t_fr, read_pattern, w_all, has_all,
+                                 DevArray(t_endslice), seed=seed, layer=1000 + i_noise, ctx=ctx)
+        if "S" in cmd:
+            sky_order = int("0" + _get_subscript(cmd, "S"))
+            diff = diff.contiguous()
+            tsync()
+            sky.medfit(DevArray(diff), order=sky_order, subtract=True, ctx=ctx, want_model=False)
+        noiseimage[i_noise] = diff.cpu().numpy()
+    return noiseimage
+
+
 def make_noise_cube(config, rng=None):
     """The noise realisations listed in ``config["NOISE"]["LAYER"]``: array (N_noise, ny_active, nx_active) f32."""
     layers = config["NOISE"]["LAYER"]
     files = _Files()
+    if _device_path_applies(config, rng):
+        with calio.open_tree(config["IN"]) as f_in:
+            base_tree_ = calio._materialise(f_in if isinstance(f_in, dict) else dict(f_in))
+        seed_ = config["NOISE"].get("SEED", 0) if rng is None else int(rng)
+        got = _make_noise_cube_device(config, seed_, files, base_tree_)
+        if got is not None:
+            return got
     synth_dev = None   # from_sim.sim_to_isim.L1Synth of this CALDIR set: reference pixels and correlated noise on the device
     host_rng = rng if isinstance(rng, np.random.Generator) else None
     seed = config["NOISE"].get("SEED", 0) if (rng is None or host_rng is not None) else int(rng)
@@ -262,8 +455,9 @@ def make_noise_cube(config, rng=None):
             ngrp_o = len(read_pattern)
             w, _has, endslice = ramp_weight_vectors(pinfo, ngrp_o)
             start = 1 if pinfo["exclude_first"] else 0
-            a_beta = np.array([read_pattern[k][0] for k in range(ngrp_o)], dtype=int)   # (the L2 file's processinfo holds the same)
-            N_beta = np.array([len(read_pattern[k]) for k in range(ngrp_o)], dtype=int)
+            rp_l2 = pinfo["meta"].get("read_pattern", read_pattern)   # from the L2 file, as gen_noise_image.py:208-212 reads it
+            a_beta = np.array([rp_l2[k][0] for k in range(ngrp_o)], dtype=int)
+            N_beta = np.array([len(rp_l2[k]) for k in range(ngrp_o)], dtype=int)
             noise_array = np.zeros(endslice.shape, dtype=np.float32)
             for k in range(start + 1, ngrp_o):
                 tilnu21, tilnu31, tilnu41, _tilnu42 = get_tilde_nus(N_beta, a_beta, w[k])

@@ -113,6 +113,7 @@ int rip_ctx_create(int device_id, rip_ctx **out) {
                         prop.gcnArchName);
     rip_ctx *ctx = new rip_ctx();
     ctx->device = device_id;
+    ctx->ncu = prop.multiProcessorCount;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
@@ -141,7 +142,7 @@ void rip_ctx_destroy(rip_ctx *ctx) {
             delete p;
         }
     rip_pink_release(ctx);
-    for (hipEvent_t e : {ctx->ev_tab[0], ctx->ev_tab[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_in, ctx->ev_pre})
+    for (hipEvent_t e : {ctx->ev_tab[0], ctx->ev_tab[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_in, ctx->ev_pre, ctx->ev_frames, ctx->ev_fill})
         if (e) (void)hipEventDestroy(e);
     for (void *p : ctx->ws)   // every workspace slot, the Level-1 synthesis ones included
         if (p) (void)hipFree(p);

@@ -943,12 +943,7 @@ static inline size_t chain2_lds_bytes(int G, size_t ksize = 4) {
 template <int NP, int G, int START, typename KT = float>
 static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
     const size_t lds = chain2_lds_bytes(G, sizeof(KT));
-    static int ncu = 0;
-    if (!ncu) {
-        hipDeviceProp_t prop;
-        RIP_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        ncu = prop.multiProcessorCount;
-    }
+    const int ncu = ctx->ncu;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
     const int max_wg = ((G > 8 || sizeof(KT) == 8) ? 8 : 16) / (C2_THREADS / 64);  // 4 waves/SIMD at <= 128 VGPRs (2 at 256 for G = 16 / f64)

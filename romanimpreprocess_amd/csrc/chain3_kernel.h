@@ -851,16 +851,11 @@ constexpr int chain3_wps() {
 template <int NP, int G, int START, typename KT = float>
 static int launch_chain3_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
     constexpr int WPS = chain3_wps<G, KT>();
-    static int ncu = 0;
-    if (!ncu) {
-        hipDeviceProp_t prop;
-        RIP_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        ncu = prop.multiProcessorCount;
-    }
+    const int ncu = ctx->ncu;
     // exactly resident grid: a second round of workgroups would start only when the first ends (measured: +40 %).
     // Registers allow (4 * WPS) / C3_NW workgroups per CU; LDS may allow fewer (asked from the runtime).
     const size_t lds = chain3_lds_bytes(G, sizeof(KT));
-    static int wg_per_cu = 0;
+    int &wg_per_cu = ctx->wg_per_cu[reinterpret_cast<const void *>(chain3_kernel<NP, G, START, KT, WPS>)];   // per context
     if (!wg_per_cu) {
         if (lds > 48 * 1024)
             RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chain3_kernel<NP, G, START, KT, WPS>),

@@ -627,12 +627,7 @@ static inline size_t chain_lds_tables(int G, int rc_rows) { return (size_t)(3 * 
 template <int NP, int G, typename KT>
 static int launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
     const size_t lds0 = chain_lds_bytes(G, sizeof(KT) == 8 ? RIP_F64 : RIP_F32);
-    static int ncu = 0;
-    if (!ncu) {
-        hipDeviceProp_t prop;
-        RIP_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        ncu = prop.multiProcessorCount;
-    }
+    const int ncu = ctx->ncu;
     const int per_cu = (int)((150 * 1024) / lds0) < 1 ? 1 : (int)((150 * 1024) / lds0);
     const int nstrips = (a.nx + CH_OUTW - 1) / CH_OUTW;
     const long resident = (long)ncu * (per_cu > 4 ? 4 : per_cu);

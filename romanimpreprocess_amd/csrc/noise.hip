@@ -90,18 +90,18 @@ extern "C" int rip_stage_noise_inject(rip_ctx *ctx, const uint16_t *cube, int ng
     NZ_HIP(hipMalloc(&d_out, (size_t)ngrp * npix * 2));
     NZ_HIP(hipMalloc(&d_read, npix * 4));
     NZ_HIP(hipMalloc(&d_rs, sizeof(double) * RIP_MAX_GROUPS));
-    NZ_HIP(hipMemcpyAsync(d_cube, cube, (size_t)ngrp * npix * 2, hipMemcpyHostToDevice, ctx->stream));
-    NZ_HIP(hipMemcpyAsync(d_read, read_noise, npix * 4, hipMemcpyHostToDevice, ctx->stream));
-    NZ_HIP(hipMemcpyAsync(d_rs, rs, sizeof(double) * ngrp, hipMemcpyHostToDevice, ctx->stream));
+    NZ_HIP(hipMemcpyAsync(d_cube, cube, (size_t)ngrp * npix * 2, hipMemcpyDefault, ctx->stream));
+    NZ_HIP(hipMemcpyAsync(d_read, read_noise, npix * 4, hipMemcpyDefault, ctx->stream));
+    NZ_HIP(hipMemcpyAsync(d_rs, rs, sizeof(double) * ngrp, hipMemcpyDefault, ctx->stream));
     if (normals) {
         NZ_HIP(hipMalloc(&d_nrm, (size_t)ngrp * nact * 4));
-        NZ_HIP(hipMemcpyAsync(d_nrm, normals, (size_t)ngrp * nact * 4, hipMemcpyHostToDevice, ctx->stream));
+        NZ_HIP(hipMemcpyAsync(d_nrm, normals, (size_t)ngrp * nact * 4, hipMemcpyDefault, ctx->stream));
     }
     hipLaunchKernelGGL(noise_inject_kernel, dim3((nx + 255) / 256, ny, ngrp), dim3(256), 0, ctx->stream, (const uint16_t *)d_cube,
                        (const float *)d_nrm, (const float *)d_read, (const double *)d_rs, ngrp, ny, nx, nb, seed, layer,
                        (uint16_t *)d_out);
     NZ_HIP(hipGetLastError());
-    NZ_HIP(hipMemcpyAsync(out, d_out, (size_t)ngrp * npix * 2, hipMemcpyDeviceToHost, ctx->stream));
+    NZ_HIP(hipMemcpyAsync(out, d_out, (size_t)ngrp * npix * 2, hipMemcpyDefault, ctx->stream));
     NZ_HIP(hipStreamSynchronize(ctx->stream));
 #undef NZ_HIP
     done();
@@ -248,13 +248,13 @@ extern "C" int rip_stage_poisson_resample(rip_ctx *ctx, const float *skylevel, c
     PR_HIP(hipMalloc(&d_gain, n * gs));
     PR_HIP(hipMalloc(&d_end, n));
     PR_HIP(hipMalloc(&d_diff, n * 4));
-    PR_HIP(hipMemcpyAsync(d_sky, skylevel, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    PR_HIP(hipMemcpyAsync(d_gain, gain, n * gs, hipMemcpyHostToDevice, ctx->stream));
-    PR_HIP(hipMemcpyAsync(d_end, endslice, n, hipMemcpyHostToDevice, ctx->stream));
-    PR_HIP(hipMemcpyAsync(d_diff, diff, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    PR_HIP(hipMemcpyAsync(d_sky, skylevel, n * 4, hipMemcpyDefault, ctx->stream));
+    PR_HIP(hipMemcpyAsync(d_gain, gain, n * gs, hipMemcpyDefault, ctx->stream));
+    PR_HIP(hipMemcpyAsync(d_end, endslice, n, hipMemcpyDefault, ctx->stream));
+    PR_HIP(hipMemcpyAsync(d_diff, diff, n * 4, hipMemcpyDefault, ctx->stream));
     if (samples) {
         PR_HIP(hipMalloc(&d_smp, (size_t)nsamp * n * 8));
-        PR_HIP(hipMemcpyAsync(d_smp, samples, (size_t)nsamp * n * 8, hipMemcpyHostToDevice, ctx->stream));
+        PR_HIP(hipMemcpyAsync(d_smp, samples, (size_t)nsamp * n * 8, hipMemcpyDefault, ctx->stream));
     }
     ResampleArgs a;
     a.sky = (const float *)d_sky;
@@ -275,7 +275,7 @@ extern "C" int rip_stage_poisson_resample(rip_ctx *ctx, const float *skylevel, c
     else
         hipLaunchKernelGGL(resample_kernel<float>, grid, dim3(256), 0, ctx->stream, a, t);
     PR_HIP(hipGetLastError());
-    PR_HIP(hipMemcpyAsync(diff, d_diff, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PR_HIP(hipMemcpyAsync(diff, d_diff, n * 4, hipMemcpyDefault, ctx->stream));
     PR_HIP(hipStreamSynchronize(ctx->stream));
 #undef PR_HIP
     done();

@@ -272,13 +272,13 @@ extern "C" int rip_stage_pearson(rip_ctx *ctx, size_t n, const double *I, double
     if (draws) PX_HIP(hipMalloc((void **)&d_o, n * 8));
     if (types) PX_HIP(hipMalloc((void **)&d_t, n * 4));
     if (params) PX_HIP(hipMalloc((void **)&d_p, n * 32));
-    PX_HIP(hipMemcpyAsync(d_I, I, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    PX_HIP(hipMemcpyAsync(d_I, I, n * 8, hipMemcpyDefault, ctx->stream));
     hipLaunchKernelGGL(pearson_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_I, n, tilnu21, tilnu31,
                        tilnu41, seed, stream, draws ? 1 : 0, d_o, d_t, d_p);
     PX_HIP(hipGetLastError());
-    if (draws) PX_HIP(hipMemcpyAsync(draws, d_o, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (types) PX_HIP(hipMemcpyAsync(types, d_t, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (params) PX_HIP(hipMemcpyAsync(params, d_p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (draws) PX_HIP(hipMemcpyAsync(draws, d_o, n * 8, hipMemcpyDefault, ctx->stream));
+    if (types) PX_HIP(hipMemcpyAsync(types, d_t, n * 4, hipMemcpyDefault, ctx->stream));
+    if (params) PX_HIP(hipMemcpyAsync(params, d_p, n * 32, hipMemcpyDefault, ctx->stream));
     PX_HIP(hipStreamSynchronize(ctx->stream));
 #undef PX_HIP
     done();

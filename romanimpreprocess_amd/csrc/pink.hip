@@ -177,10 +177,41 @@ void rip_pink_release(rip_ctx *ctx) {
 
 extern "C" int rip_stage_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, const double *normals, uint64_t seed,
                                   uint32_t stream_id, float *out) {
+    if (ctx->frames_pending && ctx->ev_frames) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_frames, 0);
     return noise_1f_impl(ctx, rows, width, nframes, normals, seed, stream_id, out, false);
+}
+
+// frames made ahead on the second stream share the transform buffers with every other 1/f call: those wait for them first
+static int frames_drain(rip_ctx *ctx) {
+    if (ctx->frames_pending && ctx->ev_frames) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_frames, 0));
+    return RIP_OK;
 }
 
 extern "C" int rip_synth_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, uint64_t seed, uint32_t stream_id, float *out) {
     ctx->stream_dirty = true;
+    int rc = frames_drain(ctx);
+    if (rc) return rc;
     return noise_1f_impl(ctx, rows, width, nframes, nullptr, seed, stream_id, out, true);
+}
+
+extern "C" int rip_synth_frames_ahead(rip_ctx *ctx, int rows, int width, int nframes, uint64_t seed) {
+    if (!ctx->stream2) return RIP_OK;   // no second stream: rip_synth_fill makes the frames itself, in stream order
+    if (rows < 1 || width < 1 || nframes < 1) return rip_fail(ctx, RIP_EINVAL, "synth_frames_ahead: bad geometry");
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    float *made = (float *)rip_ws(ctx, 12, (size_t)nframes * rows * width * sizeof(float));
+    if (!made) return RIP_ENOMEM;
+    if (!ctx->ev_frames) RIP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_frames, hipEventDisableTiming));
+    // behind the previous exposure's fill kernels (they read the frames this call overwrites)
+    if (ctx->ev_fill_valid) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fill, 0));
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->stream2;
+    const int rc = noise_1f_impl(ctx, rows, width, nframes, nullptr, seed, 0x31660000u, made, true);
+    hipError_t e = rc ? hipSuccess : hipEventRecord(ctx->ev_frames, ctx->stream2);
+    ctx->stream = main_stream;
+    if (rc) return rc;
+    RIP_HIP(ctx, e);
+    ctx->frames_pending = true;
+    ctx->frames_seed = seed;
+    ctx->frames_geom[0] = rows, ctx->frames_geom[1] = width, ctx->frames_geom[2] = nframes;
+    return RIP_OK;
 }

@@ -26,11 +26,11 @@ struct DevBuf {
     int upload(const T *src, size_t n) {
         int rc = alloc(n);
         if (rc) return rc;
-        RIP_HIP(ctx, hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        RIP_HIP(ctx, hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyDefault, ctx->stream));
         return RIP_OK;
     }
     int download(T *dst, size_t n) {
-        RIP_HIP(ctx, hipMemcpyAsync(dst, p, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        RIP_HIP(ctx, hipMemcpyAsync(dst, p, n * sizeof(T), hipMemcpyDefault, ctx->stream));
         RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return RIP_OK;
     }
@@ -303,7 +303,7 @@ int rip_stage_select_ranks(rip_ctx *ctx, const float *arr, int ny, int nx, int y
     RIP_HIP(ctx, hipMemsetAsync(hist.p, 0, (size_t)nblk * PS_BINS * 4, ctx->stream));
     hipLaunchKernelGGL(ps_hist_kernel, dim3(chunks, nblk), dim3(256), 0, ctx->stream, d.p, g, prefix.p, hist.p, -1);
     std::vector<uint32_t> hh((size_t)nblk * PS_BINS);
-    RIP_HIP(ctx, hipMemcpyAsync(hh.data(), hist.p, hh.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipMemcpyAsync(hh.data(), hist.p, hh.size() * 4, hipMemcpyDefault, ctx->stream));
     RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<int64_t> cnt(nblk);
     for (int b = 0; b < nblk; ++b) cnt[b] = hh[(size_t)b * PS_BINS];
@@ -316,7 +316,7 @@ int rip_stage_select_ranks(rip_ctx *ctx, const float *arr, int ny, int nx, int y
             const int64_t want = ranks[(size_t)b * nranks + q];
             r[b] = (want >= 0 && want < cnt[b]) ? (unsigned long long)want : 0ull;
         }
-        RIP_HIP(ctx, hipMemcpyAsync(rk.p, r.data(), (size_t)nblk * 8, hipMemcpyHostToDevice, ctx->stream));
+        RIP_HIP(ctx, hipMemcpyAsync(rk.p, r.data(), (size_t)nblk * 8, hipMemcpyDefault, ctx->stream));
         RIP_HIP(ctx, hipMemsetAsync(hist.p, 0, (size_t)nblk * PS_BINS * 4, ctx->stream));
         for (int level = 0; level < 3; ++level) {
             hipLaunchKernelGGL(ps_hist_kernel, dim3(chunks, nblk), dim3(256), 0, ctx->stream, d.p, g, prefix.p, hist.p, level);

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/romanhip.h"
@@ -152,6 +153,17 @@ struct rip_ctx {
     // the pre-pass / saturation pass share workspaces (selection histograms, row tables in the making, exceed bits): when two
     // consecutive calls run them on different streams (a non-overlapped call between overlapped ones), the later waits for the
     // earlier through this event
+    // launch geometry of the fused kernels, per CONTEXT (a second context may sit on another device): CU count, and per
+    // kernel instantiation the resident workgroups per CU (0 = not asked yet; asking also opts into > 48 KB of dynamic LDS)
+    int ncu = 0;
+    std::map<const void *, int> wg_per_cu;
+    // 1/f frames made AHEAD on the second stream (rip_synth_frames_ahead, pink.hip) for the next rip_synth_fill: the transforms
+    // (HBM-bound) then run beside the apportioning and the inverse-linearity kernels (arithmetic-bound) of the same exposure
+    hipEvent_t ev_frames = nullptr, ev_fill = nullptr;
+    bool frames_pending = false, ev_fill_valid = false;
+    uint64_t frames_seed = 0;
+    int frames_geom[3] = {0, 0, 0};   // rows, channel width, frames
+    std::vector<double> share_tab;   // synth.hip: the read-share table whose device copy sits in workspace slot 10
     hipEvent_t ev_pre = nullptr;
     hipStream_t pre_stream = nullptr;
     bool ev_pre_valid = false;

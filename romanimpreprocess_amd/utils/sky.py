@@ -8,9 +8,14 @@ import scipy.stats
 from scipy.special import legendre_p
 
 from .. import _native
+from ..devarray import DevArray, is_dev
 
 
 def _f32(a):
+    if is_dev(a):   # a float32 plane resident in HBM (devarray.DevArray): handed over as it is
+        if a.dtype != np.float32:
+            raise TypeError("device arrays must be float32 here")
+        return a
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
@@ -126,12 +131,16 @@ def block_nanmedians(arr, N, ctx=None):
     return med.reshape(N, N)
 
 
-def medfit(arr, N=8, order=2, subtract=False, ctx=None):
+def medfit(arr, N=8, order=2, subtract=False, ctx=None, want_model=True):
     """Low-order 2-D Legendre fit to the block medians (``sky.py:100-191``).  Returns (coef, model f32); with
-    ``subtract`` the model is also subtracted from ``arr`` in place (``gen_cal_image.py:646-647``)."""
+    ``subtract`` the model is also subtracted from ``arr`` in place (``gen_cal_image.py:646-647``).  ``arr`` may be a
+    ``DevArray`` (a plane in HBM); ``want_model=False`` (with ``subtract``) returns None for the model instead of
+    bringing 67 MB back to the host."""
     ctx = ctx or _native.default_context()
-    if subtract and not (isinstance(arr, np.ndarray) and arr.dtype == np.float32 and arr.flags.c_contiguous):
+    if subtract and not ((isinstance(arr, np.ndarray) or is_dev(arr)) and arr.dtype == np.float32 and arr.flags.c_contiguous):
         raise TypeError("subtract=True needs a C-contiguous float32 array (updated in place)")
+    if not want_model and not subtract:
+        raise ValueError("want_model=False only makes sense with subtract=True")
     a = arr if subtract else _f32(arr)
     ny, nx = a.shape
     kx, ky = nx // N, ny // N
@@ -162,10 +171,11 @@ def medfit(arr, N=8, order=2, subtract=False, ctx=None):
     LPX = np.stack([np.reshape(legendre_p(i, np.linspace(-1, 1 - 2 / nx, nx)), nx) for i in range(order + 1)]).astype(np.float64)
     LPY = np.stack([np.reshape(legendre_p(j, np.linspace(-1, 1 - 2 / ny, ny)), ny) for j in range(order + 1)]).astype(np.float64)
     LPX, LPY = np.ascontiguousarray(LPX), np.ascontiguousarray(LPY)
-    model = np.empty((ny, nx), np.float32)
+    model = np.empty((ny, nx), np.float32) if want_model else None
     coef = np.ascontiguousarray(x, dtype=np.float64)
     ctx.check(ctx.lib.rip_stage_legendre2d(ctx.h, a.ctypes.data if subtract else None, ny, nx, int(order), LPX.ctypes.data,
-                                           LPY.ctypes.data, coef.ctypes.data, int(bool(subtract)), model.ctypes.data))
+                                           LPY.ctypes.data, coef.ctypes.data, int(bool(subtract)),
+                                           None if model is None else model.ctypes.data))
     return x, model
 
 

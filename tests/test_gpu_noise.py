@@ -109,6 +109,10 @@ def test_noise_layers_end_to_end(tmp_path):
     # same seed, same layers
     again = gen_noise_image.make_noise_cube(config)
     assert_same_bits(again, noise, "layers from the same seed")
+    # the HBM-resident layer loop (default) and the host-array loop drive the same kernels with the same seeds: every layer of the
+    # list -- read noise with correlated noise, clipping, sky model, resampled Poisson, pseudo-Poisson -- bit for bit
+    host_loop = gen_noise_image.make_noise_cube(dict(config, NOISE=dict(config["NOISE"], DEVICE_RESIDENT=False)))
+    assert_same_bits(host_loop, noise, "host-array layer loop vs the HBM-resident one")
     # the exposures kept in memory (default) or sent through the TEMP files as the reference does: the same layers
     one = dict(config["NOISE"], LAYER=["R", "Raz3S1"])
     mem = gen_noise_image.make_noise_cube(dict(config, NOISE=one))

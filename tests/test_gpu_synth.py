@@ -214,3 +214,37 @@ def test_calibrate_right_behind_the_synthesis_without_a_sync():
         for x, y in zip(a, b):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     assert np.isfinite(want[0][0]).mean() > 0.9 and abs(np.median(want[0][0][8:-8, 8:-8])) < 50
+
+
+def test_frames_made_ahead_give_the_same_exposure():
+    """L1Synth.make starts the 1/f frames of its fill on the second stream (rip_synth_frames_ahead) beside the apportioning and
+    the inverse linearity; the exposure must equal, bit for bit, the one whose fill makes its frames in stream order -- also
+    when exposures follow each other without a pause, with another seed in between, and with a mismatching seed."""
+    rp = synth.READ_PATTERN_8
+    ny, nx, nb = 264, 512, 4
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=9)
+    ctx = _native.default_context(0)
+    s = sim_to_isim.L1Synth(cal, rp, synth.FRAME_TIME, ctx=ctx)
+    dev = s.dev
+    counts = torch.full((ny - 2 * nb, nx - 2 * nb), 2500.0, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    def in_order(seed):
+        reads_e = s.apportion(counts, seed, poisson=True)
+        cube = s.resultants(reads_e, seed)["cube"]
+        a33 = torch.zeros((len(rp), ny, s.cw), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        s.fill(cube, a33, seed)
+        ctx.synchronize()
+        return cube.cpu().numpy(), a33.cpu().numpy()
+
+    want = {sd: in_order(sd) for sd in (11, 12, 13)}
+    for sd in (11, 12, 13, 12):
+        cube, a33 = s.make(counts, sd, poisson=True)
+        assert np.array_equal(cube.cpu().numpy(), want[sd][0]) and np.array_equal(a33.cpu().numpy(), want[sd][1]), sd
+    # frames made ahead for ANOTHER seed are not taken by the fill (it makes its own, after waiting for the stray ones)
+    ctx.check(ctx.lib.rip_synth_frames_ahead(ctx.h, ny, s.cw, len(rp) * (nx // s.cw + 2), 999))
+    got = in_order(13)
+    assert np.array_equal(got[0], want[13][0]) and np.array_equal(got[1], want[13][1])
+    # and the exposures do differ by seed
+    assert not np.array_equal(want[11][0], want[12][0])
