@@ -5,10 +5,11 @@ numpy restatements, with the random deviates as arguments, of
   * its resampled-Poisson branch (``:285-331``),
   * ``sim_to_isim.noise_1f_frame`` (``sim_to_isim.py:265-303``).
 The reference draws its deviates from galsim generators inside these code paths (not importable offline, streams not
-reproducible): PARITY UNPINNED for the random part.  ``noise_1f_frame`` IS pinned: the reference's function is numpy-only apart
-from the draw, so tools/make_goldens.py takes it from sim_to_isim.py with ``ast``, executes it with a deviate stand-in that
-fills from given normals, and tests/test_oracle_golden.py holds this restatement to the same frame bit for bit.  The other
-two follow the cited lines operation by operation (numpy 2 promotion rules) on given deviates.
+reproducible): PARITY UNPINNED for the random streams only.  The ARITHMETIC is pinned (round 3 for the first two): the
+reference's functions are numpy-only apart from the draws, so tools/make_goldens.py takes them from their files with ``ast``
+and EXECUTES them with deviate stand-ins that hand out recorded values -- ``noise_1f_frame`` (fixture noise_1f_frame.npz) and
+the whole layer loop ``make_noise_cube`` (fixture noise_arith.npz: the injected cubes of 'Ra' / 'R' layers and the 'Pr',
+'Pb1r', 'RaPr' layers) -- and tests/test_oracle_golden.py holds these restatements to the same arrays bit for bit.
 """
 
 import numpy as np

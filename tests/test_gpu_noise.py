@@ -2,6 +2,7 @@
 
 import numpy as np
 import pytest
+import torch
 from conftest import assert_same_bits, gpu_context
 
 from oracle import noise as onoise
@@ -233,3 +234,46 @@ def test_1f_frames_against_numpy_fft(rows, width):
     ratio = octave_power(dev) / octave_power(ref)
     assert np.all((ratio > 0.8) & (ratio < 1.25)), ratio
     assert abs(dev.std() / ref.std() - 1) < 0.15
+
+
+def test_injection_and_resampling_against_the_executed_reference_loop(golden):
+    """rip_stage_noise_inject and rip_stage_poisson_resample against arrays made by EXECUTING the reference's make_noise_cube with
+    recorded deviates (tests/golden/noise_arith.npz, tools/make_goldens.py noise_arith): injected cubes and layers bit for bit, with
+    host arrays and with the planes resident in HBM."""
+    import json
+
+    from romanimpreprocess_amd.devarray import DevArray
+
+    g = golden("noise_arith")
+    ctx = gpu_context()
+    rp = json.loads(str(g["read_pattern"]))
+    G, nb, ft = len(rp), 4, float(g["frame_time"])
+    gain_act = np.ascontiguousarray(np.clip(g["gain"], 1e-4, 1e4)[nb:-nb, nb:-nb])
+    pinfo = {"meta": {"tbar": g["tbar"]}, "weights": g["weights"], "exclude_first": True, "endslice": g["endslice"]}
+    w, has, endslice = gen_noise_image.ramp_weight_vectors(pinfo, G)
+    inj_a = gen_noise_image.inject_read_noise(g["cube"], g["read"], rp, normals=g["normals"][0], ctx=ctx)
+    assert_same_bits(inj_a, g["injected_Ra"], "cube after the injection ('Ra')")
+    dark_as_data = np.ascontiguousarray(g["dark"].astype(np.uint16)[1:])
+    inj_d = gen_noise_image.inject_read_noise(dark_as_data, g["read"], rp, normals=g["normals"][1], ctx=ctx)
+    assert_same_bits(inj_d, g["injected_R"], "dark cube after the injection ('R')")
+    zero = np.zeros_like(g["withsky"])
+    lay2 = gen_noise_image.poisson_resample(zero.copy(), g["withsky"], gain_act, ft, rp, w, has, endslice, samples=g["poisson"][0], ctx=ctx)
+    assert_same_bits(lay2, g["noise"][2], "layer 'Pr'")
+    lay3 = gen_noise_image.poisson_resample(zero.copy(), g["sky_b1"], gain_act, ft, rp, w, has, endslice, samples=g["poisson"][1], ctx=ctx)
+    assert_same_bits(lay3, g["noise"][3], "layer 'Pb1r'")
+    # the same with every plane resident in HBM (the layer loop's form)
+    dev = torch.device("cuda", ctx.device)
+    t_diff = torch.zeros(g["withsky"].shape, dtype=torch.float32, device=dev)
+    t_sky, t_gain, t_end = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (g["withsky"], gain_act, endslice))
+    torch.cuda.synchronize()
+    gen_noise_image.poisson_resample(DevArray(t_diff), DevArray(t_sky), DevArray(t_gain), ft, rp, w, has, DevArray(t_end),
+                                     samples=g["poisson"][0], ctx=ctx)
+    assert_same_bits(t_diff.cpu().numpy(), g["noise"][2], "layer 'Pr' (HBM-resident planes)")
+    t_cube = torch.from_numpy(g["cube"].view(np.int16)).to(dev)
+    t_read = torch.from_numpy(g["read"]).to(dev)
+    nreads = np.array([len(r) for r in rp], dtype=np.int32)
+    nrm = np.ascontiguousarray(g["normals"][0], dtype=np.float32)
+    torch.cuda.synchronize()
+    ctx.check(ctx.lib.rip_stage_noise_inject(ctx.h, t_cube.data_ptr(), G, 64, 64, nb, t_read.data_ptr(), nreads.ctypes.data,
+                                             nrm.ctypes.data, 0, 0, t_cube.data_ptr()))
+    assert_same_bits(t_cube.cpu().numpy().view(np.uint16), g["injected_Ra"], "injection in place in HBM")

@@ -415,3 +415,57 @@ def test_golden_recipe_reproduces_the_fixtures():
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:]
     assert "identical" in out.stdout.splitlines()[-1]
+
+
+def _noise_arith_inputs(g):
+    rp = json.loads(str(g["read_pattern"]))
+    G = len(rp)
+    nb = 4
+    gain_act = np.clip(g["gain"], 1e-4, 1e4)[nb:-nb, nb:-nb]
+    # ramp-fit weights by end slice, as gen_noise_image.py:248-262 builds them
+    rows = np.zeros((G, G), np.float32)
+    has = np.zeros(G, bool)
+    rows[-1], has[-1] = g["weights"], True
+    start = 1
+    for iend in range(start + 2, G):
+        rows[iend - 1, iend - 1] = 1.0 / (g["tbar"][iend - 1] - g["tbar"][start])
+        rows[iend - 1, start] = -rows[iend - 1, iend - 1]
+        has[iend - 1] = True
+    endslice = np.where(g["endslice"] > 0, g["endslice"], G - 1)
+    return rp, G, nb, gain_act, rows, has, endslice
+
+
+def _stand_in_l2(cube, nb=4):
+    """the L2 'data' the golden run's calibrateimage stand-in answers with (tools/make_goldens.py: case_noise_arith)"""
+    act = cube[:, nb:-nb, nb:-nb].astype(np.float32)
+    return (act[-1] - act[1]) / np.float32(7.0)
+
+
+def test_noise_layer_arithmetic_against_the_reference_loop():
+    """oracle/noise.py against arrays produced by EXECUTING the reference's make_noise_cube (gen_noise_image.py:60-331) with
+    recording stand-ins for its deviates, files and chain runs: the injected cubes and every layer, bit for bit."""
+    from oracle import noise as onoise
+
+    g = load_golden("noise_arith")
+    rp, G, nb, gain_act, rows, has, endslice = _noise_arith_inputs(g)
+    ft = float(g["frame_time"])
+    assert json.loads(str(g["layers"])) == ["Ra", "R", "Pr", "Pb1r", "RaPr"]
+    inj_a = onoise.inject_read_noise(g["cube"], g["read"], rp, g["normals"][0], nb)
+    assert_same_bits(inj_a, g["injected_Ra"], "cube after the injection ('Ra')")
+    dark_as_data = g["dark"].astype(np.uint16)[1:]
+    assert_same_bits(dark_as_data, g["dark_as_data"], "dark cube taken as data ('R' without 'a')")
+    inj_d = onoise.inject_read_noise(dark_as_data, g["read"], rp, g["normals"][1], nb)
+    assert_same_bits(inj_d, g["injected_R"], "dark cube after the injection ('R')")
+    assert_same_bits(_stand_in_l2(inj_a) - _stand_in_l2(g["cube"]), g["noise"][0], "layer 'Ra'")
+    assert_same_bits(_stand_in_l2(inj_d) - _stand_in_l2(dark_as_data), g["noise"][1], "layer 'R'")
+    zero = np.zeros_like(g["withsky"])
+    lay2 = onoise.poisson_resample(zero.copy(), g["withsky"], gain_act, ft, rp, rows, has, endslice, g["poisson"][0])
+    assert_same_bits(lay2, g["noise"][2], "layer 'Pr'")
+    lay3 = onoise.poisson_resample(zero.copy(), g["sky_b1"], gain_act, ft, rp, rows, has, endslice, g["poisson"][1])
+    assert_same_bits(lay3, g["noise"][3], "layer 'Pb1r'")
+    inj_c = onoise.inject_read_noise(g["cube"], g["read"], rp, g["normals"][2], nb)
+    assert_same_bits(inj_c, g["injected_RaPr"], "cube after the injection ('RaPr')")
+    start4 = _stand_in_l2(inj_c) - _stand_in_l2(g["cube"])
+    lay4 = onoise.poisson_resample(start4.copy(), g["withsky"], gain_act, ft, rp, rows, has, endslice, g["poisson"][2])
+    assert_same_bits(lay4, g["noise"][4], "layer 'RaPr'")
+    assert np.count_nonzero(inj_a != g["cube"]) > 1000 and np.std(lay2) > 0

@@ -740,6 +740,142 @@ def case_noise1f():
     save("noise_1f_frame", seeds=np.array([3, 4]), **out)
 
 
+def case_noise_arith():
+    """The arithmetic of the noise-layer loop, ``make_noise_cube`` of L1_to_L2/gen_noise_image.py (:60-331): white read-noise
+    injection into the Level-1 cube (:120-134) and the resampled-Poisson layers (:242-324).  The module cannot be imported
+    (galsim, astropy, romanisim at import), so the function is taken from the file with ``ast`` and EXECUTED as it stands on a
+    64 x 64 frame (``pars.nside_active`` = 56, ``pars.nborder`` = 4 in the namespace it runs in) with recording stand-ins:
+    ``galsim.GaussianDeviate(rng).generate(a)`` / ``galsim.PoissonDeviate(rng).generate_from_expectation(a)`` fill from a numpy
+    generator and record what they drew; ``asdf`` serves and stores in-memory trees; ``fill_in_refdata_and_1f`` does nothing
+    (its arithmetic is pinned by the l1sim fixture); ``calibrateimage`` records the cube it is handed -- the INJECTED cube -- and
+    answers with an L2 tree whose data is a fixed linear function of that cube.  ``sky`` is the reference's own module."""
+    import ast
+    import copy
+    import importlib
+
+    path = os.path.join(REF_SRC, "romanimpreprocess", "L1_to_L2", "gen_noise_image.py")
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("make_noise_cube", "_get_subscript")]
+    assert len(keep) == 2
+    ref_sky = importlib.import_module("romanimpreprocess.utils.sky")
+    rng = np.random.default_rng(71)
+    ny = nx = 64
+    nb = 4
+    rp = [[0], [1], [2, 3], [4, 5, 6]]
+    G = len(rp)
+    frame_time = 3.04
+    cube = (3000 + 40 * np.arange(G)[:, None, None] + rng.integers(0, 900, size=(G, ny, nx))).astype(np.uint16)
+    cube[2, 10, 10] = 65534          # the injection clips at the top of the u16 range ...
+    cube[1, 11, 11] = 1              # ... and at zero
+    dark = (2900 + rng.integers(0, 300, size=(G + 1, ny, nx)) / 4.0).astype(np.float32)     # one reference read in front (de = 1)
+    read = (5.0 + 4.0 * rng.random((ny, nx))).astype(np.float32)
+    gain = (1.5 + 0.05 * rng.standard_normal((ny, nx))).astype(np.float32)
+    gain[20, 20] = 0.0               # clipped to 1e-4
+    withsky = (0.3 + 1.5 * rng.random((ny - 2 * nb, nx - 2 * nb)) ** 3).astype(np.float32)
+    withsky[5, 5] = -0.4             # negative sky: no electrons
+    endslice = rng.integers(-1, G, size=(ny - 2 * nb, nx - 2 * nb)).astype(np.int8)
+    weights = np.array([0.0, -0.11, 0.02, 0.09], dtype=np.float32)
+    tbar = np.array([frame_time * np.mean(g) for g in rp], dtype=np.float32)
+
+    drawn = {"normals": [], "poisson": []}
+
+    class _GD:
+        def __init__(self, r):
+            pass
+
+        def generate(self, a):
+            v = rng.standard_normal(a.shape).astype(a.dtype)
+            drawn["normals"].append(v.copy())
+            a[...] = v
+
+    class _PD:
+        def __init__(self, r):
+            pass
+
+        def generate_from_expectation(self, a):
+            v = rng.poisson(a).astype(a.dtype)
+            drawn["poisson"].append(v.copy())
+            a[...] = v
+
+    class _TreeDict(dict):
+        @property
+        def tree(self):
+            return self
+
+    class _Open:
+        def __init__(self, key):
+            self.t = _TreeDict(_STORE[key])
+
+        def __enter__(self):
+            return self.t
+
+        def __exit__(self, *exc):
+            return False
+
+    class _AF:
+        def __init__(self, t):
+            self.t = t
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+        def write_to(self, f):
+            _STORE[f.name] = copy.deepcopy(dict(self.t))
+
+    captured = []
+
+    def calibrateimage(cfg):
+        t = _STORE[cfg["IN"]]
+        c = np.array(t["roman"]["data"])
+        captured.append(c.copy())
+        act = c[:, nb:-nb, nb:-nb].astype(np.float32)
+        _STORE[cfg["OUT"]] = {"roman": {"data": (act[-1] - act[1]) / np.float32(7.0)}}
+
+    tmp = "/tmp/make_goldens_noise_arith"
+    os.makedirs(tmp, exist_ok=True)
+    base = {"roman": {"data": cube.copy(), "amp33": np.zeros((G, ny, 128), np.uint16),
+                      "meta": {"exposure": {"read_pattern": rp, "frame_time": frame_time}}}}
+    act0 = cube[:, nb:-nb, nb:-nb].astype(np.float32)
+    l2 = {"roman": {"data": (act0[-1] - act0[1]) / np.float32(7.0), "data_withsky": withsky,
+                    "meta": {"exposure": {"read_pattern": rp, "frame_time": frame_time}}},
+          "processinfo": {"meta": {"tbar": tbar, "read_pattern": rp}, "weights": weights, "exclude_first": True, "endslice": endslice}}
+    _STORE["/mem/na_l1.asdf"], _STORE["/mem/na_l2.asdf"] = base, l2
+    register("/mem/na_dark.asdf", {"data": dark})
+    register("/mem/na_read.asdf", {"data": read})
+    register("/mem/na_gain.asdf", {"data": gain})
+    layers = ["Ra", "R", "Pr", "Pb1r", "RaPr"]
+    config = {"IN": "/mem/na_l1.asdf", "OUT": "/mem/na_l2.asdf",
+              "CALDIR": {"dark": "/mem/na_dark.asdf", "read": "/mem/na_read.asdf", "gain": "/mem/na_gain.asdf"},
+              "NOISE": {"LAYER": layers, "TEMP": os.path.join(tmp, "temp.asdf")}}
+    asdf_ns = types.SimpleNamespace(open=lambda key, *a, **k: _Open(key), AsdfFile=_AF)
+    ns = {"np": np, "asdf": asdf_ns, "galsim": types.SimpleNamespace(GaussianDeviate=_GD, PoissonDeviate=_PD), "sys": sys,
+          "re": __import__("re"), "deepcopy": copy.deepcopy, "pars": types.SimpleNamespace(nside_active=ny - 2 * nb, nborder=nb),
+          "fill_in_refdata_and_1f": lambda *a, **k: None, "calibrateimage": calibrateimage, "sky": ref_sky,
+          "get_tilde_nus": None, "draw_from_Pearson": None}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        noise = ns["make_noise_cube"](config, object())
+    import shutil
+
+    shutil.rmtree(tmp, ignore_errors=True)
+    assert noise.shape == (len(layers), ny - 2 * nb, nx - 2 * nb) and noise.dtype == np.float32
+    # captured cubes: "Ra" -> 1 (injected data); "R" -> 2 (the dark cube itself, then the injected dark); "RaPr" -> 1
+    assert len(captured) == 4 and len(drawn["normals"]) == 3 * G and len(drawn["poisson"]) == 3 * (rp[-1][-1] + 1)
+    sky_b1 = ref_sky.medfit(withsky, order=1)[1]
+    save("noise_arith", cube=cube, dark=dark, read=read, gain=gain, withsky=withsky, endslice=endslice, weights=weights, tbar=tbar,
+         read_pattern=json.dumps(rp), frame_time=np.float64(frame_time), layers=json.dumps(layers),
+         normals=np.stack(drawn["normals"]).reshape(3, G, ny - 2 * nb, nx - 2 * nb),
+         poisson=np.stack(drawn["poisson"]).reshape(3, rp[-1][-1] + 1, ny - 2 * nb, nx - 2 * nb),
+         injected_Ra=captured[0], dark_as_data=captured[1], injected_R=captured[2], injected_RaPr=captured[3],
+         sky_b1=sky_b1.astype(np.float32), noise=noise)
+
+
 def case_l1sim():
     """``make_l1_fullcal`` (:163-262) and ``fill_in_refdata_and_1f`` (:306-403) of from_sim/sim_to_isim.py, taken from the file
     with ``ast`` and EXECUTED as they stand on a 32 x 512 frame (the smallest one that satisfies the border rules the two
@@ -852,7 +988,7 @@ CASES = {
     "weights": case_weights, "rampfit": case_rampfit, "flat": case_flat, "refpix": case_refpix,
     "chain": case_chain, "post": case_post, "harness": case_harness, "il": case_il, "il_example": case_il_example,
     "pearson": case_pearson, "noise1f": case_noise1f, "l1sim": case_l1sim,
-    "refpix_variants": case_refpix_variants, "jump_detect_trunc": case_jump_detect_trunc,
+    "refpix_variants": case_refpix_variants, "jump_detect_trunc": case_jump_detect_trunc, "noise_arith": case_noise_arith,
 }
 
 
