@@ -313,9 +313,9 @@ int rip_caldir_upload(rip_ctx *ctx, int slot, const rip_caldir_desc *d) {
     if (d->lin_coefs && (!d->lin_smin || !d->lin_smax || !d->lin_sref || !d->lin_dq || d->lin_nplanes < 1))
         return rip_fail(ctx, RIP_EINVAL, "caldir upload: incomplete linearity arrays");
     const int NPl = d->lin_coefs ? d->lin_nplanes : 0;
-    if (hipMalloc((void **)&c.slab, (size_t)(NPl + 9) * npix * 4) != hipSuccess)
-        return rip_fail(ctx, RIP_ENOMEM, "caldir upload: %zu bytes for the per-pixel planes", (size_t)(NPl + 9) * npix * 4);
-    RIP_HIP(ctx, hipMemsetAsync(c.slab, 0, (size_t)(NPl + 9) * npix * 4, ctx->stream));
+    if (hipMalloc((void **)&c.slab, (size_t)(NPl + 12) * npix * 4) != hipSuccess)
+        return rip_fail(ctx, RIP_ENOMEM, "caldir upload: %zu bytes for the per-pixel planes", (size_t)(NPl + 12) * npix * 4);
+    RIP_HIP(ctx, hipMemsetAsync(c.slab, 0, (size_t)(NPl + 12) * npix * 4, ctx->stream));
     float *pl = c.slab;
     auto plane = [&](int k) { return pl + (size_t)(NPl + k) * npix; };
 #define UPS(dst, src, bytes)                                                                           \
@@ -437,6 +437,35 @@ int rip_caldir_upload(rip_ctx *ctx, int slot, const rip_caldir_desc *d) {
             return rc;
         }
         c.has_flat = true;
+    }
+    // the flag words of the wave-specialised fused kernel: linearity dq merged with the flat flags and / or the dark dq
+    if (c.lin_dq) {
+        DevBuf clash;
+        if ((rc = clash.alloc(ctx, 16))) {
+            free_cal(c);
+            return rc;
+        }
+        uint32_t h_clash[3] = {0, 0, 0};
+        RIP_HIP(ctx, hipMemsetAsync(clash.p, 0, 16, ctx->stream));
+        for (int combo = 1; combo < 4 && !rc; ++combo) {
+            const bool ff = (combo & 1) && c.has_flat, dd = (combo & 2) && c.has_dark_dq;
+            if (((combo & 1) && !c.has_flat) || ((combo & 2) && !c.has_dark_dq)) continue;   // nothing to add: see below
+            rc = rip_launch_merge_dq(ctx, c.lin_dq, ff ? c.flat_flags : nullptr, dd ? c.dark_dq : nullptr, (uint32_t *)plane(8 + combo),
+                                     c.ny, c.nx, c.nb, clash.as<uint32_t>() + (combo - 1));
+        }
+        if (!rc) {
+            hipError_t em = hipMemcpyAsync(h_clash, clash.p, 12, hipMemcpyDeviceToHost, ctx->stream);
+            if (em == hipSuccess) em = hipStreamSynchronize(ctx->stream);
+            if (em != hipSuccess) rc = rip_fail(ctx, RIP_EHIP, "caldir upload: %s", hipGetErrorString(em));
+        }
+        if (rc) {
+            free_cal(c);
+            return rc;
+        }
+        for (int combo = 1; combo < 4; ++combo) {
+            const int eff = (c.has_flat ? (combo & 1) : 0) | (c.has_dark_dq ? (combo & 2) : 0);   // what this set can add at all
+            c.merged_plane[combo] = eff == 0 ? 3 : (h_clash[eff - 1] ? -1 : 8 + eff);
+        }
     }
 #undef UP
 #undef UPS
@@ -850,6 +879,9 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         ca.nb = c.nb;
         ca.ngrp = G;
         ca.dense = plan->d_dense;
+        // the flag word that holds what this call's finish step ORs into pixeldq (flat flags with the flat stage, dark dq with
+        // the dark stage): -1 = not mergeable for this CALDIR set, the wave-specialised kernel is then not taken
+        ca.merged_dq = c.merged_plane[((flat_plane ? 1 : 0) | ((stages & RIP_STAGE_DARK) ? 2 : 0))];
         ca.dbg = ctx->chain_dbg;
         ca.dbg_buf = ctx->chain_dbg_buf;
         if ((rc = rip_launch_chain(ctx, plan, ca, c.lin_nplanes, c.ipc_dtype))) return rc;

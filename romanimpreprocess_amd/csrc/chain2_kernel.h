@@ -162,8 +162,11 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
     double *O1d = reinterpret_cast<double *>(O12);                  // f64 ipc4d: [G][3][C2_COLS] instead
     uint32_t *DQ = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(O12) +
                                                 (size_t)G * 3 * C2_COLS * sizeof(KT));  // [4][C2_COLS] linearity dq of the row
-    uint32_t *QS = DQ + 4 * C2_COLS;                                // [4][QW][C2_COLS] groupdq bytes of the pixel, packed
-    double *LN = reinterpret_cast<double *>(QS + 4 * QW * C2_COLS);  // [3][G][2] channel lines of this strip
+    // per-pixel words that travel from the ingest thread of a column to its fit thread (3-row rings, slots as the x ring: the fit
+    // thread takes row r+1's at the end of step r): the flag word, the packed groupdq bytes, the gain
+    uint32_t *QS = DQ + 3 * C2_COLS;                                // [3][QW][C2_COLS] groupdq bytes of the pixel, packed
+    float *GN = reinterpret_cast<float *>(QS + 3 * QW * C2_COLS);   // [3][C2_COLS] gain of the pixel (f32)
+    double *LN = reinterpret_cast<double *>(GN + 3 * C2_COLS);       // [3][G][2] channel lines of this strip
     // K ring: the nine IPC coefficients of destination (row, col), loaded ONCE by the ingest thread of the column and handed to
     // its fit thread (two rows live: C of row y runs two steps before O2 of row y)
     f2 *KR2 = reinterpret_cast<f2 *>(LN + 3 * G * 2);               // f32 ipc4d: [2][4][C2_COLS] pairs (k0,k1)..(k6,k7)
@@ -239,6 +242,10 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
     const unsigned lane_mask = fit_role ? ((col >= 2 && col < C2_COLS - 2) ? colmask : 0u)
                                         : ((col >= 1 && col < C2_COLS - 1) ? colmask : 0u);
     const unsigned row4 = (unsigned)nx * 4u;  // row pitch of an f32/u32 plane; offsets within a plane fit 32 bits
+    // rows this (strip, row range) cell really uses: R0-2 .. R1+1 (two halo rows on each side).  The straight-line loads of the
+    // warm-up and drain steps are clamped INTO that band, so that they touch lines the cell reads anyway instead of 3-5 rows of
+    // its neighbours' (each such row costs HBM traffic and buys nothing)
+    const int ylo = max(R0 - 2, 0), yhi = min(R1 + 1, ny - 1);
 
     // coefficient loader: raw loads at clamped source positions + validity mask for destination (y, c);
     // `want` is wave-uniform.  Planes are walked in memory order (plane = 3*(1+dy) + (1+dx)).
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         for (int dyi = 0; dyi < 3; ++dyi) {
             const int sy = y - (dyi - 1);
             rok[dyi] = sy >= ay0 && sy < ay1;
-            rowoff[dyi] = (unsigned)min(max(sy, 0), ny - 1) * row4;
+            rowoff[dyi] = (unsigned)min(max(sy, ylo), yhi) * row4;   // rows outside the range's own are never used: keep to lines it reads anyway
         }
         // terms by source row: dy = -1 -> k in {2, 7, 8}, dy = 0 -> {0, 3, 4}, dy = +1 -> {1, 5, 6}
         const unsigned rowbits = (rok[0] ? 0x184u : 0u) | (rok[1] ? 0x019u : 0u) | (rok[2] ? 0x062u : 0u);
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         for (int dyi = 0; dyi < 3; ++dyi) {
             const int sy = y - (dyi - 1);
             rok[dyi] = sy >= ay0 && sy < ay1;
-            rowoff[dyi] = (unsigned)min(max(sy, 0), ny - 1) * (row4 * 2u);
+            rowoff[dyi] = (unsigned)min(max(sy, ylo), yhi) * (row4 * 2u);
         }
         const unsigned rowbits = (rok[0] ? 0x184u : 0u) | (rok[1] ? 0x019u : 0u) | (rok[2] ? 0x062u : 0u);
         const __amdgpu_buffer_rsrc_t kr = c2_rsrc(kern_base);
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         auto fetch_groups = [&](const RIP_K ChainArgs *ka, int y, int g0, int g1, RowRegs<NP, G> &rr) {
             if ((dbg & 64) && y > R0 - 2) return;   // timing experiment: every row works on the first row's (valid) values
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
+            const unsigned yl = (unsigned)min(max(y, ylo), yhi);
             const __amdgpu_buffer_rsrc_t rs = c2_rsrc(ka->data), rq = c2_rsrc(ka->gdq), rd = c2_rsrc(ka->dark_data),
                                          rb = c2_rsrc(ka->bias);
             unsigned o4 = yl * row4 + (unsigned)g0 * pl4, o2 = yl * (row4 >> 1) + (unsigned)g0 * (pl4 >> 1),
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         auto fetch_coefs = [&](const RIP_K ChainArgs *ka, int y, int i0, int i1, RowRegs<NP, G> &rr) {
             if ((dbg & 64) && y > R0 - 2) return;
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
+            const unsigned yl = (unsigned)min(max(y, ylo), yhi);
             const __amdgpu_buffer_rsrc_t rp = c2_rsrc(ka->planes);
             unsigned o4 = yl * row4 + (unsigned)i0 * pl4;
 #pragma unroll
@@ -372,8 +379,8 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                     rr.smax = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
                 else if (i == NP + 2)
                     rr.sref = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
-                else if (i == NP + 3)
-                    rr.dq = c2_ld_u32<C2_NT_C>(rp, cc4, o4);
+                else if (i == NP + 3)   // the flag word: linearity dq merged with what the finish step ORs into pixeldq (RipCal)
+                    rr.dq = c2_ld_u32<C2_NT_C>(rp, cc4, yl * row4 + (unsigned)(NP + ka->merged_dq) * pl4);
                 else
                     rr.gain = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
                 o4 += pl4;
@@ -429,8 +436,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             // row.  The loads are issued UNCONDITIONALLY between the blocks (the wait-count pass is path-insensitive: a
             // load that exists on one side of a branch only forces vmcnt(0) at later uses).  All lanes compute (lanes
             // beyond the frame edge work on the clamped column and store zeros).
-            const int slot = yi & 3;                         // 4-row rings of the per-pixel words
-            const int xslot = (so_c == 2) ? 0 : so_c + 1;    // x ring (3 rows): row yi = r + 3 takes the slot of row r
+            const int xslot = (so_c == 2) ? 0 : so_c + 1;    // 3-row rings (x and the per-pixel words): row yi = r + 3 takes the slot of row r
             f2 *xs = X2 + xslot * C2_COLS + col;
             const bool act = col_act && yi >= ay0 && yi < ay1;
             uint32_t dq = rr.dq;
@@ -574,9 +580,10 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             }
             if (do_a) {
                 const bool keep = a_full && col_ok;
-                DQ[slot * C2_COLS + col] = keep ? dq : 0u;
+                DQ[xslot * C2_COLS + col] = keep ? dq : 0u;
 #pragma unroll
-                for (int i = 0; i < QW; ++i) QS[(slot * QW + i) * C2_COLS + col] = keep ? w[i] : 0u;
+                for (int i = 0; i < QW; ++i) QS[(xslot * QW + i) * C2_COLS + col] = keep ? w[i] : 0u;
+                GN[xslot * C2_COLS + col] = rr.gain;
             }
 #if !C2_KEARLY
             // IPC coefficients of row yc, consumed by C after the barrier; issued here so that their registers are not live
@@ -673,12 +680,15 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         const RipVariant v0 = rip_load_variant(vars, 0);
         const RipFitConst fc0 = rip_fit_const(h);
         constexpr int start = START;  // first group of the fit (exclude_first)
-        float gain_next = 1.0f;
+        float gain_next = 1.0f;   // gain, flag word and packed groupdq bytes of (row r + 1, own column): from the rings, like xnext
+        uint32_t dq_next = 0, qw_next[QW];
+#pragma unroll
+        for (int i = 0; i < QW; ++i) qw_next[i] = 0;
         int o0_r = (R0 - 5 + 3000) % 3;  // O1 ring slot of row r
         for (int r = R0 - 5; r <= R1; ++r, o0_r = (o0_r == 2) ? 0 : o0_r + 1) {
             const bool emit = (r >= R0) && (r < R1) && col >= 2 && col < C2_COLS - 2 && col_ok;
             const RIP_K C2KernArgs *kf = c2_args(kargs);  // S1 copy of the argument block
-            const unsigned rc_ = (unsigned)min(max(r, 0), ny - 1);
+            const unsigned rc_ = (unsigned)min(max(r, R0), yhi);   // (rows before R0 are warm-up steps: nothing is emitted there)
             const unsigned pe = rc_ * (unsigned)nx + cc1;
             // ---- S1: read noise of the pixel (used by the fit), then the second IPC iterate of row r
             const __amdgpu_buffer_rsrc_t rpl = c2_rsrc(kf->a.planes);
@@ -690,14 +700,11 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             const size_t t_row4 = (size_t)t_row;
             const size_t pe_row = (size_t)(rc_ * (unsigned)nx);   // element offset of row r
             const float e_dark = c2_ld_f32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_ld);
-            const uint32_t e_ff = c2_ld_u32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 8) * pl4 + t_ld);
+            // (flat flags and dark dq arrive with the linearity dq of the pixel: ChainArgs::merged_dq)
             const uint32_t e_pdq = c2_ld_u32<C2_NT_F>(c2_rsrc(kf->a.pdq), cc4, t_ld);
             // flat / dark_dq == null: read the first slab plane instead (value unused), keeps the loads in one block
             const float e_flat_raw = c2_ld_f32<C2_NT_F>(c2_rsrc(kf->a.flat ? (const void *)kf->a.flat : (const void *)kf->a.planes), cc4, t_ld);
             const float e_flat = kf->a.flat ? e_flat_raw : 1.0f;
-            const uint32_t e_ddq_raw =
-                c2_ld_u32<C2_NT_F>(c2_rsrc(kf->a.dark_dq ? (const void *)kf->a.dark_dq : (const void *)kf->a.planes), cc4, t_ld);
-            const uint32_t e_ddq = kf->a.dark_dq ? e_ddq_raw : 0u;
             float d[G];
             f2 dpair[GP];
             uint32_t qw[QW];  // the pixel's groupdq bytes, packed
@@ -710,7 +717,6 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             C2_DRAIN()
             CH_T(1)
             if (emit) {
-                const int sx = r & 3;
                 // the nine coefficients of destination (r, col) from the ingest thread of this column
                 f2 kF[5];
                 double kFd[9];
@@ -728,8 +734,8 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 }
                 const unsigned vF = k_valid(r);
 #pragma unroll
-                for (int i = 0; i < QW; ++i) qw[i] = QS[(sx * QW + i) * C2_COLS + col];
-                lin_dq = DQ[sx * C2_COLS + col];
+                for (int i = 0; i < QW; ++i) qw[i] = qw_next[i];
+                lin_dq = dq_next;
                 const bool fastdiv = __all(rcp_safe(e_gain) || !act);
                 const float rgain = rip_rcp_mid(e_gain);
                 const bool all = __all(vF == 0x1ffu || !act);
@@ -826,9 +832,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             C2_SYNC();
             CH_T(3)
             const RIP_K C2KernArgs *kg = c2_args(kargs);  // S2 copy
-            // ---- S2: coefficients and gain of the next row's O2, second half of the fit, tail of pixel (r, c)
-            gain_next = c2_ld_f32<C2_NT_F>(c2_rsrc(kg->a.planes), cc4,
-                                          (unsigned)(NP + 4) * pl4 + ((dbg & 256) ? 0u : (unsigned)min(max(r + 1, 0), ny - 1) * row4));
+            // ---- S2: second half of the fit, tail of pixel (r, c); at its end the per-pixel words of row r + 1 from the rings
             CH_T(4)
             C2_DRAIN()
             CH_T(5)
@@ -872,7 +876,6 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                                                               (ep == 0.0f || rip_mid36(ep)) && e_flat > 0.0f && rip_mid36(e_flat));
                         if (lean) {
                             const float err = hypot_f32(er, ep);
-                            pdq |= e_ddq | e_ff;
                             const float ep2 = ep;  // sqrt(ep * ep)
                             const float e2 = err * err;
                             const float p2 = ep2 * ep2;
@@ -890,13 +893,11 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                                 vp = 0.0f;
                             }
                             if (act && kg->a.dark_rate) s = s - e_dark;
-                            if (act) pdq |= e_ddq;
                             float ep2 = sqrtf(vp);
                             const float e2 = err * err;
                             const float p2 = ep2 * ep2;
                             float er2 = sqrtf(clip_lo<float>(e2 - p2, 0.0f));
                             if (kg->a.flat) {
-                                pdq |= e_ff;
                                 s = s / e_flat;
                                 er2 = er2 / e_flat;
                                 ep2 = ep2 / e_flat;
@@ -920,6 +921,10 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 const int sn = (o0_r == 2) ? 0 : o0_r + 1;
 #pragma unroll
                 for (int p0 = 0; p0 < GP; ++p0) xnext[p0] = X2[(p0 * XR + sn) * C2_COLS + col];
+#pragma unroll
+                for (int i = 0; i < QW; ++i) qw_next[i] = QS[(sn * QW + i) * C2_COLS + col];
+                dq_next = DQ[sn * C2_COLS + col];
+                gain_next = GN[sn * C2_COLS + col];
             }
             CH_T(6)
             C2_SYNC();
@@ -935,8 +940,8 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
 }
 
 static inline size_t chain2_lds_bytes(int G, size_t ksize = 4) {
-    // x ring (3 rows) + O1 ring (3 rows) + linearity dq / packed groupdq rings (4 rows) + channel lines + K ring (2 rows)
-    return (size_t)(G / 2) * C2_COLS * 8 * 3 + (size_t)G * C2_COLS * ksize * 3 + (size_t)C2_COLS * 4 * 4 * (1 + (G + 3) / 4) +
+    // x ring (3 rows) + O1 ring (3 rows) + flag word / packed groupdq / gain rings (3 rows) + channel lines + K ring (2 rows)
+    return (size_t)(G / 2) * C2_COLS * 8 * 3 + (size_t)G * C2_COLS * ksize * 3 + (size_t)C2_COLS * 4 * 3 * (2 + (G + 3) / 4) +
            (size_t)3 * G * 2 * 8 + (size_t)2 * 9 * C2_COLS * ksize;
 }
 

@@ -185,6 +185,29 @@ __global__ __launch_bounds__(256) void sat_flags_kernel(const uint64_t *__restri
     *reinterpret_cast<uint4 *>(pdq_out + p) = pd;
 }
 
+// flag word of the wave-specialised fused kernel: linearity dq with the words its finish step ORs into pixeldq anyway
+__global__ void merge_dq_kernel(const uint32_t *__restrict__ lin_dq, const uint32_t *__restrict__ flat_flags,
+                                const uint32_t *__restrict__ dark_dq, uint32_t *__restrict__ out, int ny, int nx, int nb,
+                                uint32_t *__restrict__ clash) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ny * nx) return;
+    const int y = (int)(i / nx), x = (int)(i % nx);
+    const bool act = y >= nb && y < ny - nb && x >= nb && x < nx - nb;
+    uint32_t add = flat_flags ? flat_flags[i] : 0u;
+    if (dark_dq && act) add |= dark_dq[i];   // gen_cal_image.py:213-229: the dark step works on the active region
+    out[i] = lin_dq[i] | add;
+    if (add & (DQ_NO_LIN_CORR | DQ_REFERENCE_PIXEL)) atomicOr(clash, 1u);
+}
+
+int rip_launch_merge_dq(rip_ctx *ctx, const uint32_t *lin_dq, const uint32_t *flat_flags, const uint32_t *dark_dq, uint32_t *out, int ny,
+                        int nx, int nb, uint32_t *d_clash) {
+    const size_t n = (size_t)ny * nx;
+    hipLaunchKernelGGL(merge_dq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lin_dq, flat_flags, dark_dq, out, ny,
+                       nx, nb, d_clash);
+    RIP_HIP(ctx, hipGetLastError());
+    return RIP_OK;
+}
+
 int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const float *thr, const uint32_t *sat_dq,
                        const uint8_t *gdq_in, const uint32_t *pdq_in, uint8_t *gdq_out, uint32_t *pdq_out, int G, int ny,
                        int nx, int backup, int skip_firstn, int dnu_first, const double *dilution) {

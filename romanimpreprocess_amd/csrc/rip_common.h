@@ -106,8 +106,14 @@ struct RipCal {
     // one allocation holding the per-pixel planes the fused kernel walks together, in this order:
     //   [0,NP) Legendre planes | NP Smin | NP+1 Smax | NP+2 Sref | NP+3 lin dq (u32) | NP+4 gain (f32 only)
     //   | NP+5 read noise | NP+6 dark rate | NP+7 flat_dn | NP+8 flat flags (u32)
+    //   | NP+9 lin dq OR flat flags | NP+10 lin dq OR dark dq (active region) | NP+11 lin dq OR both   (u32: the flag words the
+    //     wave-specialised fused kernel reads in place of NP+3, so that its fit role need not load flat flags / dark dq)
     // (lin_coefs, lin_smin, ..., read_noise, dark_rate, flat_dn, flat_flags point into it)
     float *slab = nullptr;
+    // merged_plane[c], c = (flat flags in ? 1 : 0) | (dark dq in ? 2 : 0): plane index relative to NP (3 = the linearity dq alone),
+    // or -1 where merging would change the linearity test (an added word carries NO_LIN_CORR / REFERENCE_PIXEL: never seen in a
+    // reference-written file; the dispatcher then takes another kernel form)
+    int merged_plane[4] = {3, -1, -1, -1};
     size_t bytes = 0;
 };
 
@@ -255,6 +261,7 @@ struct ChainArgs {
     float *cube_out;   // may be null
     const RipDense *dense;        // RipPlan::d_dense
     unsigned long long *dbg_buf;  // CH_STAMP builds only: per-wave phase cycle sums
+    int merged_dq;     // plane index (relative to NP) of the flag word that already holds flat flags / dark dq as this call applies them
     int dbg;           // timing experiments only (rip_set_option "chain_dbg"): skips phases, results invalid
     int ny, nx, nb, ngrp;
 };
@@ -304,6 +311,9 @@ int rip_launch_embed(rip_ctx *ctx, const void *src, void *dst, int nplanes, int 
 int rip_launch_flat_prepare(rip_ctx *ctx, const float *flat, const void *gain, int g_dtype, int ny, int nx, int nb,
                             float *flat_padded, void *gain_clipped, uint32_t *flags, int with_gain);
 int rip_launch_flat_area(rip_ctx *ctx, const float *flat_dn, const double *area, float *out, size_t n);
+// out = lin_dq | (flat_flags or 0) | (dark_dq on the active region or 0); *d_clash |= added bits & (NO_LIN_CORR | REFERENCE_PIXEL)
+int rip_launch_merge_dq(rip_ctx *ctx, const uint32_t *lin_dq, const uint32_t *flat_flags, const uint32_t *dark_dq, uint32_t *out, int ny,
+                        int nx, int nb, uint32_t *d_clash);
 // dq-init + saturation flagging (misc.hip): gdq_in / pdq_in may be null (= zeros)
 int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const float *thr, const uint32_t *sat_dq,
                        const uint8_t *gdq_in, const uint32_t *pdq_in, uint8_t *gdq_out, uint32_t *pdq_out, int G, int ny,

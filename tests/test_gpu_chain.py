@@ -785,3 +785,53 @@ def test_read_file_without_reference_output(form):
     finally:
         _default_form(ctx)
         cb.ctx.drop_caldir(10)
+
+
+@pytest.mark.parametrize("clash", [False, True])
+def test_flat_flags_and_dark_dq_reach_pixeldq_through_the_merged_flag_word(clash):
+    """The wave-specialised kernel reads ONE flag word per pixel (linearity dq merged with the flat flags and the dark dq on the
+    active region, built at rip_caldir_upload) instead of three planes.  A dark file with dq bits and a flat with out-of-range
+    pixels must give the oracle's pixeldq bit for bit; when an added word carries NO_LIN_CORR / REFERENCE_PIXEL (it would change
+    the linearity test) the set is not mergeable and another kernel form runs -- same results."""
+    rp = synth.READ_PATTERN_8
+    ny, nx = 48, 384
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=91, bias_amplitude=1.0, bad_lin_frac=0.01)
+    rng = np.random.default_rng(92)
+    ddq = np.where(rng.random((ny, nx)) < 0.05, np.uint32(1) << rng.integers(3, 18, size=(ny, nx)).astype(np.uint32), 0).astype(np.uint32)
+    ddq[0, 0] = ddq[1, 200] = 1 << 9          # on the reference-pixel border: the dark step never reaches it
+    if clash:
+        ddq[20, 50] |= np.uint32(1 << 20)     # NO_LIN_CORR in the dark dq
+    cal["dark"] = dict(cal["dark"], dq=ddq)
+    flat = cal["flat"]["data"].copy()
+    flat[10, 10], flat[11, 300], flat[30, 77] = 0.01, 50.0, 0.05      # NO_FLAT_FIELD
+    cal["flat"] = dict(cal["flat"], data=flat)
+    gain = cal["gain"]["data"].copy()
+    gain[12, 12] = 0.05                                               # NO_GAIN_VALUE
+    cal["gain"] = dict(cal["gain"], data=gain)
+    ramp = synth.make_ramp(cal, read_pattern=rp, seed=93, cr_frac=0.02)
+    with np.errstate(all="ignore"):
+        ref = oracle.calibrate_arrays(ramp, cal)
+    ctx = gpu_context()
+    _default_form(ctx)
+    cb = pipeline.Calibrator(ctx=ctx)
+    cb.load_caldir(11, cal)
+    try:
+        got = cb.calibrate(11, ramp, channel_lines=_oracle_lines(ref, len(rp), nx // 128))
+        form = ctx.last_chain_form()
+        assert (form != 2) if clash else (form == 2), form
+        assert_same_bits(got["pixeldq"], ref["pixeldq"], "pixeldq")
+        assert_same_bits(got["groupdq"], ref["groupdq"], "groupdq")
+        for k in ("slope", "err_read", "err_poisson"):
+            assert_same_bits(got[k], ref[k], k, zero_sign_ok=True)
+        # the flags are there: dark dq on active pixels only, flat and gain flags
+        assert (got["pixeldq"][4:-4, 4:-4] & ddq[4:-4, 4:-4] == ddq[4:-4, 4:-4]).all() and not (got["pixeldq"][0, 0] & (1 << 9))
+        assert got["pixeldq"][10, 10] & (1 << 18) and got["pixeldq"][12, 12] & (1 << 19)
+        # a sub-chain without the flat stage: the flat flags must not appear (another merged word, or none)
+        no_flat = cb.calibrate(11, ramp, stages=pipeline.STAGE_ALL & ~pipeline.STAGE_FLAT, channel_lines=_oracle_lines(ref, len(rp), nx // 128))
+        assert not (no_flat["pixeldq"][10, 10] & (1 << 18)) and (no_flat["pixeldq"][4:-4, 4:-4] & ddq[4:-4, 4:-4] == ddq[4:-4, 4:-4]).all()
+        no_dark = cb.calibrate(11, ramp, stages=pipeline.STAGE_ALL & ~pipeline.STAGE_DARK, channel_lines=_oracle_lines(ref, len(rp), nx // 128))
+        assert no_dark["pixeldq"][10, 10] & (1 << 18)
+        sel = (ddq[4:-4, 4:-4] != 0) & ((ref["pixeldq"][4:-4, 4:-4] & ~ddq[4:-4, 4:-4]) == (no_dark["pixeldq"][4:-4, 4:-4]))
+        assert sel.sum() > 10     # pixels whose only extra flags were the dark's: gone without the dark stage
+    finally:
+        cb.ctx.drop_caldir(11)
