@@ -24,8 +24,9 @@ C3_DECL(11)
 
 int rip_launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int nplanes, int k_dtype) {
     // wave-private kernel (chain3_kernel.h) first; 1 = no instantiation for this plan
-    const bool only3 = a.ngrp == 16 && k_dtype == RIP_F64;  // no other fused instantiation
-    const bool want3 = ctx->use_chain3 == 1 || (ctx->use_chain3 == 2 && k_dtype == RIP_F64);
+    const bool only3 = a.ngrp == 16 && k_dtype == RIP_F64 && a.merged_dq >= 0;  // no other specialised instantiation
+    // (merged_dq < 0: the flag words of this CALDIR set cannot be merged, RipCal -- the specialised kernels are not taken)
+    const bool want3 = (ctx->use_chain3 == 1 || (ctx->use_chain3 == 2 && k_dtype == RIP_F64)) && a.merged_dq >= 0;
     if ((want3 || only3) && (nplanes == 4 || nplanes == 9 || nplanes == 11)) {
         const bool k64 = k_dtype == RIP_F64;
         int rc = 1;

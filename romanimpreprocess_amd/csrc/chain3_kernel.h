@@ -234,8 +234,11 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     };
 
     // ---- loaders (buffer loads: scalar base + plane/row scalar offset + loop-invariant per-lane column offset)
+    // rows this wave's range really uses: R0-2 .. R1+1; the loads of the drain steps are clamped into that band (lines the wave
+    // reads anyway) instead of fetching a row of the next range's
+    const int ylo = max(R0 - 2, 0), yhi = min(R1 + 1, ny - 1);
     auto fetch_groups = [&](const RIP_K ChainArgs *ka, int y, RowRegs<NP, G> &rr, int g_lo, int g_hi) {
-        const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
+        const unsigned yl = (unsigned)min(max(y, ylo), yhi);
         const __amdgpu_buffer_rsrc_t rs = c2_rsrc(ka->data), rq = c2_rsrc(ka->gdq), rd = c2_rsrc(ka->dark_data),
                                      rb = c2_rsrc(ka->bias);
         unsigned o4 = yl * row4 + (unsigned)g_lo * pl4, o2 = yl * (row4 >> 1) + (unsigned)g_lo * (pl4 >> 1),
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     };
     // planes i0..i1-1 of [cf[0..NP-1], Smin, Smax, Sref, dq, gain]
     auto fetch_coefs = [&](const RIP_K ChainArgs *ka, int y, RowRegs<NP, G> &rr, int i0, int i1) {
-        const unsigned yl = (unsigned)min(max(y, 0), ny - 1);
+        const unsigned yl = (unsigned)min(max(y, ylo), yhi);
         const __amdgpu_buffer_rsrc_t rp = c2_rsrc(ka->planes);
         unsigned o4 = yl * row4 + (unsigned)i0 * pl4;
 #pragma unroll
@@ -266,8 +269,8 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
                 rr.smax = c2_ld_f32<0>(rp, cc4, o4);
             else if (i == NP + 2)
                 rr.sref = c2_ld_f32<0>(rp, cc4, o4);
-            else if (i == NP + 3)
-                rr.dq = c2_ld_u32<0>(rp, cc4, o4);
+            else if (i == NP + 3)   // the flag word: linearity dq merged with the flat flags / dark dq this call applies (RipCal)
+                rr.dq = c2_ld_u32<0>(rp, cc4, yl * row4 + (unsigned)(NP + ka->merged_dq) * pl4);
             else
                 rr.gain = c2_ld_f32<0>(rp, cc4, o4);
             o4 += pl4;
@@ -278,8 +281,8 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
     auto fetch_kset = [&](const RIP_K ChainArgs *ka, int y, C3KSet<T> &k) {
         const __amdgpu_buffer_rsrc_t kr = c2_rsrc(ka->kern);
         const unsigned rowK = row4 * (unsigned)(sizeof(KT) / 4), plK = pl4 * (unsigned)(sizeof(KT) / 4);
-        const unsigned om = (unsigned)min(max(y - 1, 0), ny - 1) * rowK, oz = (unsigned)min(max(y, 0), ny - 1) * rowK,
-                       op = (unsigned)min(max(y + 1, 0), ny - 1) * rowK;
+        const unsigned om = (unsigned)min(max(y - 1, ylo), yhi) * rowK, oz = (unsigned)min(max(y, ylo), yhi) * rowK,
+                       op = (unsigned)min(max(y + 1, ylo), yhi) * rowK;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             if constexpr (K64) {
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
         const int yc = yi - 1, r = yi - 2;
         const bool do_c = (yc >= R0 - 1) && (yc <= R1);
         const bool do_e = (r >= R0) && (r < R1);
-        const unsigned rc_ = (unsigned)min(max(r, 0), ny - 1);
+        const unsigned rc_ = (unsigned)min(max(r, max(R0, 0)), yhi);   // (rows before R0: warm-up steps, nothing is emitted)
         const unsigned t_row = rc_ * row4;
         // Loads are requested in small batches spread over the step (a burst of 30-50 loads per wave stalls the issue of every
         // wave of the CU behind the vector-memory queue).  Row yi+1: Legendre planes after A; Smin..gain and the first quarter
@@ -734,15 +737,13 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
         }
         // what the tail of pixel (r, c) reads: lands while the fit runs
         float e_dark, e_flat_raw;
-        uint32_t e_ff, e_pdq, e_ddq_raw;
+        uint32_t e_pdq;   // (flat flags and dark dq arrive with the linearity dq: ChainArgs::merged_dq)
         {
             const RIP_K ChainArgs *kb = &c2_args(kargs)->a;
             const __amdgpu_buffer_rsrc_t rpl = c2_rsrc(kb->planes);
             e_dark = c2_ld_f32<0>(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_row);
-            e_ff = c2_ld_u32<0>(rpl, cc4, (unsigned)(NP + 8) * pl4 + t_row);
             e_pdq = c2_ld_u32<0>(c2_rsrc(kb->pdq), cc4, t_row);
             e_flat_raw = c2_ld_f32<0>(c2_rsrc(kb->flat ? (const void *)kb->flat : (const void *)kb->planes), cc4, t_row);
-            e_ddq_raw = c2_ld_u32<0>(c2_rsrc(kb->dark_dq ? (const void *)kb->dark_dq : (const void *)kb->planes), cc4, t_row);
         }
         CH_T(5)
         C3_SYNC();
@@ -752,7 +753,6 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
         if (do_e && emit_lane && !(dbg & 8)) {
             const RIP_K C2KernArgs *kg = c2_args(kargs);
             const float e_flat = kg->a.flat ? e_flat_raw : 1.0f;
-            const uint32_t e_ddq = kg->a.dark_dq ? e_ddq_raw : 0u;
             const unsigned pe = rc_ * (unsigned)nx + cc1;
             if (kg->a.cube_out) {
 #pragma unroll
@@ -787,7 +787,6 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
                                                       (ep == 0.0f || rip_mid36(ep)) && e_flat > 0.0f && rip_mid36(e_flat));
                 if (lean) {
                     const float err = hypot_f32(er, ep);
-                    pdq |= e_ddq | e_ff;
                     const float ep2 = ep;  // sqrt(ep * ep)
                     const float e2 = err * err;
                     const float p2 = ep2 * ep2;
@@ -805,13 +804,11 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
                         vp = 0.0f;
                     }
                     if (act && kg->a.dark_rate) s = s - e_dark;
-                    if (act) pdq |= e_ddq;
                     float ep2 = sqrtf(vp);
                     const float e2 = err * err;
                     const float p2 = ep2 * ep2;
                     float er2 = sqrtf(clip_lo<float>(e2 - p2, 0.0f));
                     if (kg->a.flat) {
-                        pdq |= e_ff;
                         s = s / e_flat;
                         er2 = er2 / e_flat;
                         ep2 = ep2 / e_flat;
