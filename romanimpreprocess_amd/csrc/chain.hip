@@ -26,7 +26,9 @@ int rip_launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int 
     // wave-private kernel (chain3_kernel.h) first; 1 = no instantiation for this plan
     const bool only3 = a.ngrp == 16 && k_dtype == RIP_F64 && a.merged_dq >= 0;  // no other specialised instantiation
     // (merged_dq < 0: the flag words of this CALDIR set cannot be merged, RipCal -- the specialised kernels are not taken)
-    const bool want3 = (ctx->use_chain3 == 1 || (ctx->use_chain3 == 2 && k_dtype == RIP_F64)) && a.merged_dq >= 0;
+    // (use_chain3 == 2, the default: where it is the faster fused kernel -- since the f64 chains of the wave-specialised kernel are
+    // batched, round 3, that is only where it is the only one)
+    const bool want3 = ctx->use_chain3 == 1 && a.merged_dq >= 0;
     if ((want3 || only3) && (nplanes == 4 || nplanes == 9 || nplanes == 11)) {
         const bool k64 = k_dtype == RIP_F64;
         int rc = 1;

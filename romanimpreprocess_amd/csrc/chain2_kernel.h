@@ -38,6 +38,21 @@
 #define C2_SYNC() __syncthreads()
 #endif
 #define C2_OUTW (C2_COLS - 4)
+// Where the half-step barrier falls in the fit role: 0 after the first half of the fit, 1 after its second half (and the saturated
+// refits), 2 after the flag propagation and the group-flag stores, 3 after the finish and the plane stores.  Same-box A/B on the
+// bench frame (profiles/r03_summary.md): f32 ipc4d x 8 groups 0.884 / 0.887 / 0.895 ms for 0 / 1 / 2; 16 groups 2.048 / 2.003 /
+// 2.024; f64 ipc4d 1.354 / 1.328 / 1.280 -- the forms whose IPC stages are longer want the barrier later.  -1: per instantiation.
+#ifndef C2_BAR
+#define C2_BAR -1
+#endif
+// Pairs per block of the linearity phase for the forms with a 256-register budget (16 groups: 2.048 -> 2.008 ms with 4; f64 ipc4d:
+// 1.345 -> 1.360, stays 2)
+#ifndef C2_PBW
+#define C2_PBW -1
+#endif
+#ifndef C2_NBO   // f64 ipc4d: groups the second iterate evaluates in lockstep (2 or 4)
+#define C2_NBO 2
+#endif
 
 // Returns x, opaque to the optimiser: used on loop-invariant per-lane offsets right before a global access so that
 // the zero-extension stays next to the address add and instruction selection can use the
@@ -142,6 +157,25 @@ struct C2AllT {
 struct C2SomeT {
     static constexpr bool value = false;
 };
+
+// forward IPC operator in f64 for NBB groups in lockstep (f64 ipc4d): v[b][k] = source value of term k of group b, terms in the
+// reference's order (0 centre, 1 (y-1, x), 2 (y+1, x), 3 (y, x-1), 4 (y, x+1), 5 (y-1, x-1), 6 (y-1, x+1), 7 (y+1, x-1),
+// 8 (y+1, x+1) as the rows / columns of the rings hold them); the NBB products of a term first, then the NBB accumulating adds --
+// independent chains that hide the f64 latencies (one group at a time: 1.51 ms, batched: 1.34 ms for 8 groups, same box).
+// Term order and edge rule of ipc_linearity.py:69-94.
+template <bool ALL, int NBB, typename VT>
+__device__ __forceinline__ void c2_ipc9_batch(const VT (&v)[NBB][9], const double (&kk)[9], unsigned valid, double (&acc)[NBB]) {
+#pragma unroll
+    for (int b = 0; b < NBB; ++b) acc[b] = (double)v[b][0] * kk[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) {
+        double p_[NBB];
+#pragma unroll
+        for (int b = 0; b < NBB; ++b) p_[b] = (double)v[b][k] * kk[k];
+#pragma unroll
+        for (int b = 0; b < NBB; ++b) acc[b] = (ALL || ((valid >> k) & 1u)) ? acc[b] + p_[b] : acc[b];
+    }
+}
 
 template <int NP, int G, int START, typename KT = float>
 __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
@@ -448,7 +482,10 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             const bool fastdiv = __all(rcp_safe(span));
             const float rspan = rip_rcp_mid(span);  // used only when every lane passes rcp_safe (2^-59.8 .. 2^59.8)
             const double yd = (double)yi;
-            constexpr int PB = (GP % 2 == 0) ? 2 : 1;  // pairs per block
+            // pairs per block (their recurrences interleave): 2 at 128 registers; the forms with a 256-register budget (16 groups, f64
+            // ipc4d: one workgroup per CU) may take C2_PBW
+            constexpr int PBW = (C2_PBW > 0) ? C2_PBW : ((G > 8 && !K64) ? 4 : 2);
+            constexpr int PB = ((K64 || G > 8) && GP % PBW == 0) ? PBW : (GP % 2 == 0) ? 2 : 1;
 #pragma unroll
             for (int pb = 0; pb < GP; pb += PB) {
                 f2 zz[PB], SS[PB];
@@ -622,20 +659,32 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                     }
                 }
                 if constexpr (K64) {
-                    const float *Xf = reinterpret_cast<const float *>(X2);
+                    // two pairs (four groups) in lockstep: their 18 ring reads first, then four interleaved f64 chains
+                    constexpr int PBC = (GP % 2 == 0) ? 2 : 1;
 #pragma unroll
-                    for (int p0 = 0; p0 < GP; ++p0) {
-                        fetch_coefs(kb2, r + 4, p0 * CO_STEP, (p0 * CO_STEP + CO_STEP < NCO) ? p0 * CO_STEP + CO_STEP : NCO, rr);
+                    for (int p0 = 0; p0 < GP; p0 += PBC) {
+#pragma unroll
+                        for (int q = 0; q < PBC; ++q)
+                            fetch_coefs(kb2, r + 4, (p0 + q) * CO_STEP, ((p0 + q) * CO_STEP + CO_STEP < NCO) ? (p0 + q) * CO_STEP + CO_STEP : NCO, rr);
                         if (do_c) {
+                            float v[2 * PBC][9];
 #pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const float *xb = Xf + (size_t)p0 * XR * C2_COLS * 2 + e;  // scalar view of the pair-interleaved ring
-                                auto at_m = [&](int dx) { return xb[((sm * C2_COLS) + col + dx) * 2]; };
-                                auto at_0 = [&](int dx) { return xb[((s0 * C2_COLS) + col + dx) * 2]; };
-                                auto at_p = [&](int dx) { return xb[((sp * C2_COLS) + col + dx) * 2]; };
-                                const double f = all ? ipc9(C2AllT{}, at_m, at_0, at_p, kCd, vC) : ipc9(C2SomeT{}, at_m, at_0, at_p, kCd, vC);
-                                const float xc = at_0(0);
-                                O1d[((2 * p0 + e) * 3 + so) * C2_COLS + col] = (double)(xc + xc) - f;
+                            for (int q = 0; q < PBC; ++q) {
+                                const f2 *xb = X2 + (p0 + q) * XR * C2_COLS + col;
+                                const f2 *xm_ = xb + sm * C2_COLS, *x0_ = xb + s0 * C2_COLS, *xp_ = xb + sp * C2_COLS;
+                                const f2 tt[9] = {x0_[0], xm_[0], xp_[0], x0_[-1], x0_[1], xm_[-1], xm_[1], xp_[-1], xp_[1]};
+#pragma unroll
+                                for (int k = 0; k < 9; ++k) v[2 * q][k] = tt[k].x, v[2 * q + 1][k] = tt[k].y;
+                            }
+                            double f[2 * PBC];
+                            if (all)
+                                c2_ipc9_batch<true, 2 * PBC>(v, kCd, vC, f);
+                            else
+                                c2_ipc9_batch<false, 2 * PBC>(v, kCd, vC, f);
+#pragma unroll
+                            for (int b = 0; b < 2 * PBC; ++b) {
+                                const float xc = v[b][0];
+                                O1d[((2 * p0 + b) * 3 + so) * C2_COLS + col] = (double)(xc + xc) - f[b];
                             }
                         }
                     }
@@ -716,6 +765,94 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             CH_T(0)
             C2_DRAIN()
             CH_T(1)
+            constexpr int BAR = (C2_BAR >= 0) ? C2_BAR : (K64 ? 2 : (G > 8 ? 1 : 0));
+            // The tail of pixel (r, c) in three parts; the half-step barrier falls between two of them (C2_BAR: everything after O2 is
+            // register-only in a fit thread, so the barrier sits where both roles take about the same time in both halves).
+            float s = 0.0f, er = 0.0f, ep = 0.0f;
+            uint32_t jmask = 0, pdq = 0;
+            // second half of the fit: exact pass where needed, jump mask; then the saturated refits
+            auto part_fb = [&](const RIP_K C2KernArgs *kx) {
+                if (kx->a.cube_out) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) kx->a.cube_out[(unsigned)g * npix + pe] = d[g];
+                }
+                uint32_t qor = 0;
+#pragma unroll
+                for (int i = 0; i < QW; ++i) qor |= qw[i];
+                const bool anysat = (qor & 0x02020202u) != 0u;
+                const bool unsat = ((qw[(G - 1) / 4] >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
+                if (dbg & 4) {
+                    s = d[0], er = e_read, ep = e_gain;
+                } else {
+                    fit_full_pk_b<G>(dpair, kx->h, fc0, kx->a.dense, kx->kvals + v0.k_ofs, kx->diffs + v0.diff_ofs, unsat && act,
+                                     fs, jmask);
+                    s = fs.s, er = fs.er, ep = fs.ep;
+                    if (__any(anysat)) {
+                        uint32_t qe[G];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) qe[g] = (qw[g / 4] >> (8 * (g & 3))) & 0xffu;
+                        trunc_layers<G, G - 1>(d, qe, kx->h, kx->vars, kx->kvals, kx->diffs, e_gain, e_read, act, kx->guard, s, er, ep,
+                                               jmask);
+                    }
+                }
+            };
+            // T, first part: flag propagation (fitting.py:339-353) and the stores of the group flags
+            auto part_flags = [&](const RIP_K C2KernArgs *kx) {
+                if (dbg & 8) return;
+                uint8_t *gq = (kx->a.gdq_out && !(dbg & 512)) ? kx->a.gdq_out + pe_row : nullptr;
+                pdq = propagate_flags_packed<G>(qw, jmask, start, e_pdq | lin_dq, gq, npix, c2_opaque(cc1));
+            };
+            // T, second part: finish and the stores of the four planes
+            auto part_finish = [&](const RIP_K C2KernArgs *kx) {
+                if (dbg & 8) return;
+                if (kx->a.finish) {
+                    // gen_cal_image.py:458-475, 213-229, 607-629.  One wave vote selects the straight-line form built
+                    // from the short exact operations (rip_rcp_mid, rip_sqrt_mid, sqrt(x*x) = x: tools/gpu_checks/
+                    // fpcheck.hip); every intermediate then lies in their validated range 2^-100 .. 2^100 or is +0.
+                    const float sd = (act && kx->a.dark_rate) ? s - e_dark : s;
+                    const bool lean = kx->a.flat && __all(act && rip_mid36(sd) && (er == 0.0f || rip_mid36(er)) &&
+                                                          (ep == 0.0f || rip_mid36(ep)) && e_flat > 0.0f && rip_mid36(e_flat));
+                    if (lean) {
+                        const float err = hypot_f32(er, ep);
+                        const float ep2 = ep;  // sqrt(ep * ep)
+                        const float e2 = err * err;
+                        const float p2 = ep2 * ep2;
+                        const float er2 = rip_sqrt_mid(clip_lo<float>(e2 - p2, 0.0f));
+                        const float rflat = rip_rcp_mid(e_flat);
+                        s = div_rcp(sd, e_flat, rflat);
+                        er = div_rcp(er2, e_flat, rflat);
+                        ep = div_rcp(ep2, e_flat, rflat);
+                    } else {
+                        float err = hypot_f32(er, ep);
+                        float vp = ep * ep;
+                        if (!act) {
+                            s = 0.0f;
+                            err = 0.0f;
+                            vp = 0.0f;
+                        }
+                        if (act && kx->a.dark_rate) s = s - e_dark;
+                        float ep2 = sqrtf(vp);
+                        const float e2 = err * err;
+                        const float p2 = ep2 * ep2;
+                        float er2 = sqrtf(clip_lo<float>(e2 - p2, 0.0f));
+                        if (kx->a.flat) {
+                            s = s / e_flat;
+                            er2 = er2 / e_flat;
+                            ep2 = ep2 / e_flat;
+                        }
+                        er = er2;
+                        ep = ep2;
+                    }
+                }
+                const unsigned w4 = c2_opaque(cc4);
+                // (dbg & 512: timing experiment without the plane stores; the test keeps the four values live)
+                if (!(dbg & 512) || (s + er + ep == 12345.678f && pdq == 0xdeadbeefu)) {
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(kx->a.slope) + t_row4 + w4) = s;
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(kx->a.err_read) + t_row4 + w4) = er;
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(kx->a.err_poisson) + t_row4 + w4) = ep;
+                    *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kx->a.pdq_out) + t_row4 + w4) = pdq;
+                }
+            };
             if (emit) {
                 // the nine coefficients of destination (r, col) from the ingest thread of this column
                 f2 kF[5];
@@ -742,21 +879,38 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 const int o0_ = o0_r, om_ = (o0_r == 0) ? 2 : o0_r - 1, op_ = (o0_r == 2) ? 0 : o0_r + 1;
                 constexpr int NB = (GP % 2 == 0) ? 2 : 1;
                 if constexpr (K64) {
-                    // f64 iterate: (O1 + x) - fwd(O1) and the division by the gain in f64, one rounding to f32 at the end
+                    // f64 iterate: (O1 + x) - fwd(O1) and the division by the gain in f64, one rounding to f32 at the end; C2_NBO groups in
+                    // lockstep (their ring reads, then interleaved chains), the divisions together at the end.  Lanes that are not
+                    // active (border pixels) evaluate on whatever the rings hold there and keep x.
+                    constexpr int NBO = (G % C2_NBO == 0) ? C2_NBO : 2;
+                    double o2v[G];
+#pragma unroll
+                    for (int gb = 0; gb < G; gb += NBO) {
+                        double v[NBO][9];
+#pragma unroll
+                        for (int b = 0; b < NBO; ++b) {
+                            const double *ob = O1d + (size_t)(gb + b) * 3 * C2_COLS + col;
+                            const double *om = ob + om_ * C2_COLS, *o0 = ob + o0_ * C2_COLS, *op = ob + op_ * C2_COLS;
+                            v[b][0] = o0[0], v[b][1] = om[0], v[b][2] = op[0], v[b][3] = o0[-1], v[b][4] = o0[1], v[b][5] = om[-1],
+                            v[b][6] = om[1], v[b][7] = op[-1], v[b][8] = op[1];
+                        }
+                        double f[NBO];
+                        if (all)
+                            c2_ipc9_batch<true, NBO>(v, kFd, vF, f);
+                        else
+                            c2_ipc9_batch<false, NBO>(v, kFd, vF, f);
+#pragma unroll
+                        for (int b = 0; b < NBO; ++b) {
+                            const float xc = ((gb + b) & 1) ? xnext[(gb + b) / 2].y : xnext[(gb + b) / 2].x;
+                            o2v[gb + b] = (v[b][0] + (double)xc) - f[b];
+                        }
+                    }
+                    const double gd = (double)e_gain;
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const float xc = (g & 1) ? xnext[g / 2].y : xnext[g / 2].x;
-                        float val = xc;
-                        if (act) {
-                            const double *ob = O1d + (size_t)g * 3 * C2_COLS;
-                            auto at_m = [&](int dx) { return ob[om_ * C2_COLS + col + dx]; };
-                            auto at_0 = [&](int dx) { return ob[o0_ * C2_COLS + col + dx]; };
-                            auto at_p = [&](int dx) { return ob[op_ * C2_COLS + col + dx]; };
-                            const double f = all ? ipc9(C2AllT{}, at_m, at_0, at_p, kFd, vF) : ipc9(C2SomeT{}, at_m, at_0, at_p, kFd, vF);
-                            const double o2 = (at_0(0) + (double)xc) - f;
-                            val = (float)(o2 / (double)e_gain);
-                        }
-                        d[g] = val;
+                        const float q_ = (float)(o2v[g] / gd);
+                        d[g] = act ? q_ : xc;
                     }
 #pragma unroll
                     for (int p0 = 0; p0 < GP; ++p0) dpair[p0] = f2{d[2 * p0], d[2 * p0 + 1]};
@@ -827,94 +981,22 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 const bool unsat = ((qw[(G - 1) / 4] >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
                 if (!(dbg & 4))
                     fit_full_pk_a<G, rip_full_valid<G, START>()>(dpair, fc0, v0, kf->a.dense, e_gain, e_read, unsat && act, kf->guard, fs);
+                if (BAR >= 1) part_fb(kf);
+                if (BAR >= 2) part_flags(kf);
+                if (BAR >= 3) part_finish(kf);
             }
             CH_T(2)
             C2_SYNC();
             CH_T(3)
             const RIP_K C2KernArgs *kg = c2_args(kargs);  // S2 copy
-            // ---- S2: second half of the fit, tail of pixel (r, c); at its end the per-pixel words of row r + 1 from the rings
+            // ---- S2: the rest of pixel (r, c) (C2_BAR); at its end the per-pixel words of row r + 1 from the rings
             CH_T(4)
             C2_DRAIN()
             CH_T(5)
             if (emit) {
-                if (kg->a.cube_out) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g) kg->a.cube_out[(unsigned)g * npix + pe] = d[g];
-                }
-                uint32_t qor = 0;
-#pragma unroll
-                for (int i = 0; i < QW; ++i) qor |= qw[i];
-                const bool anysat = (qor & 0x02020202u) != 0u;
-                float s, er, ep;
-                uint32_t jmask = 0;
-                const bool unsat = ((qw[(G - 1) / 4] >> (8 * ((G - 1) & 3))) & DQ_SATURATED) == 0;
-                if (dbg & 4) {
-                    s = d[0], er = e_read, ep = e_gain;
-                } else {
-                    // second half of the fit: exact pass where needed, jump mask; then the saturated refits
-                    fit_full_pk_b<G>(dpair, kg->h, fc0, kg->a.dense, kg->kvals + v0.k_ofs, kg->diffs + v0.diff_ofs, unsat && act,
-                                     fs, jmask);
-                    s = fs.s, er = fs.er, ep = fs.ep;
-                    if (__any(anysat)) {
-                        uint32_t qe[G];
-#pragma unroll
-                        for (int g = 0; g < G; ++g) qe[g] = (qw[g / 4] >> (8 * (g & 3))) & 0xffu;
-                        trunc_layers<G, G - 1>(d, qe, kg->h, kg->vars, kg->kvals, kg->diffs, e_gain, e_read, act, kg->guard, s, er, ep,
-                                               jmask);
-                    }
-                }
-                // ---- T: flag propagation (fitting.py:339-353), finish and stores of pixel (r, c)
-                if (!(dbg & 8)) {
-                    uint8_t *gq = (kg->a.gdq_out && !(dbg & 512)) ? kg->a.gdq_out + pe_row : nullptr;
-                    uint32_t pdq = propagate_flags_packed<G>(qw, jmask, start, e_pdq | lin_dq, gq, npix, c2_opaque(cc1));
-                    if (kg->a.finish) {
-                        // gen_cal_image.py:458-475, 213-229, 607-629.  One wave vote selects the straight-line form built
-                        // from the short exact operations (rip_rcp_mid, rip_sqrt_mid, sqrt(x*x) = x: tools/gpu_checks/
-                        // fpcheck.hip); every intermediate then lies in their validated range 2^-100 .. 2^100 or is +0.
-                        const float sd = (act && kg->a.dark_rate) ? s - e_dark : s;
-                        const bool lean = kg->a.flat && __all(act && rip_mid36(sd) && (er == 0.0f || rip_mid36(er)) &&
-                                                              (ep == 0.0f || rip_mid36(ep)) && e_flat > 0.0f && rip_mid36(e_flat));
-                        if (lean) {
-                            const float err = hypot_f32(er, ep);
-                            const float ep2 = ep;  // sqrt(ep * ep)
-                            const float e2 = err * err;
-                            const float p2 = ep2 * ep2;
-                            const float er2 = rip_sqrt_mid(clip_lo<float>(e2 - p2, 0.0f));
-                            const float rflat = rip_rcp_mid(e_flat);
-                            s = div_rcp(sd, e_flat, rflat);
-                            er = div_rcp(er2, e_flat, rflat);
-                            ep = div_rcp(ep2, e_flat, rflat);
-                        } else {
-                            float err = hypot_f32(er, ep);
-                            float vp = ep * ep;
-                            if (!act) {
-                                s = 0.0f;
-                                err = 0.0f;
-                                vp = 0.0f;
-                            }
-                            if (act && kg->a.dark_rate) s = s - e_dark;
-                            float ep2 = sqrtf(vp);
-                            const float e2 = err * err;
-                            const float p2 = ep2 * ep2;
-                            float er2 = sqrtf(clip_lo<float>(e2 - p2, 0.0f));
-                            if (kg->a.flat) {
-                                s = s / e_flat;
-                                er2 = er2 / e_flat;
-                                ep2 = ep2 / e_flat;
-                            }
-                            er = er2;
-                            ep = ep2;
-                        }
-                    }
-                    const unsigned w4 = c2_opaque(cc4);
-                    // (dbg & 512: timing experiment without the plane stores; the test keeps the four values live)
-                    if (!(dbg & 512) || (s + er + ep == 12345.678f && pdq == 0xdeadbeefu)) {
-                        *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.slope) + t_row4 + w4) = s;
-                        *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_read) + t_row4 + w4) = er;
-                        *reinterpret_cast<float *>(reinterpret_cast<char *>(kg->a.err_poisson) + t_row4 + w4) = ep;
-                        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kg->a.pdq_out) + t_row4 + w4) = pdq;
-                    }
-                }
+                if (BAR < 1) part_fb(kg);
+                if (BAR < 2) part_flags(kg);
+                if (BAR < 3) part_finish(kg);
             }
             // x of (r + 1, own column) for the next step's O2: its ring slot is overwritten in S1 of that step (row r + 4)
             {

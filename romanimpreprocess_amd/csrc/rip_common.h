@@ -126,9 +126,10 @@ struct rip_ctx {
     int parity = 0;
     bool use_overlap = true;
     bool use_chain2 = true;  // wave-specialised fused kernel where it applies
-    // wave-private fused kernel (chain3_kernel.h): 2 (default) = where it is the faster fused kernel by measurement (f64 ipc4d:
-    // 1.47 ms against 1.58 ms for the wave-specialised kernel on 8 groups, and the only instantiation for 16), 1 = wherever it
-    // is instantiated, 0 = only where nothing else fits.  Same-box A/B, profiles/r02_summary.md.
+    // wave-private fused kernel (chain3_kernel.h): 2 (default) = where it is the faster fused kernel by measurement (round 3: only
+    // f64 ipc4d x 16 groups, where it is the only specialised instantiation; f64 ipc4d x 8 groups: 1.376 ms against 1.340 ms for
+    // the wave-specialised kernel with batched f64 chains, same box), 1 = wherever it is instantiated, 0 = only where nothing else
+    // fits.  Same-box A/B, profiles/r03_summary.md.
     int use_chain3 = 2;
     int last_form = 0;       // diagnostic: how the last rip_calibrate ran (0 stage kernels, 1 general fused, 2 wave-specialised, 3 wave-private)
     std::string err;

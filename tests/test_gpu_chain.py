@@ -391,7 +391,7 @@ def test_full_frame_4096x4096_vs_oracle_and_between_forms(name, rp, kdt, p, orac
         if oracle_rows == n:
             ref = oracle.calibrate_arrays(ramp, cal)
             got = cb.calibrate(6, ramp, channel_lines=_oracle_lines(ref, len(rp), n // 128))
-            assert ctx.last_chain_form() == (3 if kdt is np.float64 else 2)
+            assert ctx.last_chain_form() == 2   # (f64 ipc4d too: with its f64 chains batched the wave-specialised kernel is the faster one)
             assert_same_bits(got["groupdq"], ref["groupdq"], "groupdq")
             assert_same_bits(got["pixeldq"], ref["pixeldq"], "pixeldq")
             for k in ("slope", "err_read", "err_poisson"):

@@ -11,7 +11,8 @@ if os.environ.get("ALTLIB"):
     _native.LIB_PATH = os.path.join(os.path.dirname(_native.__file__), os.environ["ALTLIB"])
 from romanimpreprocess_amd import pipeline, synth
 
-rp = synth.READ_PATTERN_8
+NG = int(os.environ.get("NGROUPS", "8"))   # NGROUPS=16: BASELINE config 3
+rp = synth.READ_PATTERN_8 if NG == 8 else synth.READ_PATTERN_16
 N = 4096
 KDT = np.float64 if os.environ.get("IPC64") == "1" else np.float32  # IPC64=1: f64 ipc4d coefficients
 cal, ramp = synth.make_tiled_inputs(N, N, read_pattern=rp, p_order=8, seed=1, strip_rows=64, ipc_dtype=KDT)
@@ -27,7 +28,7 @@ g[0] |= 1
 t = [torch.from_numpy(ramp["data"].view(np.int16)).to(dev), torch.from_numpy(ramp["amp33"].view(np.int16)).to(dev),
      torch.from_numpy(g).to(dev), torch.from_numpy(ramp["pixeldq"].view(np.int32)).to(dev)]
 o = [torch.empty((N, N), dtype=torch.float32, device=dev) for _ in range(3)] + [
-    torch.empty((N, N), dtype=torch.int32, device=dev), torch.empty((8, N, N), dtype=torch.uint8, device=dev)]
+    torch.empty((N, N), dtype=torch.int32, device=dev), torch.empty((NG, N, N), dtype=torch.uint8, device=dev)]
 torch.cuda.synchronize()
 
 
@@ -36,7 +37,7 @@ KW = {"inputs_complete": True} if "inputs_complete" in inspect.signature(cb.cali
 
 
 def call():
-    cb.calibrate_device(0, pid, 8, t[0].data_ptr(), True, t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
+    cb.calibrate_device(0, pid, NG, t[0].data_ptr(), True, t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
                         o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(), **KW)
 
 

@@ -34,10 +34,12 @@ __global__ __launch_bounds__(256) void mix_kernel(Args a, int rows_per) {
         for (int w = 0; w < W; ++w) acc[w] = 0.f, q[w] = 0;
         if constexpr (W == 1) {
             unsigned s[G], qq[G]; float dk[G], bs[G], pl[NPL];
+            // L = 3: the CALDIR words TILED (row, strip of 256 columns, word, column): one contiguous 45 KB piece per row step of a strip
+            const size_t tb = (((size_t)r * (N / 256) + col / 256) * 45) * 256 + (col & 255);
 #pragma unroll
-            for (int g = 0; g < G; ++g) { s[g] = a.cube[g * npix + p]; qq[g] = a.gdq[g * npix + p]; dk[g] = a.dark[L ? ((size_t)r * G + g) * N + col : g * npix + p]; bs[g] = a.bias[L ? ((size_t)r * G + g) * N + col : g * npix + p]; }
+            for (int g = 0; g < G; ++g) { s[g] = a.cube[g * npix + p]; qq[g] = a.gdq[g * npix + p]; dk[g] = (L == 3) ? a.planes[tb + g * 256] : a.dark[L ? ((size_t)r * G + g) * N + col : g * npix + p]; bs[g] = (L == 3) ? a.planes[tb + (8 + g) * 256] : a.bias[L ? ((size_t)r * G + g) * N + col : g * npix + p]; }
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) pl[i] = a.planes[L ? ((size_t)r * NPL + i) * N + col : i * npix + p];
+            for (int i = 0; i < NPL; ++i) pl[i] = (L == 3) ? a.planes[tb + (16 + i) * 256] : a.planes[L ? ((size_t)r * NPL + i) * N + col : i * npix + p];
 #pragma unroll
             for (int g = 0; g < G; ++g) { acc[0] += (float)s[g] - dk[g] + bs[g]; q[0] |= qq[g] << (g & 3); }
 #pragma unroll
@@ -115,20 +117,21 @@ int main() {
     auto mk = [&](size_t bytes) { CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 1, bytes)); return p; };
     a.cube = (const uint16_t *)mk(G * npix * 2); a.gdq = (const uint8_t *)mk(G * npix); a.dark = (const float *)mk(G * npix * 4);
     a.bias = (const float *)mk(G * npix * 4);
-    a.planes = (const float *)mk((size_t)44 * npix * 4);   // 29 scalar planes, or the 11 float4 planes of quad_kernel (44 words per pixel)
+    a.planes = (const float *)mk((size_t)45 * npix * 4);   // 29 scalar planes, or the 11 float4 planes of quad_kernel (44 words per pixel)
     a.o0 = (float *)mk(npix * 4); a.o1 = (float *)mk(npix * 4); a.o2 = (float *)mk(npix * 4); a.o3 = (float *)mk(npix * 4);
     a.gout = (uint8_t *)mk(G * npix);
     const double bytes = (double)npix * (G * (2 + 1 + 4 + 4) + NPL * 4 + 16 + G);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rows_per : {8, 128}) {
-        for (int WL : {10, 11, 40, 41}) {
+        for (int WL : {10, 11, 13, 40, 41}) {
             const int W = WL / 10, L = WL % 10;
             if (W == 4 && rows_per == 128) continue;   // 128 blocks: not enough parallelism, measured once (2.3 ms)
             const int strips = N / (256 * W), ranges = (N + rows_per - 1) / rows_per;
             auto launch = [&]() {
                 if (WL == 10) hipLaunchKernelGGL((mix_kernel<1, 0>), dim3(strips * ranges), dim3(256), 0, 0, a, rows_per);
                 if (WL == 11) hipLaunchKernelGGL((mix_kernel<1, 1>), dim3(strips * ranges), dim3(256), 0, 0, a, rows_per);
+                if (WL == 13) hipLaunchKernelGGL((mix_kernel<1, 3>), dim3(strips * ranges), dim3(256), 0, 0, a, rows_per);
                 if (WL == 40) hipLaunchKernelGGL((mix_kernel<4, 0>), dim3(strips * ranges), dim3(256), 0, 0, a, rows_per);
                 if (WL == 41) hipLaunchKernelGGL((mix_kernel<4, 1>), dim3(strips * ranges), dim3(256), 0, 0, a, rows_per);
             };
