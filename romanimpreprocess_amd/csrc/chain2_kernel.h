@@ -177,6 +177,38 @@ __device__ __forceinline__ void c2_ipc9_batch(const VT (&v)[NBB][9], const doubl
     }
 }
 
+// (float)(a[g] / (double)bf) for NG numerators and ONE divisor (the second iterate over the pixel's gain, f64 ipc4d), lanes with
+// `use` only.  The compiler expands an f64 division into v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal (four
+// fma), q0 = a * y, r = fma(-b, q0, a), v_div_fmas (= fma(r, y, q0) when nothing was scaled), v_div_fixup (= its first operand for
+// finite non-zero operands).  Everything up to y depends on the divisor alone, so it is computed once and each quotient costs a
+// multiply and two fma: the same operations on the same operands as the expansion, hence the same bits, as long as v_div_scale
+// scales nothing and v_div_fixup has nothing to fix -- which holds for 2^-60 < |b| < 2^60 and every quotient (rounded to f32)
+// finite, non-zero and within 2^-59 .. 2^59 (then 2^-119 < |a| < 2^119: far from every scaling rule of the instruction).  One
+// wave vote checks that; otherwise every lane takes the division operator.
+template <int NG>
+__device__ __forceinline__ void c2_div64_shared(const double (&a)[NG], float bf, bool use, float (&qf)[NG]) {
+    const double b = (double)bf;
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    float asum = 0.0f, amin = 3.0e38f;   // NaN / Inf show in the sum, zeros and tiny values in the minimum
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const double q0 = a[g] * y;
+        const double r = __builtin_fma(-b, q0, a[g]);
+        qf[g] = (float)__builtin_fma(r, y, q0);
+        asum = asum + fabsf(qf[g]);
+        amin = fminf(amin, fabsf(qf[g]));
+    }
+    const bool ok = rcp_safe(bf) && asum < 5.7e17f && amin > 1.8e-18f;
+    if (!__all(ok || !use)) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) qf[g] = (float)(a[g] / b);
+    }
+}
+
 template <int NP, int G, int START, typename KT = float>
 __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
                                                                const RipVariant *__restrict__ vars,
@@ -905,12 +937,12 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                             o2v[gb + b] = (v[b][0] + (double)xc) - f[b];
                         }
                     }
-                    const double gd = (double)e_gain;
+                    float qf[G];
+                    c2_div64_shared<G>(o2v, e_gain, act, qf);
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const float xc = (g & 1) ? xnext[g / 2].y : xnext[g / 2].x;
-                        const float q_ = (float)(o2v[g] / gd);
-                        d[g] = act ? q_ : xc;
+                        d[g] = act ? qf[g] : xc;
                     }
 #pragma unroll
                     for (int p0 = 0; p0 < GP; ++p0) dpair[p0] = f2{d[2 * p0], d[2 * p0 + 1]};

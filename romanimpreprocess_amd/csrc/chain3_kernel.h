@@ -696,8 +696,10 @@ __global__ __launch_bounds__(C3_THREADS, WPS) void chain3_kernel(ChainArgs a, co
 #pragma unroll
                     for (int b = 0; b < NB; ++b) o2[b] = (a0[b] + (T)bx[b]) - f[b];
                     if constexpr (K64) {
+                        float qf[NB];   // (c2_div64_shared: the divisor's half of the division expansion once per batch)
+                        c2_div64_shared<NB>(o2, e_gain, act, qf);
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) d[g0 + b] = act ? (float)(o2[b] / (double)e_gain) : bx[b];
+                        for (int b = 0; b < NB; ++b) d[g0 + b] = act ? qf[b] : bx[b];
                     } else if (ALLC && fastdiv && allact) {  // interior wave
 #pragma unroll
                         for (int b = 0; b < NB; b += 2) {
