@@ -3,9 +3,13 @@
 // the reference output, per group).  One frame of rows x width samples:
 //     L = 2*rows*width ;  z_k = (n_k + i n_{L+k}) * a_k ,  a_k = |k|^-1/2 for the signed frequency index k (a_0 = 0)
 //     block = Re(FFT(z))[0 : L/2] / sqrt(2) ;  block -= mean(block) ;  reshaped (rows, width), cast to f32
-// in f64 as the reference (complex128 FFT of 2^20 points for the 4096 x 128 frame; hipFFT Z2Z, batched).  The 2L standard
-// normal deviates per frame come from the caller or, normals == NULL, from the device (Philox + Box-Muller).  The FFT is not
-// the reference's pocketfft: results agree to rounding (~1e-12 relative), not bit for bit.
+// in f64 as the reference (complex128 FFT of 2^20 points for the 4096 x 128 frame).  Only the REAL part of the transform is kept,
+// and Re(sum_j z_j e^{-i t_j}) pairs the terms j and L-j (cos t_{L-j} = cos t_j, sin t_{L-j} = -sin t_j):
+//     Re Z_k = s_0 + s_{L/2} (-1)^k + sum_{0<j<L/2} Re(s_j e^{+i t_j}),   s_j = (Re z_j + Re z_{L-j}) - i (Im z_j - Im z_{L-j})
+// which is a complex-to-real transform of length L on the L/2+1 folded coefficients (hipFFT Z2D, batched: half the arithmetic and
+// half the traffic of the complex transform of round 2; the same products a_k n_k as the reference forms, added in another order).
+// The 2L standard normal deviates per frame come from the caller or, normals == NULL, from the device (Philox + Box-Muller).  The
+// FFT is not the reference's pocketfft: results agree to rounding (~1e-12 relative), not bit for bit.
 #include <hipfft/hipfft.h>
 
 #include <algorithm>
@@ -28,12 +32,20 @@ __device__ __forceinline__ void philox10(uint32_t (&c)[4], uint32_t k0, uint32_t
     }
 }
 
-// z[f*L + k] from the deviates of frame f (or from the device generator)
-__global__ __launch_bounds__(256) void pink_fill_kernel(const double *__restrict__ normals, hipfftDoubleComplex *__restrict__ z, size_t L,
-                                                        int nframes, uint64_t seed, uint32_t stream_id) {
+// a_k for k = 0 .. L-1, once per frame length (the f64 power is the most expensive operation of the fill, and the same for every
+// frame): signed frequency index as the reference builds it -- linspace(0, 1 - 1/L, L), upper half minus one, times L
+__global__ __launch_bounds__(256) void pink_amp_kernel(double *__restrict__ amp, size_t L) {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int f = blockIdx.y;
     if (k >= L) return;
+    const double step = (1.0 - 1.0 / (double)L) / (double)(L - 1);
+    double freq = (double)k * step;
+    if (k >= L / 2) freq -= 1.0;
+    amp[k] = (k == 0) ? 0.0 : pow(1.0e-99 + fabs(freq * (double)L), -0.5);
+}
+
+// the deviate pair (n_k, n_{L+k}) of frame f times the amplitude a_k: from the caller's array or from the device generator
+__device__ __forceinline__ void pink_term(const double *__restrict__ normals, const double *__restrict__ amps, size_t L, int f, size_t k,
+                                          uint64_t seed, uint32_t stream_id, double &re, double &im) {
     double a, b;
     if (normals) {
         a = normals[(size_t)f * 2 * L + k];
@@ -47,26 +59,43 @@ __global__ __launch_bounds__(256) void pink_fill_kernel(const double *__restrict
         a = r * cospi(2.0 * u2);
         b = r * sinpi(2.0 * u2);
     }
-    // signed frequency index as the reference builds it: linspace(0, 1 - 1/L, L), upper half minus one, times L
-    const double step = (1.0 - 1.0 / (double)L) / (double)(L - 1);
-    double freq = (double)k * step;
-    if (k >= L / 2) freq -= 1.0;
-    double amp = pow(1.0e-99 + fabs(freq * (double)L), -0.5);
-    if (k == 0) amp = 0.0;
-    hipfftDoubleComplex v;
-    v.x = a * amp;
-    v.y = b * amp;
-    z[(size_t)f * L + k] = v;
+    const double amp = amps[k];
+    re = a * amp;
+    im = b * amp;
 }
 
-// sum of Re(Z)[0 : L/2] / sqrt(2) per frame (f64): 256 block partials per frame, added in a FIXED order by pink_out_kernel
+// folded coefficients S[f*(L/2+1) + j], j = 0 .. L/2, of the complex-to-real transform (see the head of the file): S_0 = Re z_0,
+// S_{L/2} = Re z_{L/2}, S_j = ((Re z_j + Re z_{L-j}) - i (Im z_j - Im z_{L-j})) / 2 (the transform counts those terms twice)
+__global__ __launch_bounds__(256) void pink_fill_kernel(const double *__restrict__ normals, const double *__restrict__ amps,
+                                                        hipfftDoubleComplex *__restrict__ S, size_t L, int nframes, uint64_t seed,
+                                                        uint32_t stream_id) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    const size_t half = L / 2;
+    if (j > half) return;
+    double re, im;
+    pink_term(normals, amps, L, f, j, seed, stream_id, re, im);
+    hipfftDoubleComplex v;
+    if (j == 0 || j == half) {
+        v.x = re;
+        v.y = 0.0;
+    } else {
+        double re2, im2;
+        pink_term(normals, amps, L, f, L - j, seed, stream_id, re2, im2);
+        v.x = (re + re2) * 0.5;
+        v.y = -(im - im2) * 0.5;
+    }
+    S[(size_t)f * (half + 1) + j] = v;
+}
+
+// sum of x[0 : L/2] / sqrt(2) per frame (f64): 256 block partials per frame, added in a FIXED order by pink_out_kernel
 // (an atomicAdd across blocks would make the subtracted mean, hence the frame, differ in the last bit from run to run)
-__global__ __launch_bounds__(256) void pink_sum_kernel(const hipfftDoubleComplex *__restrict__ z, size_t L, double *__restrict__ sums) {
+__global__ __launch_bounds__(256) void pink_sum_kernel(const double *__restrict__ x, size_t L, double *__restrict__ sums) {
     __shared__ double sh[256];
     const int f = blockIdx.y;
     const size_t half = L / 2;
     double acc = 0.0;
-    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < half; k += (size_t)gridDim.x * 256) acc += z[(size_t)f * L + k].x / sqrt(2.0);
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < half; k += (size_t)gridDim.x * 256) acc += x[(size_t)f * L + k] / sqrt(2.0);
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -76,7 +105,7 @@ __global__ __launch_bounds__(256) void pink_sum_kernel(const hipfftDoubleComplex
     if (threadIdx.x == 0) sums[(size_t)f * gridDim.x + blockIdx.x] = sh[0];
 }
 
-__global__ __launch_bounds__(256) void pink_out_kernel(const hipfftDoubleComplex *__restrict__ z, size_t L, const double *__restrict__ sums,
+__global__ __launch_bounds__(256) void pink_out_kernel(const double *__restrict__ x, size_t L, const double *__restrict__ sums,
                                                        float *__restrict__ out) {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
@@ -85,7 +114,7 @@ __global__ __launch_bounds__(256) void pink_out_kernel(const hipfftDoubleComplex
     double tot = 0.0;
     for (int b = 0; b < 256; ++b) tot += sums[(size_t)f * 256 + b];  // same order in every thread and every run
     const double mean = tot / (double)half;
-    out[(size_t)f * half + k] = (float)(z[(size_t)f * L + k].x / sqrt(2.0) - mean);
+    out[(size_t)f * half + k] = (float)(x[(size_t)f * L + k] / sqrt(2.0) - mean);
 }
 
 // out: host memory (frames copied back chunk by chunk, call synchronous) or, out_dev, device memory (asynchronous: the transform
@@ -116,11 +145,14 @@ int noise_1f_impl(rip_ctx *ctx, int rows, int width, int nframes, const double *
     if (ctx->pink_L != L || ctx->pink_chunk != chunk) {   // another frame length or batch: new plan and buffers
         PK_HIP(hipStreamSynchronize(ctx->stream));
         rip_pink_release(ctx);
-        PK_HIP(hipMalloc(&ctx->pink_z, (size_t)chunk * L * sizeof(hipfftDoubleComplex)));
-        PK_HIP(hipMalloc(&ctx->pink_s, (size_t)chunk * 256 * sizeof(double)));
+        // one buffer: the folded coefficients (chunk x (L/2+1) complex), then the real series (chunk x L), then the block sums
+        PK_HIP(hipMalloc(&ctx->pink_z, (size_t)chunk * (half + 1) * sizeof(hipfftDoubleComplex) + (size_t)chunk * L * sizeof(double)));
+        PK_HIP(hipMalloc(&ctx->pink_s, ((size_t)chunk * 256 + L) * sizeof(double)));   // the block sums, then the amplitudes a_k
+        hipLaunchKernelGGL(pink_amp_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, (double *)ctx->pink_s + (size_t)chunk * 256, L);
+        PK_HIP(hipStreamSynchronize(ctx->stream));   // (once per frame length: later calls may come on the context's other stream)
         int n1 = (int)L;
         hipfftHandle made = 0;
-        if (hipfftPlanMany(&made, 1, &n1, nullptr, 1, n1, nullptr, 1, n1, HIPFFT_Z2Z, chunk) != HIPFFT_SUCCESS) {
+        if (hipfftPlanMany(&made, 1, &n1, nullptr, 1, (int)(half + 1), nullptr, 1, n1, HIPFFT_Z2D, chunk) != HIPFFT_SUCCESS) {
             rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftPlanMany(%zu points x %d) failed", L, chunk);
             rip_pink_release(ctx);
             done();
@@ -131,7 +163,9 @@ int noise_1f_impl(rip_ctx *ctx, int rows, int width, int nframes, const double *
         ctx->pink_chunk = chunk;
     }
     hipfftDoubleComplex *z = (hipfftDoubleComplex *)ctx->pink_z;
+    double *x = reinterpret_cast<double *>(z + (size_t)chunk * (half + 1));
     double *d_s = (double *)ctx->pink_s;
+    const double *d_amp = d_s + (size_t)chunk * 256;
     hipfftHandle plan = (hipfftHandle)ctx->pink_plan;
     if (!out_dev) PK_HIP(hipMalloc((void **)&d_o, (size_t)chunk * half * sizeof(float)));
     if (normals) PK_HIP(hipMalloc((void **)&d_n, (size_t)chunk * 2 * L * sizeof(double)));
@@ -144,17 +178,19 @@ int noise_1f_impl(rip_ctx *ctx, int rows, int width, int nframes, const double *
         const int nf = std::min(chunk, nframes - f0);
         if (normals)
             PK_HIP(hipMemcpyAsync(d_n, normals + (size_t)f0 * 2 * L, (size_t)nf * 2 * L * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(pink_fill_kernel, dim3((unsigned)((L + 255) / 256), nf), dim3(256), 0, ctx->stream, (const double *)d_n, z, L,
+        hipLaunchKernelGGL(pink_fill_kernel, dim3((unsigned)((half + 1 + 255) / 256), nf), dim3(256), 0, ctx->stream, (const double *)d_n, d_amp, z, L,
                            nf, seed, stream_id + (uint32_t)f0);
-        if (nf < chunk) PK_HIP(hipMemsetAsync(z + (size_t)nf * L, 0, (size_t)(chunk - nf) * L * sizeof(hipfftDoubleComplex), ctx->stream));
-        if (hipfftExecZ2Z(plan, z, z, HIPFFT_FORWARD) != HIPFFT_SUCCESS) {
-            rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftExecZ2Z failed");
+        if (nf < chunk)
+            PK_HIP(hipMemsetAsync(z + (size_t)nf * (half + 1), 0, (size_t)(chunk - nf) * (half + 1) * sizeof(hipfftDoubleComplex), ctx->stream));
+        if (hipfftExecZ2D(plan, z, x) != HIPFFT_SUCCESS) {
+            rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftExecZ2D failed");
             done();
             return rc;
         }
-        hipLaunchKernelGGL(pink_sum_kernel, dim3(256, nf), dim3(256), 0, ctx->stream, z, L, d_s);
+        hipLaunchKernelGGL(pink_sum_kernel, dim3(256, nf), dim3(256), 0, ctx->stream, (const double *)x, L, d_s);
         float *dst = out_dev ? out + (size_t)f0 * half : d_o;
-        hipLaunchKernelGGL(pink_out_kernel, dim3((unsigned)((half + 255) / 256), nf), dim3(256), 0, ctx->stream, z, L, (const double *)d_s, dst);
+        hipLaunchKernelGGL(pink_out_kernel, dim3((unsigned)((half + 255) / 256), nf), dim3(256), 0, ctx->stream, (const double *)x, L,
+                           (const double *)d_s, dst);
         PK_HIP(hipGetLastError());
         if (!out_dev) PK_HIP(hipMemcpyAsync(out + (size_t)f0 * half, d_o, (size_t)nf * half * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         if (!out_dev) PK_HIP(hipStreamSynchronize(ctx->stream));   // device output: the next chunk follows in stream order
