@@ -356,7 +356,9 @@ def main():
                     help="dtype of the ipc4d coefficients (the reference's production writer stores f64)")
     ap.add_argument("--p-order", type=int, default=8, choices=(3, 8, 10), help="Legendre order of the linearity file")
     ap.add_argument("--tiled", action="store_true", help="the round-1 input: a 128-row strip repeated down the frame (numpy)")
-    ap.add_argument("--chain3", type=int, default=None, choices=(0, 1), help="A/B switch: 1 = wave-private fused kernel wherever instantiated")
+    ap.add_argument("--chain3", type=int, default=None, choices=(0, 1),
+                    help="(rounds 1-2: A/B switch of the wave-private fused kernel; it is instantiated for f64 ipc4d x 16 groups only "
+                         "since round 3 and taken there whatever this says)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip pre-pass exclusive timing, variants and the 18-slot batch")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),

@@ -14,27 +14,19 @@ bool rip_chain_supported(const rip_ctx *ctx, int nplanes, int G, int k_dtype, in
     return true;
 }
 
-#define C3_DECL(np)                                                                        \
-    int rip_launch_chain3_np##np(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a);   \
-    int rip_launch_chain3_k64_np##np(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a);
-C3_DECL(4)
-C3_DECL(9)
-C3_DECL(11)
-#undef C3_DECL
+int rip_launch_chain3_k64_np4(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a);
+int rip_launch_chain3_k64_np9(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a);
+int rip_launch_chain3_k64_np11(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a);
 
 int rip_launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int nplanes, int k_dtype) {
-    // wave-private kernel (chain3_kernel.h) first; 1 = no instantiation for this plan
-    const bool only3 = a.ngrp == 16 && k_dtype == RIP_F64 && a.merged_dq >= 0;  // no other specialised instantiation
+    // f64 ipc4d x 16 groups: the wave-private kernel (chain3_kernel.h), the only specialised instantiation for it (the rings of
+    // such a ramp do not fit the wave-specialised kernel's workgroup); 1 = no instantiation for this plan.
     // (merged_dq < 0: the flag words of this CALDIR set cannot be merged, RipCal -- the specialised kernels are not taken)
-    // (use_chain3 == 2, the default: where it is the faster fused kernel -- since the f64 chains of the wave-specialised kernel are
-    // batched, round 3, that is only where it is the only one)
-    const bool want3 = ctx->use_chain3 == 1 && a.merged_dq >= 0;
-    if ((want3 || only3) && (nplanes == 4 || nplanes == 9 || nplanes == 11)) {
-        const bool k64 = k_dtype == RIP_F64;
+    if (a.ngrp == 16 && k_dtype == RIP_F64 && a.merged_dq >= 0) {
         int rc = 1;
-        if (nplanes == 4) rc = k64 ? rip_launch_chain3_k64_np4(ctx, plan, a) : rip_launch_chain3_np4(ctx, plan, a);
-        if (nplanes == 9) rc = k64 ? rip_launch_chain3_k64_np9(ctx, plan, a) : rip_launch_chain3_np9(ctx, plan, a);
-        if (nplanes == 11) rc = k64 ? rip_launch_chain3_k64_np11(ctx, plan, a) : rip_launch_chain3_np11(ctx, plan, a);
+        if (nplanes == 4) rc = rip_launch_chain3_k64_np4(ctx, plan, a);
+        if (nplanes == 9) rc = rip_launch_chain3_k64_np9(ctx, plan, a);
+        if (nplanes == 11) rc = rip_launch_chain3_k64_np11(ctx, plan, a);
         if (rc != 1) {
             ctx->last_form = 3;
             return rc;

@@ -37,7 +37,13 @@
 #else
 #define C2_SYNC() __syncthreads()
 #endif
+#ifdef C2_ALIGNED_TIMING   // TIMING experiment only (wrong strip edges): 16 aligned 256-column windows, no halo
+#define C2_OUTW C2_COLS
+#define C2_HALO 0
+#else
 #define C2_OUTW (C2_COLS - 4)
+#define C2_HALO 2
+#endif
 // Where the half-step barrier falls in the fit role: 0 after the first half of the fit, 1 after its second half (and the saturated
 // refits), 2 after the flag propagation and the group-flag stores, 3 after the finish and the plane stores.  Same-box A/B on the
 // bench frame (profiles/r03_summary.md): f32 ipc4d x 8 groups 0.884 / 0.887 / 0.895 ms for 0 / 1 / 2; 16 groups 2.048 / 2.003 /
@@ -272,11 +278,11 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
     const int R0 = (bid / nstrips) * rows_per;
     const int R1 = min(ny, R0 + rows_per);
     if (bid >= nstrips * nranges || R0 >= ny) return;
-    const int c = strip * C2_OUTW - 2 + col;
+    const int c = strip * C2_OUTW - C2_HALO + col;
     const bool col_ok = (c >= 0 && c < nx);
     const bool col_act = (c >= ax0 && c < ax1);
     const int cc = col_ok ? c : 0;
-    const int ch0 = max(strip * C2_OUTW - 2, 0) / RIP_CW;
+    const int ch0 = max(strip * C2_OUTW - C2_HALO, 0) / RIP_CW;
     const int chr = cc / RIP_CW - ch0;
     for (int i = tid; i < 3 * G * 2; i += C2_THREADS) {
         const int ch = i / (G * 2), g = (i / 2) % G, w = i & 1;

@@ -126,10 +126,10 @@ struct rip_ctx {
     int parity = 0;
     bool use_overlap = true;
     bool use_chain2 = true;  // wave-specialised fused kernel where it applies
-    // wave-private fused kernel (chain3_kernel.h): 2 (default) = where it is the faster fused kernel by measurement (round 3: only
-    // f64 ipc4d x 16 groups, where it is the only specialised instantiation; f64 ipc4d x 8 groups: 1.376 ms against 1.340 ms for
-    // the wave-specialised kernel with batched f64 chains, same box), 1 = wherever it is instantiated, 0 = only where nothing else
-    // fits.  Same-box A/B, profiles/r03_summary.md.
+    // (option "chain3" of rounds 1-2: the wave-private fused kernel, chain3_kernel.h, is instantiated for f64 ipc4d x 16 groups only
+    // since round 3 -- with its f64 chains batched the wave-specialised kernel is the faster one everywhere else: 1.340 against
+    // 1.376 ms for f64 ipc4d x 8 groups, 0.85 against 0.95 ms for f32, same box, profiles/r03_summary.md -- and is taken there
+    // whatever the option says; the option is still accepted)
     int use_chain3 = 2;
     int last_form = 0;       // diagnostic: how the last rip_calibrate ran (0 stage kernels, 1 general fused, 2 wave-specialised, 3 wave-private)
     std::string err;

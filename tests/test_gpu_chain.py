@@ -204,22 +204,21 @@ def test_calibrateimage_files_end_to_end(tmp_path):
         gen_cal_image.calibrateimage(dict(config, romancal_ramp_fit=True), verbose=False)
 
 
-# ---- the specialised fused kernels (wave-private chain3_kernel.h, wave-specialised chain2_kernel.h): every instantiation the
-# dispatcher can pick, and the seams between their column strips / row ranges
+# ---- the specialised fused kernels (wave-specialised chain2_kernel.h; wave-private chain3_kernel.h for f64 ipc4d x 16 groups):
+# every instantiation the dispatcher can pick, and the seams between their column strips / row ranges
 
 
 def _set_form(ctx, form):
-    """3: wave-private fused kernel, 2: wave-specialised, 1: general fused, 0: stage kernels"""
+    """2: the specialised fused kernel of the configuration (it reports 3 where that is the wave-private one: f64 ipc4d x 16
+    groups), 1: general fused, 0: stage kernels"""
     ctx.set_option("fused", 1 if form else 0)
-    ctx.set_option("chain3", 1 if form == 3 else 0)   # (the library's default, 2, picks by ipc4d dtype)
     ctx.set_option("chain2", 1 if form >= 2 else 0)
 
 
 def _default_form(ctx):
-    """the library's defaults: fused; wave-specialised kernel for f32 ipc4d, wave-private kernel for f64 ipc4d"""
+    """the library's defaults: fused, the specialised kernels where they apply"""
     ctx.set_option("fused", 1)
     ctx.set_option("chain2", 1)
-    ctx.set_option("chain3", 2)
 
 
 SPECIALISED = [
@@ -236,20 +235,18 @@ SPECIALISED = [
     ("g8_np11_start0_k64", (40, 256), synth.READ_PATTERN_8, 10, False, np.float64),
     ("g6_np4_start1_k64", (48, 128), synth.READ_PATTERN_6, 3, True, np.float64),
     ("g6_np9_start0_k64", (40, 256), synth.READ_PATTERN_6, 8, False, np.float64),
-    # f64 ipc4d x 16 groups: wave-private kernel only
+    # f64 ipc4d x 16 groups: the wave-private kernel
     ("g16_np9_start1_k64", (40, 256), synth.READ_PATTERN_16, 8, True, np.float64),
     ("g16_np11_start0_k64", (32, 256), synth.READ_PATTERN_16, 10, False, np.float64),
 ]
 
 
-@pytest.mark.parametrize("form", [3, 2])
 @pytest.mark.parametrize("name,shape,rp,p,exclude_first,kdt", SPECIALISED)
-def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first, kdt, form):
+def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first, kdt):
     ny, nx = shape
-    if form == 2 and len(rp) == 16 and kdt is np.float64:
-        pytest.skip("not instantiated for the wave-specialised kernel")
+    form = 3 if (len(rp) == 16 and kdt is np.float64) else 2
     ctx = gpu_context()
-    _set_form(ctx, form)
+    _set_form(ctx, 2)
     cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=p, seed=91, bias_amplitude=2.0, bad_lin_frac=0.01,
                             ipc_dtype=kdt)
     # degenerate gains: the waves holding them leave the shared-reciprocal division for the division operator
@@ -276,9 +273,8 @@ def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first, kdt, fo
 
 @pytest.mark.parametrize("kdt", [np.float32, np.float64])
 def test_fused_forms_agree_across_seams(kdt):
-    """A frame wider than several column strips and taller than several row ranges: the wave-private kernel, the
-    wave-specialised kernel, the general fused kernel and the stage kernels must give identical bits (halo columns, range
-    boundaries, frame edges)."""
+    """A frame wider than several column strips and taller than several row ranges: the wave-specialised kernel, the general
+    fused kernel and the stage kernels must give identical bits (halo columns, range boundaries, frame edges)."""
     rp = synth.READ_PATTERN_8
     ny, nx = 1160, 896
     cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=31, bias_amplitude=2.0, bad_lin_frac=0.005,
@@ -289,15 +285,15 @@ def test_fused_forms_agree_across_seams(kdt):
     cb.load_caldir(5, cal)
     outs = []
     try:
-        for form in (3, 2, 1, 0):
+        for form in (2, 1, 0):
             _set_form(ctx, form)
             outs.append(cb.calibrate(5, ramp, want_cube=True))
             assert ctx.last_chain_form() == form
     finally:
         _default_form(ctx)
-    for other, label in ((outs[1], "wave-specialised"), (outs[2], "general fused"), (outs[3], "stage kernels")):
+    for other, label in ((outs[1], "general fused"), (outs[2], "stage kernels")):
         for k in ("cube", "slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
-            assert_same_bits(outs[0][k], other[k], f"{k}: wave-private vs {label}")
+            assert_same_bits(outs[0][k], other[k], f"{k}: wave-specialised vs {label}")
     assert np.count_nonzero(outs[0]["pixeldq"] & 4) > 1000 and np.count_nonzero(outs[0]["pixeldq"] & 2) > 100
     cb.ctx.drop_caldir(5)
 
@@ -354,7 +350,7 @@ FULL_FRAME = [
     ("g8_k64", synth.READ_PATTERN_8, np.float64, 8, 4096),     # ... with the f64 ipc4d of production CALDIR sets
     # BASELINE config 3 (READS = [0..35], 16 groups): the numpy oracle needs more than 7 minutes for a 16-group full frame
     # (13 truncated refits, O(G^2) variance passes), so it checks a 264-row frame of the full width and the full frame is
-    # checked between the four device forms
+    # checked between the three device forms
     ("g16_f32", synth.READ_PATTERN_16, np.float32, 8, 264),
 ]
 
@@ -363,8 +359,7 @@ FULL_FRAME = [
 def test_full_frame_4096x4096_vs_oracle_and_between_forms(name, rp, kdt, p, oracle_rows):
     """BASELINE configs 2 and 3 at their full size on a NON-PERIODIC frame (sky + 25 Gaussian sources, seeded, generated
     on the device by synth_gpu): the numpy oracle on the whole frame (about a minute of CPU) against the default fused kernel,
-    bit for bit with LAPACK's channel lines handed in; then every device form (wave-private, wave-specialised, general fused,
-    stage kernels) against each other with the lines fitted on the device."""
+    bit for bit with LAPACK's channel lines handed in; then every device form (wave-specialised, general fused, stage kernels) against each other with the lines fitted on the device."""
     from romanimpreprocess_amd import synth_gpu
 
     n = 4096
@@ -404,11 +399,11 @@ def test_full_frame_4096x4096_vs_oracle_and_between_forms(name, rp, kdt, p, orac
         # the sources are there
         assert np.count_nonzero(ramp["rate"][4:-4, 4:-4] > 100.0) > 200
         outs = []
-        for form in (2, 3, 1, 0):
+        for form in (2, 1, 0):
             _set_form(ctx, form)
             outs.append(cb.calibrate(6, ramp))
             assert ctx.last_chain_form() == form
-        for other, label in ((outs[1], "wave-private"), (outs[2], "general fused"), (outs[3], "stage kernels")):
+        for other, label in ((outs[1], "general fused"), (outs[2], "stage kernels")):
             for k in ("slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
                 assert_same_bits(outs[0][k], other[k], f"{k}: wave-specialised vs {label}")
         # device-fitted lines against LAPACK's: flags identical, slopes within the north-star tolerance

@@ -1,6 +1,6 @@
 """Same-box A/B timing of library variants: python tools/gpu_checks/ab.py [rounds] tag1 tag2 ...  ('' or 'cur' = working build;
-'cur:chain' = working build with the unspecialised kernel, 'cur:chain3' = with the wave-private kernel instead of the
-wave-specialised default).  Variants are timed alternately in separate processes."""
+'cur:chain' = working build with the unspecialised kernel).  IPC64=1 / NGROUPS=16 in the environment select the variant
+(tools/gpu_checks/phase_timing.py).  Variants are timed alternately in separate processes."""
 import os
 import statistics
 import subprocess
@@ -16,7 +16,6 @@ for _ in range(rounds):
         env = dict(os.environ)
         name, _, mode = t.partition(":")
         env["CHAIN2"] = "0" if mode == "chain" else "1"
-        env["CHAIN3"] = "1" if mode == "chain3" else "0"
         if name not in ("", "cur"):
             env["ALTLIB"] = f"libromanhip_{name}.so"
         out = subprocess.run([sys.executable, os.path.join(here, "phase_timing.py"), "0"], env=env, capture_output=True, text=True)

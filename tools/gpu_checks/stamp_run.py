@@ -45,7 +45,7 @@ def call():
 
 
 CHAIN2 = bool(int(os.environ.get("CHAIN2", "1")))
-CHAIN3 = bool(int(os.environ.get("CHAIN3", "1")))
+CHAIN3 = bool(int(os.environ.get("CHAIN3", "0")))   # (the wave-private kernel: f64 ipc4d x 16 groups only since round 3)
 cb.ctx.set_option("chain2", int(CHAIN2))
 cb.ctx.set_option("chain3", int(CHAIN3))
 if CHAIN3:
