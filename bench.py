@@ -71,7 +71,7 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("chain2_kernel.h", "chain_kernel.h", "device_rampfit.h", "rip_common.h", "Makefile"):
+    for name in ("chain2_kernel.h", "chain_common.h", "device_rampfit.h", "rip_common.h", "Makefile"):
         with open(os.path.join(REPO, "romanimpreprocess_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -544,7 +544,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "alg_bytes_kernel": per_kernel[dom], "kernel_ms": avg_ms[dom],
-                         "kernel_form": {0: "stage kernels", 1: "general fused", 2: "wave-specialised fused (chain2_kernel.h)",
+                         "kernel_form": {0: "stage kernels", 2: "wave-specialised fused (chain2_kernel.h)",
                                          3: "wave-private fused (chain3_kernel.h)"}.get(cb.ctx.last_chain_form())},
             "chain": {"alg_bytes_per_ramp": total, "kernel_ms": avg_ms,
                       "wall_ms_per_ramp": wall_ms, "achieved_GBs": total / (wall_ms * 1e-3) / 1e9,

@@ -385,20 +385,21 @@ int rip_stats_reduce(rip_ctx *ctx, int nseeds, const float *diffs, const float *
 int rip_profile_enable(rip_ctx *ctx, int on);
 int rip_profile_read(rip_ctx *ctx, double out_ms[4], int *ncalls);
 
-/* options: "fused" (default 1) -- run linearity + IPC + ramp fit as the single fused kernel when the
-   configuration allows it (f32 gain; 4, 9 or 11 Legendre planes; LDS budget); 0 forces the
+/* options: "fused" (default 1) -- run the chain as the single fused kernel when the configuration allows it (complete chain on a
+   u16 cube; f32 gain; 4, 9 or 11 Legendre planes; 6, 8 or 16 groups; flag words of the CALDIR set mergeable); 0 forces the
    stage-by-stage kernels.  Both give identical results. */
 int rip_set_option(rip_ctx *ctx, const char *name, int value);
 /* further options (results identical either way; they exist for A/B timing and tests):
-   "chain2"  -- (default 1) use the wave-specialised form of the fused kernel (chain2_kernel.h: f32 ipc4d with 6, 8 or 16
-                groups, f64 ipc4d with 6 or 8) where it applies, 0 = always the general fused kernel (chain_kernel.h);
-   "chain3"  -- the wave-private form (chain3_kernel.h): 2 (default) = where it is the faster fused kernel (f64 ipc4d), 1 =
-                wherever it is instantiated, 0 = only where it is the one fused kernel that fits (f64 ipc4d with 16 groups);
+   "chain2"  -- (default 1) the wave-specialised fused kernel (chain2_kernel.h: f32 ipc4d with 6, 8 or 16 groups, f64 ipc4d with
+                6 or 8); 0 = the stage kernels there (rounds 1-2: a general fused kernel, dropped in round 3);
+   "chain3"  -- accepted, without effect since round 3: the wave-private fused kernel (chain3_kernel.h) is instantiated for f64
+                ipc4d with 16 groups only -- the one configuration the wave-specialised kernel's rings do not fit -- and is
+                taken there;
    "overlap" -- run the reference-pixel pre-pass of a ramp on a second stream so that it overlaps the previous ramp's
                 fused kernel. */
 
-/* how the last rip_calibrate ran: 0 = stage kernels, 1 = general fused kernel, 2 = wave-specialised fused kernel,
-   3 = wave-private fused kernel */
+/* how the last rip_calibrate ran: 0 = stage kernels, 2 = wave-specialised fused kernel, 3 = wave-private fused kernel
+   (1 was the general fused kernel of rounds 1-2) */
 int rip_last_chain_form(rip_ctx *ctx);
 
 /* pseudo-Poisson noise layers ("O" directives, gen_noise_image.py:173-240): per element of I (n doubles, host memory) the

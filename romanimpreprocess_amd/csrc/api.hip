@@ -854,6 +854,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     ctx->last_form = 0;
     const bool fused = ctx->use_fused && do_ref && do_bias && do_lin && do_ipc && do_fit && in->data_dtype == RIP_U16 &&
                        rip_chain_supported(ctx, c.lin_nplanes, G, c.ipc_dtype, c.gain_dtype);
+    bool ran_fused = false;
     if (fused) {
         // ---- one kernel: refpix apply + bias + linearity + IPC + ramp fit + finish (chain.hip)
         ChainArgs ca;
@@ -897,11 +898,20 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         ca.merged_dq = c.merged_plane[((flat_plane ? 1 : 0) | ((stages & RIP_STAGE_DARK) ? 2 : 0))];
         ca.dbg = ctx->chain_dbg;
         ca.dbg_buf = ctx->chain_dbg_buf;
-        if ((rc = rip_launch_chain(ctx, plan, ca, c.lin_nplanes, c.ipc_dtype))) return rc;
-        mark();
-        mark();
-        mark();
-    } else {
+        rc = rip_launch_chain(ctx, plan, ca, c.lin_nplanes, c.ipc_dtype);
+        if (rc == RIP_OK) {
+            ran_fused = true;
+            mark();
+            mark();
+            mark();
+        } else if (rc != 1) {
+            return rc;
+        } else {   // 1: no fused kernel for this plan / CALDIR set (flag words not mergeable, unusual difference mask): stage kernels
+            cur = nullptr;
+            rc = RIP_OK;
+        }
+    }
+    if (!ran_fused) {
     // ---- cube stage: refpix apply + bias + linearity (or a plain conversion to f32)
     const bool need_cube_stage = do_ref || do_bias || do_lin || in->data_dtype != RIP_F32;
     if (need_cube_stage) {

@@ -1,24 +1,29 @@
-// Fused L1->L2 kernel, wave-specialised form (f32 gain; f32 ipc4d with 6, 8 or 16 groups, f64 ipc4d with 6 or 8): the arithmetic, the strip geometry and
-// the packed-pair forms are those of chain_kernel.h; what changes is WHO does what.
+// Fused L1->L2 kernel, wave-specialised form (f32 gain; f32 ipc4d with 6, 8 or 16 groups, f64 ipc4d with 6 or 8): one launch per
+// ramp does reference-pixel apply + bias + Legendre linearity + IPC deconvolution + ramp fit / jump detection / flag propagation
+// + dark rate + error split + flat (gen_cal_image.py:533-629; stage arithmetic and reference lines as in linearity.hip, ipc.hip,
+// rampfit.hip), every array read from HBM once.
 //
-// chain_kernel.h is bound by instruction issue at 2 waves/SIMD (one wave carries the registers of the linearity
-// prefetch AND of the IPC/fit state, and LDS holds only two 256-column workgroups per CU).  Here a workgroup of
-// 512 threads covers the same 256 columns with TWO ROLES of four waves each:
+// Geometry: the frame is cut into strips of 252 output columns (256-column windows: 2 + 2 halo columns for the two 3 x 3 IPC
+// passes); a workgroup owns one strip and one row range and marches down its rows, keeping the rows the 3 x 3 stencils need in
+// LDS rings.  The grid is exactly resident (the row ranges are equal, no tail).  A workgroup of 512 threads covers its 256
+// columns with TWO ROLES of four waves each (one wave doing every phase needs > 200 registers: 2 waves/SIMD, issue bound):
 //     ingest waves (tid < 256)   A: refpix/bias/linearity of row r+3 -> x ring      (raw loads of row r+4 issued between
 //                                C: first IPC iterate of row r+2 -> O1 ring             its arithmetic blocks)
-//     fit waves    (tid >= 256)  O2: second iterate of row r / gain (reads O1 rows r-1..r+1, x row r)
+//     fit waves    (tid >= 256)  O2: second iterate of row r / gain (reads O1 rows r-1..r+1, x of its own column)
 //                                F: ramp fit with jump detection and saturated refits of pixel (r, c)
 //                                T: flag propagation, finish (dark rate, error split, flat), stores of pixel (r, c)
-// so each role needs <= 128 VGPRs and a CU holds 2 workgroups = 16 waves = 4 waves/SIMD.  Per step:
-//     S1: ingest A(r+3)   | fit O2(r), first half of F(r)            -- barrier --
-//     S2: ingest C(r+2)   | fit second half of F(r), T(r), loads of row r+1   -- barrier --
-// Everything after O2 is register-only in a fit thread, so the half-step barrier can fall anywhere in it: it is placed
-// where both roles take about the same time in both halves (profiles/).  The x ring is 4 rows deep (rows r..r+3 are
-// live during a step), the O1 ring 3 rows (C writes row r+2 into the slot of row r-1, which O2(r) finished reading
-// before the barrier).  The linearity dq and the 8 groupdq bytes of a pixel travel from its ingest to its fit through
-// 4-row rings.  Saturated pixels are refitted from registers (trunc_layers), so no per-pixel ramp staging in LDS.
+// so each role needs <= 128 VGPRs and a CU holds 2 workgroups = 16 waves = 4 waves/SIMD (16 groups and f64 ipc4d: the rings
+// allow one workgroup per CU, 2 waves/SIMD at <= 256 VGPRs).  Per step:
+//     S1: ingest A(r+3)   | fit O2(r), F(r) up to the half-step barrier (C2_BAR)       -- barrier --
+//     S2: ingest C(r+2)   | fit: the rest of F(r) and T(r), the ring words of row r+1  -- barrier --
+// Everything after O2 is register-only in a fit thread, so the half-step barrier can fall anywhere in it (C2_BAR, chosen per
+// instantiation by same-box A/B).  Rings (3 rows each): x = gain*phi; the first iterate O1 (C writes row r+2 into the slot of
+// row r-1, which O2(r) finished reading before the barrier; doubles with f64 ipc4d); the per-pixel words that travel from the
+// ingest thread of a column to its fit thread (merged flag word, packed groupdq bytes, gain); and the K ring (2 rows): the nine
+// IPC coefficients of a pixel are loaded ONCE, by its ingest thread, and handed to its fit thread.  Saturated pixels are
+// refitted from registers (trunc_layers), so no per-pixel ramp staging in LDS.
 #pragma once
-#include "chain_kernel.h"
+#include "chain_common.h"
 
 #ifndef C2_COLS
 #define C2_COLS 256
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         return r1 ? (lane_mask & rowbits) : 0u;
     };
     // forward IPC operator in f64 at one column: at_m / at_0 / at_p read rows y-1 / y / y+1 at a column offset; term order
-    // and edge rule of ipc_linearity.py:69-94 (fwd_rows in chain_kernel.h)
+    // and edge rule of ipc_linearity.py:69-94 (fwd_rows in chain_common.h)
     auto ipc9 = [&](auto allc, auto at_m, auto at_0, auto at_p, const double (&kk)[9], unsigned valid) -> double {
         constexpr bool ALL = decltype(allc)::value;
         double acc = (double)at_0(0) * kk[0];

@@ -19,7 +19,7 @@
 //     step after O2.  The channel lines and the dense fit table are staged in LDS once per workgroup, the row
 //     corrections of the next row come with one wide scalar load a step ahead: no serialised scalar-memory round trips
 //     inside the row loop besides the kernel arguments.
-//   * The arithmetic of every phase is that of chain2_kernel.h / chain_kernel.h (validated bit for bit against the oracle);
+//   * The arithmetic of every phase is that of chain2_kernel.h / chain_common.h (validated bit for bit against the oracle);
 //     only the data movement differs.
 //
 // A workgroup is C3_NW waves on adjacent strips (same rows): they touch neighbouring cache lines at about the same time.

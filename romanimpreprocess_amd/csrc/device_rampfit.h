@@ -56,7 +56,7 @@ __device__ __forceinline__ float rip_rcp_mid(float b) {
     const float e = fmaf(-b, r0, 1.0f);
     return fmaf(e, r0, r0);
 }
-__device__ __forceinline__ float div_rcp_(float a, float b, float rb) {  // a / b from the exact reciprocal (chain_kernel.h)
+__device__ __forceinline__ float div_rcp_(float a, float b, float rb) {  // a / b from the exact reciprocal (chain_common.h)
     const float q0 = a * rb;
     const float r0 = fmaf(-b, q0, a);
     const float q1 = fmaf(r0, rb, q0);

@@ -131,7 +131,7 @@ struct rip_ctx {
     // 1.376 ms for f64 ipc4d x 8 groups, 0.85 against 0.95 ms for f32, same box, profiles/r03_summary.md -- and is taken there
     // whatever the option says; the option is still accepted)
     int use_chain3 = 2;
-    int last_form = 0;       // diagnostic: how the last rip_calibrate ran (0 stage kernels, 1 general fused, 2 wave-specialised, 3 wave-private)
+    int last_form = 0;       // diagnostic: how the last rip_calibrate ran (0 stage kernels, 2 wave-specialised, 3 wave-private; 1 was the general fused kernel of rounds 1-2)
     std::string err;
     std::vector<RipCal> cals;
     std::vector<RipPlan *> plans;

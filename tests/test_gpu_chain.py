@@ -209,8 +209,8 @@ def test_calibrateimage_files_end_to_end(tmp_path):
 
 
 def _set_form(ctx, form):
-    """2: the specialised fused kernel of the configuration (it reports 3 where that is the wave-private one: f64 ipc4d x 16
-    groups), 1: general fused, 0: stage kernels"""
+    """2: the fused kernel of the configuration (it reports 3 where that is the wave-private one: f64 ipc4d x 16 groups),
+    0: stage kernels"""
     ctx.set_option("fused", 1 if form else 0)
     ctx.set_option("chain2", 1 if form >= 2 else 0)
 
@@ -273,8 +273,8 @@ def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first, kdt):
 
 @pytest.mark.parametrize("kdt", [np.float32, np.float64])
 def test_fused_forms_agree_across_seams(kdt):
-    """A frame wider than several column strips and taller than several row ranges: the wave-specialised kernel, the general
-    fused kernel and the stage kernels must give identical bits (halo columns, range boundaries, frame edges)."""
+    """A frame wider than several column strips and taller than several row ranges: the wave-specialised kernel and the stage
+    kernels must give identical bits (halo columns, range boundaries, frame edges)."""
     rp = synth.READ_PATTERN_8
     ny, nx = 1160, 896
     cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=31, bias_amplitude=2.0, bad_lin_frac=0.005,
@@ -285,13 +285,13 @@ def test_fused_forms_agree_across_seams(kdt):
     cb.load_caldir(5, cal)
     outs = []
     try:
-        for form in (2, 1, 0):
+        for form in (2, 0):
             _set_form(ctx, form)
             outs.append(cb.calibrate(5, ramp, want_cube=True))
             assert ctx.last_chain_form() == form
     finally:
         _default_form(ctx)
-    for other, label in ((outs[1], "general fused"), (outs[2], "stage kernels")):
+    for other, label in ((outs[1], "stage kernels"),):
         for k in ("cube", "slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
             assert_same_bits(outs[0][k], other[k], f"{k}: wave-specialised vs {label}")
     assert np.count_nonzero(outs[0]["pixeldq"] & 4) > 1000 and np.count_nonzero(outs[0]["pixeldq"] & 2) > 100
@@ -350,7 +350,7 @@ FULL_FRAME = [
     ("g8_k64", synth.READ_PATTERN_8, np.float64, 8, 4096),     # ... with the f64 ipc4d of production CALDIR sets
     # BASELINE config 3 (READS = [0..35], 16 groups): the numpy oracle needs more than 7 minutes for a 16-group full frame
     # (13 truncated refits, O(G^2) variance passes), so it checks a 264-row frame of the full width and the full frame is
-    # checked between the three device forms
+    # checked between the fused kernel and the stage kernels
     ("g16_f32", synth.READ_PATTERN_16, np.float32, 8, 264),
 ]
 
@@ -359,7 +359,7 @@ FULL_FRAME = [
 def test_full_frame_4096x4096_vs_oracle_and_between_forms(name, rp, kdt, p, oracle_rows):
     """BASELINE configs 2 and 3 at their full size on a NON-PERIODIC frame (sky + 25 Gaussian sources, seeded, generated
     on the device by synth_gpu): the numpy oracle on the whole frame (about a minute of CPU) against the default fused kernel,
-    bit for bit with LAPACK's channel lines handed in; then every device form (wave-specialised, general fused, stage kernels) against each other with the lines fitted on the device."""
+    bit for bit with LAPACK's channel lines handed in; then the fused kernel against the stage kernels against each other with the lines fitted on the device."""
     from romanimpreprocess_amd import synth_gpu
 
     n = 4096
@@ -399,11 +399,11 @@ def test_full_frame_4096x4096_vs_oracle_and_between_forms(name, rp, kdt, p, orac
         # the sources are there
         assert np.count_nonzero(ramp["rate"][4:-4, 4:-4] > 100.0) > 200
         outs = []
-        for form in (2, 1, 0):
+        for form in (2, 0):
             _set_form(ctx, form)
             outs.append(cb.calibrate(6, ramp))
             assert ctx.last_chain_form() == form
-        for other, label in ((outs[1], "general fused"), (outs[2], "stage kernels")):
+        for other, label in ((outs[1], "stage kernels"),):
             for k in ("slope", "err_read", "err_poisson", "pixeldq", "groupdq"):
                 assert_same_bits(outs[0][k], other[k], f"{k}: wave-specialised vs {label}")
         # device-fitted lines against LAPACK's: flags identical, slopes within the north-star tolerance
@@ -455,8 +455,8 @@ UNUSUAL = [
 
 @pytest.mark.parametrize("name,rp,exclude_first", UNUSUAL)
 def test_unusual_group_counts_vs_oracle(name, rp, exclude_first):
-    """Group counts outside the specialised instantiations (odd counts cannot take the fused kernel at all: groups travel in
-    pairs there) run through the general fused kernel or the stage kernels and still match the oracle bit for bit."""
+    """Group counts outside the fused kernel's instantiations run through the stage kernels and still match the oracle bit for
+    bit."""
     ny, nx = 40, 256
     cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=3, seed=61, bias_amplitude=1.0)
     ramp = synth.make_ramp(cal, read_pattern=rp, seed=62, cr_frac=0.03)
