@@ -37,6 +37,8 @@ out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate
                   "--steps 20 --warmup 2 --clock-ramp-s 0 --no-cpu-baseline --no-extras",
        "kernel": dominant, "per_kernel": {}}
 for k in sorted(set(fetch) | set(write)):
+    if "at::native" in k or "rocprim" in k or "rocclr" in k or k.strip() == "void":   # torch's kernels of the input synthesis: not the library's
+        continue
     out["per_kernel"][k] = {"FETCH_SIZE_KB_mean": sum(fetch[k]) / max(len(fetch[k]), 1), "launches_FETCH_SIZE": len(fetch[k]),
                             "WRITE_SIZE_KB_mean": sum(write[k]) / max(len(write[k]), 1), "launches_WRITE_SIZE": len(write[k])}
 if dominant:
