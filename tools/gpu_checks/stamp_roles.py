@@ -19,7 +19,12 @@ rp = synth.READ_PATTERN_8 if NG == 8 else synth.READ_PATTERN_16
 KDT = np.float64 if os.environ.get("IPC64") == "1" else np.float32
 SPLIT = 0   # (the split form -- four roles on half the groups each, profiles/r03_summary.md -- was not kept)
 N = 4096
-cal, ramp = synth.make_tiled_inputs(N, N, read_pattern=rp, p_order=8, seed=1, strip_rows=64, ipc_dtype=KDT)
+if os.environ.get("TILED") == "1":   # the homogeneous tiled frame of round 1 (many more saturated / jump pixels per wave)
+    cal, ramp = synth.make_tiled_inputs(N, N, read_pattern=rp, p_order=8, seed=1, strip_rows=64, ipc_dtype=KDT)
+else:                                # the bench's non-periodic frame
+    from romanimpreprocess_amd import synth_gpu
+    cal = synth_gpu.make_caldir(N, N, read_pattern=rp, p_order=8, seed=1000, ipc_dtype=KDT, device=0)
+    ramp = synth_gpu.make_ramp(cal, read_pattern=rp, seed=1, device=0)
 cb = pipeline.Calibrator(device=0)
 lib = cb.ctx.lib
 lib.rip_chain_stamps.restype = C.c_int
