@@ -68,6 +68,56 @@ __device__ inline double poisson(double lam, uint64_t seed, uint32_t a, uint32_t
     return floor(lam + 0.5);   // not reached in practice
 }
 
+// log(k!) for integer-valued k >= 0: exact table below 8, Stirling's series above (truncation < 2e-12 at k + 1 = 9): one logarithm
+// where lgamma costs several
+__device__ __forceinline__ double log_factorial(double k) {
+    if (k < 8.0) {
+        const int i = (int)k;
+        const double t[8] = {0.0, 0.0, 0.6931471805599453, 1.791759469228055, 3.1780538303479458, 4.787491742782046, 6.579251212010101,
+                             8.525161361065415};
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r = (i == j) ? t[j] : r;
+        return r;
+    }
+    const double x = k + 1.0, ix = 1.0 / x, ix2 = ix * ix;
+    const double corr = ix * (1.0 / 12.0 - ix2 * (1.0 / 360.0 - ix2 * (1.0 / 1260.0 - ix2 * (1.0 / 1680.0))));
+    return (k + 0.5) * log(x) - x + 0.9189385332046727 + corr;
+}
+
+// Poisson deviate of mean lam with sqrt(lam) and log(lam) handed in (the apportioning draws 35 of them per pixel with
+// lam = counts * share: the root and the logarithm of the counts once per pixel, those of the shares once per read pattern).
+// Same algorithm as poisson(); the acceptance test outside the squeeze costs two logarithms (log_factorial, one merged left side)
+// instead of three and a lgamma -- every wave takes that path for some lane on almost every draw.
+__device__ inline double poisson_pre(double lam, double slam, double loglam, uint64_t seed, uint32_t a, uint32_t b, uint32_t tag) {
+    if (!(lam > 0.0)) return 0.0;
+    if (lam < 10.0) {
+        uint32_t c[4] = {a, b, tag, 0x706f6932u};
+        philox(c, seed);
+        const double u = u53(c[0], c[1]);
+        double p = exp(-lam), cdf = p;
+        int k = 0;
+        while (u > cdf && k < 200) {
+            ++k;
+            p *= lam / k;
+            cdf += p;
+        }
+        return (double)k;
+    }
+    const double bb = 0.931 + 2.53 * slam, aa = -0.059 + 0.02483 * bb, inv_alpha = 1.1239 + 1.1328 / (bb - 3.4), vr = 0.9277 - 3.6224 / (bb - 2.0);
+    for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+        uint32_t c[4] = {a, b, tag ^ (attempt << 24), 0x70747232u};
+        philox(c, seed);
+        const double u = u53(c[0], c[1]) - 0.5, v = u53(c[2], c[3]);
+        const double us = 0.5 - fabs(u);
+        const double k = floor((2.0 * aa / us + bb) * u + lam + 0.43);
+        if (us >= 0.07 && v <= vr) return k;
+        if (k < 0.0 || (us < 0.013 && v > us)) continue;
+        if (log(v * inv_alpha / (aa / (us * us) + bb)) <= -lam + k * loglam - log_factorial(k)) return k;
+    }
+    return floor(lam + 0.5);   // not reached in practice
+}
+
 // Binomial(n, p) deviate: inversion (sequential search) where n min(p, 1-p) < 10, else W. Hoermann's transformed rejection
 // with squeeze (BTRS, "The generation of binomial random variates", 1993); the acceptance test compares with the exact ratio
 // of probabilities through lgamma.

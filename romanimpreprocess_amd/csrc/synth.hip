@@ -24,7 +24,10 @@ constexpr uint32_t TAG_TOTAL = 0x10, TAG_SHARE = 0x11, TAG_RESET = 0x12, TAG_REA
 constexpr int MAX_READS = 1024;
 
 struct ShareTable {
-    double p[MAX_READS];   // share of the electrons still to come that read r collects
+    double p[MAX_READS];    // share of the electrons still to come that read r collects
+    double w[MAX_READS];    // share of ALL the electrons that read r collects, its square root and its logarithm
+    double sw[MAX_READS];
+    double lw[MAX_READS];
 };
 
 __global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict__ counts, size_t npix, int poisson, int nreads,
@@ -32,7 +35,20 @@ __global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict_
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= npix) return;
     double c = (double)counts[i];
-    if (poisson) c = riprng::poisson(c, seed, (uint32_t)i, 0u, TAG_TOTAL);
+    if (poisson) {
+        // A Poisson total split multinomially over the reads IS a set of independent Poisson increments of mean counts * share:
+        // same joint distribution as drawing the total first and then the binomial shares (romanisim's order), one cheap deviate
+        // per read instead of an expensive one (the binomial's acceptance test costs four log-gammas)
+        c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);
+        const double sc = sqrt(c), lc = (c > 0.0) ? log(c) : 0.0;
+        const double *w = share + MAX_READS, *sw = share + 2 * MAX_READS, *lw = share + 3 * MAX_READS;
+        double got_d = 0.0;
+        for (int r = 0; r < nreads; ++r) {
+            got_d += riprng::poisson_pre(c * w[r], sc * sw[r], lc + lw[r], seed, (uint32_t)i, (uint32_t)r, TAG_TOTAL);
+            out[(size_t)r * npix + i] = (int)(got_d > 2.0e9 ? 2.0e9 : got_d);
+        }
+        return;
+    }
     c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);   // np.clip(counts, 0, 2e9).astype(i4)
     const int total = (int)c;
     int got = 0;
@@ -261,10 +277,16 @@ extern "C" int rip_synth_apportion(rip_ctx *ctx, const float *counts, int nya, i
         t_end = t_reads[r];
     }
     double t_prev = 0.0;
+    memset(&tab, 0, sizeof tab);
     for (int r = 0; r < nreads; ++r) {
         const double left = t_end - t_prev;
         double p = left > 0.0 ? (t_reads[r] - t_prev) / left : 1.0;
         tab.p[r] = p < 0.0 ? 0.0 : (p > 1.0 ? 1.0 : p);
+        double w = t_end > 0.0 ? (t_reads[r] - t_prev) / t_end : (r == nreads - 1 ? 1.0 : 0.0);
+        w = w < 0.0 ? 0.0 : w;
+        tab.w[r] = w;
+        tab.sw[r] = sqrt(w);
+        tab.lw[r] = w > 0.0 ? log(w) : 0.0;
         t_prev = t_reads[r];
     }
     const void *had = ctx->ws[10];
@@ -277,7 +299,7 @@ extern "C" int rip_synth_apportion(rip_ctx *ctx, const float *counts, int nya, i
     if (!same) {
         RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->share_tab.assign(tab.p, tab.p + nreads);
-        RIP_HIP(ctx, hipMemcpy(d_tab, ctx->share_tab.data(), sizeof(double) * nreads, hipMemcpyHostToDevice));
+        RIP_HIP(ctx, hipMemcpy(d_tab, &tab, sizeof(ShareTable), hipMemcpyHostToDevice));
     }
     const size_t npix = (size_t)nya * nxa;
     hipLaunchKernelGGL(apportion_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, counts, npix, poisson, nreads,

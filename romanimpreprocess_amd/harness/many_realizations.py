@@ -84,14 +84,15 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
 
     ``generator``: "host" = ``synth.make_ramp`` (numpy; minutes per full frame), "device" = ``synth_gpu.RampFactory`` (the same
     recipe in torch on the GPU: about half a second per full frame, nothing crosses PCIe -- BASELINE config 5 at full size),
-    "hip" = the reference's own synthesis path on the device (``from_sim.sim_to_isim.L1Synth``: Poisson totals, binomial shares
-    per read, ``make_l1_fullcal``, ``fill_in_refdata_and_1f`` as HIP kernels; dq-init and saturation flagging by the
+    "hip" = the reference's own synthesis path on the device (``from_sim.sim_to_isim.L1Synth``: Poisson totals apportioned to
+    the reads, ``make_l1_fullcal``, ``fill_in_refdata_and_1f`` as HIP kernels; dq-init and saturation flagging by the
     calibration call itself).
     ``timings``: optional dict that receives the seconds spent generating, calibrating + stacking, and reducing."""
     import time
 
     import torch
 
+    t_start = time.perf_counter()
     device = device or torch.device("cuda", calibrator.ctx.device)
     rp = synth.READ_PATTERN_8 if read_pattern is None else read_pattern
     ny, nx = cal["gain"]["data"].shape
@@ -121,6 +122,8 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
     elif generator not in ("host", "device"):
         raise ValueError(f"generator {generator!r}: host, device or hip")
     t_gen = t_cal = 0.0
+    torch.cuda.synchronize(device)
+    t_setup = time.perf_counter() - t_start   # rate image, stacks in HBM, generator state
     for k, sd in enumerate(seeds):
         t0 = time.perf_counter()
         if hip_synth is not None:
@@ -164,6 +167,6 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
                          ctx=calibrator.ctx)
     full = sharding.gather_rows(planes, ny)
     if timings is not None:
-        timings.update({"generate_s": t_gen, "calibrate_and_stack_s": t_cal, "exchange_and_reduce_s": time.perf_counter() - t_red,
-                        "realisations_on_this_rank": len(seeds)})
+        timings.update({"setup_s": t_setup, "generate_s": t_gen, "calibrate_and_stack_s": t_cal,
+                        "exchange_and_reduce_s": time.perf_counter() - t_red, "realisations_on_this_rank": len(seeds)})
     return None if full is None else full.cpu().numpy()
