@@ -140,16 +140,31 @@ __global__ __launch_bounds__(256) void resultants_kernel(ResArgs a) {
 #pragma unroll
     for (int q = 0; q < 24; ++q) phi_path[q] = 0.0f;
     int r = 0;
+    // the nine electron counts of a read are requested one read ahead: they land while the 24 bisection steps of the read before
+    // run (a read's loads are L2 hits ~1 k cycles away, its bisection ~5 k cycles: without the prefetch a fifth of the time is
+    // spent waiting for them)
+    int nreads_all = 0;
+    for (int j = 0; j < a.ngrp; ++j) nreads_all += a.count[j];
+    int32_t en[9];
+    auto fetch_read = [&](int rr) {
+        const int32_t *e = a.reads_e + (size_t)(rr < nreads_all ? rr : nreads_all - 1) * nact;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) en[k] = (off[k] >= 0) ? e[off[k]] : 0;
+    };
+    fetch_read(0);
     for (int j = 0; j < a.ngrp; ++j) {
         float acc = 0.0f;
         for (int q = 0; q < a.count[j]; ++q, ++r) {
-            const int32_t *e = a.reads_e + (size_t)r * nact;
+            int32_t ec[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) ec[k] = en[k];
+            fetch_read(r + 1);
             // ipc_fwd of (electrons + reset) in f64: centre product first, then the neighbours in the reference's order
-            double conv = ((double)e[off[0]] + sq[0]) * kq[0];
+            double conv = ((double)ec[0] + sq[0]) * kq[0];
             if (kern) {
 #pragma unroll
                 for (int k = 1; k < 9; ++k)
-                    if (off[k] >= 0) conv = conv + ((double)e[off[k]] + sq[k]) * kq[k];
+                    if (off[k] >= 0) conv = conv + ((double)ec[k] + sq[k]) * kq[k];
             }
             bool ex;
             const double S = rip_invlin_pixel_warm<double, NP>(conv / g, c, smin, smax, ex, phi_path, path, have);

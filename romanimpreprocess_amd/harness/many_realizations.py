@@ -100,7 +100,28 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
     rate = synth.make_rate_image(ny, nx, seed0)
     seeds = sharding.scatter_items([seed0 + 10 * (j + 1) for j in range(nseeds)], device=device)
     pid, _ = calibrator.plan_for(rp, synth.FRAME_TIME)
-    st = SeedStacks(len(seeds), ny, nx, device, nb=nb, ctx=calibrator.ctx)
+    # the four stacks (13 B per pixel and realisation: 56 GB for 256 realisations of an SCA) are allocated by a helper thread while
+    # the first exposure is being made -- the driver maps a fresh allocation of that size in 0.3-1.9 s, and the first exposure
+    # spends 1.3 s of host time in the transform library's plan
+    import threading
+
+    st_box = {}
+
+    def _alloc_stacks():
+        try:
+            st_box["st"] = SeedStacks(len(seeds), ny, nx, device, nb=nb, ctx=calibrator.ctx)
+        except BaseException as exc:   # re-raised by the main thread
+            st_box["exc"] = exc
+
+    st_thread = threading.Thread(target=_alloc_stacks, daemon=True)
+    st_thread.start()
+
+    def stacks():
+        if st_thread.is_alive():
+            st_thread.join()
+        if "exc" in st_box:
+            raise st_box["exc"]
+        return st_box["st"]
     slope = torch.empty((ny, nx), dtype=torch.float32, device=device)
     er, ep = torch.empty_like(slope), torch.empty_like(slope)
     pdq = torch.empty((ny, nx), dtype=torch.int32, device=device)
@@ -133,7 +154,7 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
             calibrator.calibrate_device(slot, pid, len(rp), cube.data_ptr(), True, a33.data_ptr(), None, t_pdq_hip.data_ptr(),
                                         slope.data_ptr(), er.data_ptr(), ep.data_ptr(), pdq.data_ptr(), flag_saturation=True,
                                         read_pattern=rp)   # the saturation rule calibrateimage applies (gen_cal_image.py:172-185)
-            st.push(k, cube, slope, er, ep, pdq)
+            stacks().push(k, cube, slope, er, ep, pdq)
             calibrator.synchronize()
             t_gen += t1 - t0
             t_cal += time.perf_counter() - t1
@@ -152,10 +173,11 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
         t1 = time.perf_counter()
         calibrator.calibrate_device(slot, pid, len(rp), cube.data_ptr(), True, a33.data_ptr(), t_gdq.data_ptr(),
                                     t_pdq.data_ptr(), slope.data_ptr(), er.data_ptr(), ep.data_ptr(), pdq.data_ptr())
-        st.push(k, cube, slope, er, ep, pdq)
+        stacks().push(k, cube, slope, er, ep, pdq)
         calibrator.synchronize()
         t_gen += t1 - t0
         t_cal += time.perf_counter() - t1
+    st = stacks()
     t_red = time.perf_counter()
     ideal = torch.from_numpy(ideal_slope(cal, rate, nb)).to(device)
     rows = []
