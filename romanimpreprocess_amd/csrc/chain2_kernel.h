@@ -25,9 +25,11 @@
 #pragma once
 #include "chain_common.h"
 
-#ifndef C2_COLS
-#define C2_COLS 256
+#ifndef C2_COLS_DEF
+#define C2_COLS_DEF 256
 #endif
+// columns of a workgroup's window: a constant `COLS` of the enclosing template (256; 128 in the narrow form, see chain2_kernel)
+#define C2_COLS COLS
 #define C2_THREADS (2 * C2_COLS)
 #ifdef CH_STAMP
 #define C2_DRAIN()                                \
@@ -42,13 +44,16 @@
 #else
 #define C2_SYNC() __syncthreads()
 #endif
+// Strip geometry: the window of strip s starts at column s * C2_OUTW; its lanes 2 .. C2_COLS-3 emit, lanes 0, 1 and C2_COLS-2,
+// C2_COLS-1 are the halo of the two 3 x 3 passes -- except at the frame's edge, where columns 0, 1 and nx-2, nx-1 are emitted
+// by those lanes themselves (border pixels: no IPC, no neighbours needed; nb >= 2).  So n strips cover n * C2_OUTW + 4 columns:
+// 33 strips of 128 columns cover 4096 exactly (34 with a uniform 2-column offset), 17 of 256.
 #ifdef C2_ALIGNED_TIMING   // TIMING experiment only (wrong strip edges): 16 aligned 256-column windows, no halo
 #define C2_OUTW C2_COLS
-#define C2_HALO 0
 #else
 #define C2_OUTW (C2_COLS - 4)
-#define C2_HALO 2
 #endif
+#define C2_NSTRIPS(nx) (((nx) - 4 + C2_OUTW - 1) / C2_OUTW < 1 ? 1 : ((nx) - 4 + C2_OUTW - 1) / C2_OUTW)
 // Where the half-step barrier falls in the fit role: 0 after the first half of the fit, 1 after its second half (and the saturated
 // refits), 2 after the flag propagation and the group-flag stores, 3 after the finish and the plane stores.  Same-box A/B on the
 // bench frame (profiles/r03_summary.md): f32 ipc4d x 8 groups 0.884 / 0.887 / 0.895 ms for 0 / 1 / 2; 16 groups 2.048 / 2.003 /
@@ -60,6 +65,9 @@
 // 1.345 -> 1.360, stays 2)
 #ifndef C2_PBW
 #define C2_PBW -1
+#endif
+#ifndef C2_KFIT_EARLY   // narrow form: the fit role requests its coefficients at the end of the step before (1) or at the top of the step (0)
+#define C2_KFIT_EARLY 1
 #endif
 #ifndef C2_NBO   // f64 ipc4d: groups the second iterate evaluates in lockstep (2 or 4)
 #define C2_NBO 2
@@ -220,12 +228,17 @@ __device__ __forceinline__ void c2_div64_shared(const double (&a)[NG], float bf,
     }
 }
 
-template <int NP, int G, int START, typename KT = float>
-__global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
+// NARROW = 1, the narrow form (f64 ipc4d): a workgroup of 256 threads on a 128-column window WITHOUT the K ring (the fit role loads
+// the nine coefficients itself: the second read of a line the ingest role fetched two steps earlier) -- 43 KB of LDS instead of
+// 120 KB, so that a CU holds THREE workgroups = 12 waves = 3 waves/SIMD at <= 168 VGPRs where the 256-column form has 2.
+template <int NP, int G, int START, typename KT = float, int NARROW = 0>
+__global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), (NARROW ? 3 : ((G > 8 || sizeof(KT) == 8) ? 2 : 4))) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
                                                                const RipVariant *__restrict__ vars,
                                                                const float *__restrict__ kvals,
                                                                const RipDiff *__restrict__ diffs, double guard) {
     static_assert(G % 2 == 0 && G > 4 && G <= 16, "pairs of groups; the groupdq bytes travel packed four to a word");
+    constexpr int COLS = NARROW ? 128 : C2_COLS_DEF;
+    constexpr bool KRING = !NARROW;
     constexpr int QW = (G + 3) / 4;  // words of packed group flags per pixel
     constexpr int GP = G / 2;
     // f64 ipc4d (KT = double; the reference's production writer stores f64): x = gain*phi stays f32, the Neumann iterates and
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
         chf[L] = (float)((double)(L * (L + 1)) / 2.0);
     }
 
-    const int nstrips = (nx + C2_OUTW - 1) / C2_OUTW;
+    const int nstrips = C2_NSTRIPS(nx);
     const int nranges = gridDim.x / nstrips;
     const int rows_per = (ny + nranges - 1) / nranges;
     const int bid = c2_xcd_block((int)blockIdx.x, (int)gridDim.x);
@@ -283,11 +296,11 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
     const int R0 = (bid / nstrips) * rows_per;
     const int R1 = min(ny, R0 + rows_per);
     if (bid >= nstrips * nranges || R0 >= ny) return;
-    const int c = strip * C2_OUTW - C2_HALO + col;
+    const int c = strip * C2_OUTW + col;
     const bool col_ok = (c >= 0 && c < nx);
     const bool col_act = (c >= ax0 && c < ax1);
     const int cc = col_ok ? c : 0;
-    const int ch0 = max(strip * C2_OUTW - C2_HALO, 0) / RIP_CW;
+    const int ch0 = (strip * C2_OUTW) / RIP_CW;
     const int chr = cc / RIP_CW - ch0;
     for (int i = tid; i < 3 * G * 2; i += C2_THREADS) {
         const int ch = i / (G * 2), g = (i / 2) % G, w = i & 1;
@@ -690,7 +703,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 const int so = so_c;  // slot of row yc in both 3-row rings
                 const int sm = (so == 0) ? 2 : so - 1, s0 = so, sp = (so == 2) ? 0 : so + 1;
                 // hand the coefficients of destination row yc to the fit thread of this column (O2 of row yc, two steps on)
-                {
+                if constexpr (KRING) {
                     const int ks = yc & 1;
                     if constexpr (K64) {
 #pragma unroll
@@ -703,7 +716,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 }
                 if constexpr (K64) {
                     // two pairs (four groups) in lockstep: their 18 ring reads first, then four interleaved f64 chains
-                    constexpr int PBC = (GP % 2 == 0) ? 2 : 1;
+                    constexpr int PBC = (GP % 2 == 0 && !NARROW) ? 2 : 1;   // (narrow form: 168 registers -- one pair at a time)
 #pragma unroll
                     for (int p0 = 0; p0 < GP; p0 += PBC) {
 #pragma unroll
@@ -777,8 +790,14 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
 #pragma unroll
         for (int i = 0; i < QW; ++i) qw_next[i] = 0;
         int o0_r = (R0 - 5 + 3000) % 3;  // O1 ring slot of row r
+        f2 kn[5];       // narrow form: the coefficients of the next step's row (C2_KFIT_EARLY)
+        double kn_d[9];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) kn[i] = f2{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) kn_d[k] = 0.0;
         for (int r = R0 - 5; r <= R1; ++r, o0_r = (o0_r == 2) ? 0 : o0_r + 1) {
-            const bool emit = (r >= R0) && (r < R1) && col >= 2 && col < C2_COLS - 2 && col_ok;
+            const bool emit = (r >= R0) && (r < R1) && col_ok && (col >= 2 || c < 2) && (col < C2_COLS - 2 || c >= nx - 2);
             const RIP_K C2KernArgs *kf = c2_args(kargs);  // S1 copy of the argument block
             const unsigned rc_ = (unsigned)min(max(r, R0), yhi);   // (rows before R0 are warm-up steps: nothing is emitted there)
             const unsigned pe = rc_ * (unsigned)nx + cc1;
@@ -808,7 +827,7 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
             CH_T(0)
             C2_DRAIN()
             CH_T(1)
-            constexpr int BAR = (C2_BAR >= 0) ? C2_BAR : (K64 ? 2 : (G > 8 ? 1 : 0));
+            constexpr int BAR = (C2_BAR >= 0) ? C2_BAR : (NARROW ? 1 : (K64 ? 2 : (G > 8 ? 1 : 0)));
             // The tail of pixel (r, c) in three parts; the half-step barrier falls between two of them (C2_BAR: everything after O2 is
             // register-only in a fit thread, so the barrier sits where both roles take about the same time in both halves).
             float s = 0.0f, er = 0.0f, ep = 0.0f;
@@ -896,12 +915,26 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                     *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(kx->a.pdq_out) + t_row4 + w4) = pdq;
                 }
             };
+            // narrow form: the fit role loads the nine coefficients of destination (r, col) itself (all lanes: clamped addresses)
+            f2 kF[5];
+            double kFd[9];
+            kF[4].y = 0.0f;
+            if constexpr (!KRING) {
+#if C2_KFIT_EARLY   // requested at the end of the step before (they land across the barrier)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) kFd[k] = kn_d[k];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) kF[i] = kn[i];
+#else
+                if constexpr (K64)
+                    (void)load_kd(C2Last{}, kf->a.kern, r, true, kFd);
+                else
+                    (void)load_k(C2Last{}, kf->a.kern, r, true, kF);
+#endif
+            }
             if (emit) {
                 // the nine coefficients of destination (r, col) from the ingest thread of this column
-                f2 kF[5];
-                double kFd[9];
-                kF[4].y = 0.0f;
-                {
+                if constexpr (KRING) {
                     const int ks = r & 1;
                     if constexpr (K64) {
 #pragma unroll
@@ -1051,6 +1084,14 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
                 dq_next = DQ[sn * C2_COLS + col];
                 gain_next = GN[sn * C2_COLS + col];
             }
+#if C2_KFIT_EARLY
+            if constexpr (!KRING) {
+                if constexpr (K64)
+                    (void)load_kd(C2Last{}, kg->a.kern, r + 1, true, kn_d);
+                else
+                    (void)load_k(C2Last{}, kg->a.kern, r + 1, true, kn);
+            }
+#endif
             CH_T(6)
             C2_SYNC();
             CH_T(7)
@@ -1064,29 +1105,32 @@ __global__ __launch_bounds__(C2_THREADS, ((G > 8 || sizeof(KT) == 8) ? 2 : 4)) v
 #endif
 }
 
-static inline size_t chain2_lds_bytes(int G, size_t ksize = 4) {
+static inline size_t chain2_lds_bytes(int G, size_t ksize = 4, int cols = C2_COLS_DEF, bool kring = true) {
     // x ring (3 rows) + O1 ring (3 rows) + flag word / packed groupdq / gain rings (3 rows) + channel lines + K ring (2 rows)
-    return (size_t)(G / 2) * C2_COLS * 8 * 3 + (size_t)G * C2_COLS * ksize * 3 + (size_t)C2_COLS * 4 * 3 * (2 + (G + 3) / 4) +
-           (size_t)3 * G * 2 * 8 + (size_t)2 * 9 * C2_COLS * ksize;
+    return (size_t)(G / 2) * cols * 8 * 3 + (size_t)G * cols * ksize * 3 + (size_t)cols * 4 * 3 * (2 + (G + 3) / 4) +
+           (size_t)3 * G * 2 * 8 + (kring ? (size_t)2 * 9 * cols * ksize : 0);
 }
 
-template <int NP, int G, int START, typename KT = float>
+template <int NP, int G, int START, typename KT = float, int NARROW = 0>
 static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
-    const size_t lds = chain2_lds_bytes(G, sizeof(KT));
+    constexpr int COLS = NARROW ? 128 : C2_COLS_DEF;
+    const size_t lds = chain2_lds_bytes(G, sizeof(KT), COLS, !NARROW);
     const int ncu = ctx->ncu;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
-    const int max_wg = ((G > 8 || sizeof(KT) == 8) ? 8 : 16) / (C2_THREADS / 64);  // 4 waves/SIMD at <= 128 VGPRs (2 at 256 for G = 16 / f64)
+    // 4 waves/SIMD at <= 128 VGPRs (2 at 256 for G = 16 / f64; 3 at 168 in the narrow form)
+    const int max_wg = (NARROW ? 12 : ((G > 8 || sizeof(KT) == 8) ? 8 : 16)) / (C2_THREADS / 64);
     if (per_cu > max_wg) per_cu = max_wg;
-    const int nstrips = (a.nx + C2_OUTW - 1) / C2_OUTW;
+    if (a.nb < 2) return 1;   // (the frame-edge lanes of the first / last strip emit without neighbours: border pixels)
+    const int nstrips = C2_NSTRIPS(a.nx);
     int nranges = (int)(((long)ncu * per_cu) / nstrips);
     if (nranges > (a.ny + 7) / 8) nranges = (a.ny + 7) / 8;
     if (nranges < 1) nranges = 1;
     const long grid = (long)nranges * nstrips;
     if (lds > 48 * 1024)
-        RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chain2_kernel<NP, G, START, KT>),
+        RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chain2_kernel<NP, G, START, KT, NARROW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((chain2_kernel<NP, G, START, KT>), dim3((unsigned)grid), dim3(C2_THREADS), lds, ctx->stream, a,
+    hipLaunchKernelGGL((chain2_kernel<NP, G, START, KT, NARROW>), dim3((unsigned)grid), dim3(C2_THREADS), lds, ctx->stream, a,
                        reinterpret_cast<const RipPlanHeader *>(plan->dev), plan->d_variants, plan->d_k, plan->d_diffs,
                        ctx->guard_band);
     RIP_HIP(ctx, hipGetLastError());
@@ -1094,9 +1138,9 @@ static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
 }
 
 // returns the launch status, or 1 when the plan is not one the specialised kernel was compiled for
-template <int NP, int G, typename KT = float>
+template <int NP, int G, typename KT = float, int NARROW = 0>
 static int launch_chain2(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
-    if (plan->h.start == 0 && plan->dense.valid == rip_full_valid<G, 0>()) return launch_chain2_s<NP, G, 0, KT>(ctx, plan, a);
-    if (plan->h.start == 1 && plan->dense.valid == rip_full_valid<G, 1>()) return launch_chain2_s<NP, G, 1, KT>(ctx, plan, a);
+    if (plan->h.start == 0 && plan->dense.valid == rip_full_valid<G, 0>()) return launch_chain2_s<NP, G, 0, KT, NARROW>(ctx, plan, a);
+    if (plan->h.start == 1 && plan->dense.valid == rip_full_valid<G, 1>()) return launch_chain2_s<NP, G, 1, KT, NARROW>(ctx, plan, a);
     return 1;
 }
