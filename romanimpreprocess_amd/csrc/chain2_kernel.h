@@ -239,6 +239,8 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), (NARROW ? 3 : ((G
     static_assert(G % 2 == 0 && G > 4 && G <= 16, "pairs of groups; the groupdq bytes travel packed four to a word");
     constexpr int COLS = NARROW ? 128 : C2_COLS_DEF;
     constexpr bool KRING = !NARROW;
+    constexpr bool WRING = NARROW < 2;   // NARROW = 2 (16 groups): gain and packed groupdq bytes do not travel through LDS either --
+                                         // the fit role loads them itself, like the coefficients (51 KB: three workgroups per CU)
     constexpr int QW = (G + 3) / 4;  // words of packed group flags per pixel
     constexpr int GP = G / 2;
     // f64 ipc4d (KT = double; the reference's production writer stores f64): x = gain*phi stays f32, the Neumann iterates and
@@ -255,8 +257,8 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), (NARROW ? 3 : ((G
     // per-pixel words that travel from the ingest thread of a column to its fit thread (3-row rings, slots as the x ring: the fit
     // thread takes row r+1's at the end of step r): the flag word, the packed groupdq bytes, the gain
     uint32_t *QS = DQ + 3 * C2_COLS;                                // [3][QW][C2_COLS] groupdq bytes of the pixel, packed
-    float *GN = reinterpret_cast<float *>(QS + 3 * QW * C2_COLS);   // [3][C2_COLS] gain of the pixel (f32)
-    double *LN = reinterpret_cast<double *>(GN + 3 * C2_COLS);       // [3][G][2] channel lines of this strip
+    float *GN = reinterpret_cast<float *>(QS + (WRING ? 3 * QW * C2_COLS : 0));   // [3][C2_COLS] gain of the pixel (f32)
+    double *LN = reinterpret_cast<double *>(GN + (WRING ? 3 * C2_COLS : 0));       // [3][G][2] channel lines of this strip
     // K ring: the nine IPC coefficients of destination (row, col), loaded ONCE by the ingest thread of the column and handed to
     // its fit thread (two rows live: C of row y runs two steps before O2 of row y)
     f2 *KR2 = reinterpret_cast<f2 *>(LN + 3 * G * 2);               // f32 ipc4d: [2][4][C2_COLS] pairs (k0,k1)..(k6,k7)
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), (NARROW ? 3 : ((G
             const double yd = (double)yi;
             // pairs per block (their recurrences interleave): 2 at 128 registers; the forms with a 256-register budget (16 groups, f64
             // ipc4d: one workgroup per CU) may take C2_PBW
-            constexpr int PBW = (C2_PBW > 0) ? C2_PBW : ((G > 8 && !K64) ? 4 : 2);
+            constexpr int PBW = (C2_PBW > 0) ? C2_PBW : ((G > 8 && !K64 && !NARROW) ? 4 : 2);
             constexpr int PB = ((K64 || G > 8) && GP % PBW == 0) ? PBW : (GP % 2 == 0) ? 2 : 1;
 #pragma unroll
             for (int pb = 0; pb < GP; pb += PB) {
@@ -674,9 +676,11 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), (NARROW ? 3 : ((G
             if (do_a) {
                 const bool keep = a_full && col_ok;
                 DQ[xslot * C2_COLS + col] = keep ? dq : 0u;
+                if constexpr (WRING) {
 #pragma unroll
-                for (int i = 0; i < QW; ++i) QS[(xslot * QW + i) * C2_COLS + col] = keep ? w[i] : 0u;
-                GN[xslot * C2_COLS + col] = rr.gain;
+                    for (int i = 0; i < QW; ++i) QS[(xslot * QW + i) * C2_COLS + col] = keep ? w[i] : 0u;
+                    GN[xslot * C2_COLS + col] = rr.gain;
+                }
             }
 #if !C2_KEARLY
             // IPC coefficients of row yc, consumed by C after the barrier; issued here so that their registers are not live
@@ -790,6 +794,9 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), (NARROW ? 3 : ((G
 #pragma unroll
         for (int i = 0; i < QW; ++i) qw_next[i] = 0;
         int o0_r = (R0 - 5 + 3000) % 3;  // O1 ring slot of row r
+        uint32_t qb_next[WRING ? 1 : G];   // NARROW = 2: the raw groupdq bytes of the next step's pixel
+#pragma unroll
+        for (int g = 0; g < (WRING ? 1 : G); ++g) qb_next[g] = 0;
         f2 kn[5];       // narrow form: the coefficients of the next step's row (C2_KFIT_EARLY)
         double kn_d[9];
 #pragma unroll
@@ -948,6 +955,12 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), (NARROW ? 3 : ((G
                 const unsigned vF = k_valid(r);
 #pragma unroll
                 for (int i = 0; i < QW; ++i) qw[i] = qw_next[i];
+                if constexpr (!WRING) {   // packed as the ingest role packs them
+#pragma unroll
+                    for (int i = 0; i < QW; ++i) qw[i] = 0;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) qw[g / 4] |= (qb_next[g] & 0xffu) << (8 * (g & 3));
+                }
                 lin_dq = dq_next;
                 const bool fastdiv = __all(rcp_safe(e_gain) || !act);
                 const float rgain = rip_rcp_mid(e_gain);
@@ -1079,10 +1092,24 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), (NARROW ? 3 : ((G
                 const int sn = (o0_r == 2) ? 0 : o0_r + 1;
 #pragma unroll
                 for (int p0 = 0; p0 < GP; ++p0) xnext[p0] = X2[(p0 * XR + sn) * C2_COLS + col];
-#pragma unroll
-                for (int i = 0; i < QW; ++i) qw_next[i] = QS[(sn * QW + i) * C2_COLS + col];
                 dq_next = DQ[sn * C2_COLS + col];
-                gain_next = GN[sn * C2_COLS + col];
+                if constexpr (WRING) {
+#pragma unroll
+                    for (int i = 0; i < QW; ++i) qw_next[i] = QS[(sn * QW + i) * C2_COLS + col];
+                    gain_next = GN[sn * C2_COLS + col];
+                } else {
+                    // the fit role's own loads of row r + 1 (second read of lines its ingest role fetched three steps earlier):
+                    // packed as the ingest role packs them; rows / columns outside the frame are never emitted
+                    const unsigned yl = (unsigned)min(max(r + 1, ylo), yhi);
+                    const __amdgpu_buffer_rsrc_t rq = c2_rsrc(kg->a.gdq);
+                    unsigned o1 = yl * (row4 >> 2);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {   // (raw: packed at the top of the next step, when they have landed)
+                        qb_next[g] = c2_ld_u8<C2_NT_F>(rq, cc1, o1);
+                        o1 += npix;
+                    }
+                    gain_next = c2_ld_f32<C2_NT_F>(c2_rsrc(kg->a.planes), cc4, (unsigned)(NP + 4) * pl4 + yl * row4);
+                }
             }
 #if C2_KFIT_EARLY
             if constexpr (!KRING) {
@@ -1105,16 +1132,16 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), (NARROW ? 3 : ((G
 #endif
 }
 
-static inline size_t chain2_lds_bytes(int G, size_t ksize = 4, int cols = C2_COLS_DEF, bool kring = true) {
-    // x ring (3 rows) + O1 ring (3 rows) + flag word / packed groupdq / gain rings (3 rows) + channel lines + K ring (2 rows)
-    return (size_t)(G / 2) * cols * 8 * 3 + (size_t)G * cols * ksize * 3 + (size_t)cols * 4 * 3 * (2 + (G + 3) / 4) +
+static inline size_t chain2_lds_bytes(int G, size_t ksize = 4, int cols = C2_COLS_DEF, bool kring = true, bool wring = true) {
+    // x ring (3 rows) + O1 ring (3 rows) + flag word (+ packed groupdq / gain) rings (3 rows) + channel lines + K ring (2 rows)
+    return (size_t)(G / 2) * cols * 8 * 3 + (size_t)G * cols * ksize * 3 + (size_t)cols * 4 * 3 * (wring ? 2 + (G + 3) / 4 : 1) +
            (size_t)3 * G * 2 * 8 + (kring ? (size_t)2 * 9 * cols * ksize : 0);
 }
 
 template <int NP, int G, int START, typename KT = float, int NARROW = 0>
 static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
     constexpr int COLS = NARROW ? 128 : C2_COLS_DEF;
-    const size_t lds = chain2_lds_bytes(G, sizeof(KT), COLS, !NARROW);
+    const size_t lds = chain2_lds_bytes(G, sizeof(KT), COLS, !NARROW, NARROW < 2);
     const int ncu = ctx->ncu;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;

@@ -1,6 +1,10 @@
 // Instantiations of the wave-specialised fused kernel for 4 Legendre planes (chain2_kernel.h).
 #include "chain2_kernel.h"
 
+#ifndef C2_G16_NARROW   // 16 groups: 2 = 128-column workgroups without K / word rings (three per CU), 0 = the 256-column form
+#define C2_G16_NARROW 2
+#endif
+
 int rip_launch_chain2_k64_np4(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a);  // chain_np4_k64.hip
 
 // returns the launch status, or 1 when no specialised instantiation fits (the caller takes the stage kernels)
@@ -14,7 +18,7 @@ int rip_launch_chain_np4(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, 
     } else {
         if (a.ngrp == 8) rc = launch_chain2<4, 8>(ctx, plan, a);
         if (a.ngrp == 6) rc = launch_chain2<4, 6>(ctx, plan, a);
-        if (a.ngrp == 16) rc = launch_chain2<4, 16>(ctx, plan, a);
+        if (a.ngrp == 16) rc = launch_chain2<4, 16, float, C2_G16_NARROW>(ctx, plan, a);
     }
     if (rc != 1) ctx->last_form = 2;
     return rc;
