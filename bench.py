@@ -357,8 +357,7 @@ def main():
     ap.add_argument("--p-order", type=int, default=8, choices=(3, 8, 10), help="Legendre order of the linearity file")
     ap.add_argument("--tiled", action="store_true", help="the round-1 input: a 128-row strip repeated down the frame (numpy)")
     ap.add_argument("--chain3", type=int, default=None, choices=(0, 1),
-                    help="(rounds 1-2: A/B switch of the wave-private fused kernel; it is instantiated for f64 ipc4d x 16 groups only "
-                         "since round 3 and taken there whatever this says)")
+                    help="(rounds 1-2: A/B switch of the wave-private fused kernel, removed in round 3; accepted, without effect)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip pre-pass exclusive timing, variants and the 18-slot batch")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
@@ -544,8 +543,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "alg_bytes_kernel": per_kernel[dom], "kernel_ms": avg_ms[dom],
-                         "kernel_form": {0: "stage kernels", 2: "wave-specialised fused (chain2_kernel.h)",
-                                         3: "wave-private fused (chain3_kernel.h)"}.get(cb.ctx.last_chain_form())},
+                         "kernel_form": {0: "stage kernels",
+                                         2: "wave-specialised fused (chain2_kernel.h)"}.get(cb.ctx.last_chain_form())},
             "chain": {"alg_bytes_per_ramp": total, "kernel_ms": avg_ms,
                       "wall_ms_per_ramp": wall_ms, "achieved_GBs": total / (wall_ms * 1e-3) / 1e9,
                       "frac_of_peak": total / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "good_pixel_fraction": frac_good},

@@ -390,16 +390,15 @@ int rip_profile_read(rip_ctx *ctx, double out_ms[4], int *ncalls);
    stage-by-stage kernels.  Both give identical results. */
 int rip_set_option(rip_ctx *ctx, const char *name, int value);
 /* further options (results identical either way; they exist for A/B timing and tests):
-   "chain2"  -- (default 1) the wave-specialised fused kernel (chain2_kernel.h: f32 ipc4d with 6, 8 or 16 groups, f64 ipc4d with
-                6 or 8); 0 = the stage kernels there (rounds 1-2: a general fused kernel, dropped in round 3);
-   "chain3"  -- accepted, without effect since round 3: the wave-private fused kernel (chain3_kernel.h) is instantiated for f64
-                ipc4d with 16 groups only -- the one configuration the wave-specialised kernel's rings do not fit -- and is
-                taken there;
+   "chain2"  -- (default 1) the fused kernel (chain2_kernel.h: f32 or f64 ipc4d with 6, 8 or 16 groups); 0 = the stage kernels
+                (rounds 1-2: a general fused kernel, dropped in round 3);
+   "chain3"  -- accepted, without effect since round 3 (the wave-private fused kernel of round 2 was removed: the wave-specialised
+                kernel is the faster one in every configuration);
    "overlap" -- run the reference-pixel pre-pass of a ramp on a second stream so that it overlaps the previous ramp's
                 fused kernel. */
 
-/* how the last rip_calibrate ran: 0 = stage kernels, 2 = wave-specialised fused kernel, 3 = wave-private fused kernel
-   (1 was the general fused kernel of rounds 1-2) */
+/* how the last rip_calibrate ran: 0 = stage kernels, 2 = the fused kernel (1 and 3 were the general and the wave-private fused
+   kernels of rounds 1-2) */
 int rip_last_chain_form(rip_ctx *ctx);
 
 /* pseudo-Poisson noise layers ("O" directives, gen_noise_image.py:173-240): per element of I (n doubles, host memory) the

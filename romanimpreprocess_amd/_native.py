@@ -248,7 +248,7 @@ class Context:
         self.check(self.lib.rip_set_option_f64(self.h, name.encode(), float(value)))
 
     def last_chain_form(self):
-        """0 = stage kernels, 2 = wave-specialised fused, 3 = wave-private fused kernel (last calibrate call; 1 was the general fused kernel of rounds 1-2)."""
+        """0 = stage kernels, 2 = the fused kernel (last calibrate call; 1 and 3 were the general and wave-private fused kernels of rounds 1-2)."""
         return int(self.lib.rip_last_chain_form(self.h))
 
     def profile(self, on=True):

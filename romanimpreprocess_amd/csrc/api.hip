@@ -234,19 +234,6 @@ int rip_chain_stamps(rip_ctx *ctx, double out[9]) {
     return RIP_OK;
 }
 
-// same buffer, wave-specialised kernel: waves 0-3 of a workgroup (ingest) -> out[0..8], waves 4-7 (fit) -> out[9..17]
-int rip_chain_stamps2(rip_ctx *ctx, double out[18]) {
-    const size_t n = 4096 * 9;
-    for (int i = 0; i < 18; ++i) out[i] = 0;
-    if (!ctx->chain_dbg_buf) return RIP_OK;
-    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<unsigned long long> h(n);
-    RIP_HIP(ctx, hipMemcpy(h.data(), ctx->chain_dbg_buf, n * 8, hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < n; ++k) out[(((k / 9) % 8) < 4 ? 0 : 9) + k % 9] += (double)h[k];
-    RIP_HIP(ctx, hipMemset(ctx->chain_dbg_buf, 0, n * 8));
-    return RIP_OK;
-}
-
 // same buffer, per wave of a workgroup of nw waves: out[w * 9 + i] (diagnostic builds; tools/gpu_checks/stamp_roles.py)
 extern "C" int rip_chain_stamps_n(rip_ctx *ctx, int nw, double *out) {
     const size_t n = 4096 * 9;

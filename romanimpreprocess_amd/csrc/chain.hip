@@ -1,4 +1,4 @@
-// Dispatch of the fused chain kernels (chain2_kernel.h, chain3_kernel.h; instantiated per Legendre order in chain*_np*.hip).
+// Dispatch of the fused chain kernel (chain2_kernel.h; instantiated per Legendre order in chain_np*.hip).
 #include "rip_common.h"
 
 int rip_launch_chain_np4(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int k_dtype);
@@ -14,25 +14,8 @@ bool rip_chain_supported(const rip_ctx *ctx, int nplanes, int G, int k_dtype, in
     return true;
 }
 
-int rip_launch_chain3_k64_np4(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a);
-int rip_launch_chain3_k64_np9(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a);
-int rip_launch_chain3_k64_np11(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a);
-
 // returns the launch status, or 1 when no fused kernel fits this plan / CALDIR set (the caller then takes the stage kernels)
 int rip_launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int nplanes, int k_dtype) {
-    // f64 ipc4d x 16 groups: the wave-private kernel (chain3_kernel.h), the only specialised instantiation for it (the rings of
-    // such a ramp do not fit the wave-specialised kernel's workgroup); 1 = no instantiation for this plan.
-    // (merged_dq < 0: the flag words of this CALDIR set cannot be merged, RipCal -- the specialised kernels are not taken)
-    if (a.ngrp == 16 && k_dtype == RIP_F64 && a.merged_dq >= 0) {
-        int rc = 1;
-        if (nplanes == 4) rc = rip_launch_chain3_k64_np4(ctx, plan, a);
-        if (nplanes == 9) rc = rip_launch_chain3_k64_np9(ctx, plan, a);
-        if (nplanes == 11) rc = rip_launch_chain3_k64_np11(ctx, plan, a);
-        if (rc != 1) {
-            ctx->last_form = 3;
-            return rc;
-        }
-    }
     switch (nplanes) {
         case 4:
             return rip_launch_chain_np4(ctx, plan, a, k_dtype);

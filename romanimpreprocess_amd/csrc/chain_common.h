@@ -1,4 +1,4 @@
-// Shared pieces of the fused L1->L2 kernels (chain2_kernel.h, chain3_kernel.h): packed-pair arithmetic, the exact short forms of
+// Shared pieces of the fused L1->L2 kernel (chain2_kernel.h): packed-pair arithmetic, the exact short forms of
 // division, the forward IPC operator on LDS rows, the registers of a prefetched row, the diagnostic stamps.
 //
 // The fused kernels replace gen_cal_image.py:533-629 between the reference-pixel tables (refpix.hip) and the L2 planes: reference-

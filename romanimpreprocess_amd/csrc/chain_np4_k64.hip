@@ -10,5 +10,6 @@
 int rip_launch_chain2_k64_np4(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
     if (a.ngrp == 8) return launch_chain2<4, 8, double, C2_K64_NARROW>(ctx, plan, a);
     if (a.ngrp == 6) return launch_chain2<4, 6, double, C2_K64_NARROW>(ctx, plan, a);
+    if (a.ngrp == 16) return launch_chain2<4, 16, double, 2>(ctx, plan, a);   // (two 128-column workgroups per CU: 76 KB each)
     return 1;
 }

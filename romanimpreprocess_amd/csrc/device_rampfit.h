@@ -376,40 +376,13 @@ struct RipFitState {
     bool live;                 // wave-uniform: some lane of the wave keeps jump flags
 };
 
-// where the first half reads the dense per-plan table from: the device copy through scalar loads (RipDenseK), or a copy the
-// kernel staged in LDS (chain3_kernel.h: LDS reads return in order and need no scalar registers)
+// where the first half reads the dense per-plan table from: the device copy through scalar loads
 struct RipDenseK {
     const RipDense *dn;
     __device__ __forceinline__ float k2(int t) const { return KLD(dn->K2[t]); }
     __device__ __forceinline__ uint32_t valid() const { return KLD(dn->valid); }
     __device__ __forceinline__ float amin() const { return KLD(dn->amin); }
     __device__ __forceinline__ void pair(RipDensePair &r, int ps) const { rip_load_pair(r, dn, ps); }
-};
-
-// the dense fit table of the plan, staged in LDS by the fused kernels (chain2_kernel.h, chain3_kernel.h): LDS reads return in order, so every
-// wait for a table entry is a counted one, and they take no scalar registers
-#define C3_MAXG 16  // the kernel is instantiated for at most 16 groups
-struct __attribute__((aligned(16))) C3FitTab {
-    float k2[C3_MAXG];
-    RipDensePair pairs[C3_MAXG];
-    float amin;
-    uint32_t valid;
-    float pad_[2];
-};
-template <int G>
-struct C3DenseLds {
-    const C3FitTab *t;
-    float k2v[G];  // the slope weights: loop-invariant scalars, read once before the row loop
-    __device__ __forceinline__ float k2(int i) const { return k2v[i]; }
-    __device__ __forceinline__ uint32_t valid() const { return t->valid; }
-    __device__ __forceinline__ float amin() const { return t->amin; }
-    __device__ __forceinline__ void pair(RipDensePair &r, int ps) const {
-        typedef float f4_ __attribute__((ext_vector_type(4)));
-        const f4_ *p = reinterpret_cast<const f4_ *>(&t->pairs[ps]);  // 32 B, 16-byte aligned in C3FitTab
-        const f4_ a = p[0], b = p[1];
-        r.inv_dt[0] = a[0], r.inv_dt[1] = a[1], r.A[0] = a[2], r.A[1] = a[3];
-        r.B[0] = b[0], r.B[1] = b[1], r.k1[0] = b[2], r.k1[1] = b[3];
-    }
 };
 
 // first half: slope, errors, threshold, approximate significance of every tested difference

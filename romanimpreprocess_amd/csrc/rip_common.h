@@ -126,12 +126,11 @@ struct rip_ctx {
     int parity = 0;
     bool use_overlap = true;
     bool use_chain2 = true;  // wave-specialised fused kernel where it applies
-    // (option "chain3" of rounds 1-2: the wave-private fused kernel, chain3_kernel.h, is instantiated for f64 ipc4d x 16 groups only
-    // since round 3 -- with its f64 chains batched the wave-specialised kernel is the faster one everywhere else: 1.340 against
-    // 1.376 ms for f64 ipc4d x 8 groups, 0.85 against 0.95 ms for f32, same box, profiles/r03_summary.md -- and is taken there
-    // whatever the option says; the option is still accepted)
+    // (option "chain3" of rounds 1-2, still accepted, without effect: the wave-private fused kernel was removed in round 3 -- the
+    // wave-specialised kernel is the faster one in every configuration: 0.85 against 0.95 ms for f32, 1.17 against 1.38 ms for f64
+    // ipc4d, 2.47 against 3.45 ms for f64 ipc4d x 16 groups, profiles/r03_summary.md)
     int use_chain3 = 2;
-    int last_form = 0;       // diagnostic: how the last rip_calibrate ran (0 stage kernels, 2 wave-specialised, 3 wave-private; 1 was the general fused kernel of rounds 1-2)
+    int last_form = 0;       // diagnostic: how the last rip_calibrate ran (0 stage kernels, 2 the fused kernel; 1 and 3 were the general and the wave-private fused kernels of rounds 1-2)
     std::string err;
     std::vector<RipCal> cals;
     std::vector<RipPlan *> plans;
@@ -160,10 +159,8 @@ struct rip_ctx {
     // the pre-pass / saturation pass share workspaces (selection histograms, row tables in the making, exceed bits): when two
     // consecutive calls run them on different streams (a non-overlapped call between overlapped ones), the later waits for the
     // earlier through this event
-    // launch geometry of the fused kernels, per CONTEXT (a second context may sit on another device): CU count, and per
-    // kernel instantiation the resident workgroups per CU (0 = not asked yet; asking also opts into > 48 KB of dynamic LDS)
+    // launch geometry of the fused kernel, per CONTEXT (a second context may sit on another device): CU count
     int ncu = 0;
-    std::map<const void *, int> wg_per_cu;
     // 1/f frames made AHEAD on the second stream (rip_synth_frames_ahead, pink.hip) for the next rip_synth_fill: the transforms
     // (HBM-bound) then run beside the apportioning and the inverse-linearity kernels (arithmetic-bound) of the same exposure
     hipEvent_t ev_frames = nullptr, ev_fill = nullptr;

@@ -204,13 +204,12 @@ def test_calibrateimage_files_end_to_end(tmp_path):
         gen_cal_image.calibrateimage(dict(config, romancal_ramp_fit=True), verbose=False)
 
 
-# ---- the specialised fused kernels (wave-specialised chain2_kernel.h; wave-private chain3_kernel.h for f64 ipc4d x 16 groups):
-# every instantiation the dispatcher can pick, and the seams between their column strips / row ranges
+# ---- the fused kernel (chain2_kernel.h): every instantiation the dispatcher can pick (256-column form, narrow forms), and the
+# seams between their column strips / row ranges
 
 
 def _set_form(ctx, form):
-    """2: the fused kernel of the configuration (it reports 3 where that is the wave-private one: f64 ipc4d x 16 groups),
-    0: stage kernels"""
+    """2: the fused kernel, 0: stage kernels"""
     ctx.set_option("fused", 1 if form else 0)
     ctx.set_option("chain2", 1 if form >= 2 else 0)
 
@@ -235,7 +234,7 @@ SPECIALISED = [
     ("g8_np11_start0_k64", (40, 256), synth.READ_PATTERN_8, 10, False, np.float64),
     ("g6_np4_start1_k64", (48, 128), synth.READ_PATTERN_6, 3, True, np.float64),
     ("g6_np9_start0_k64", (40, 256), synth.READ_PATTERN_6, 8, False, np.float64),
-    # f64 ipc4d x 16 groups: the wave-private kernel
+    # f64 ipc4d x 16 groups (narrow form, two workgroups per CU)
     ("g16_np9_start1_k64", (40, 256), synth.READ_PATTERN_16, 8, True, np.float64),
     ("g16_np11_start0_k64", (32, 256), synth.READ_PATTERN_16, 10, False, np.float64),
 ]
@@ -244,7 +243,7 @@ SPECIALISED = [
 @pytest.mark.parametrize("name,shape,rp,p,exclude_first,kdt", SPECIALISED)
 def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first, kdt):
     ny, nx = shape
-    form = 3 if (len(rp) == 16 and kdt is np.float64) else 2
+    form = 2
     ctx = gpu_context()
     _set_form(ctx, 2)
     cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=p, seed=91, bias_amplitude=2.0, bad_lin_frac=0.01,

@@ -104,5 +104,5 @@ for case in range(ncases):
 ctx.set_option("fused", 1)
 ctx.set_option("chain2", 1)
 ctx.set_option("chain3", 2)
-print(f"done: {ncases} cases, {fails} mismatches; kernel forms used (0 stage, 2 wave-specialised, 3 wave-private): {forms}")
+print(f"done: {ncases} cases, {fails} mismatches; kernel forms used (0 stage kernels, 2 fused kernel): {forms}")
 sys.exit(1 if fails else 0)
