@@ -66,6 +66,9 @@
 #ifndef C2_PBW
 #define C2_PBW -1
 #endif
+#ifndef C2_PBC   // f64 ipc4d: pairs the first iterate evaluates in lockstep (-1: per instantiation)
+#define C2_PBC -1
+#endif
 #ifndef C2_KFIT_EARLY   // narrow form: the fit role requests its coefficients at the end of the step before (1) or at the top of the step (0)
 #define C2_KFIT_EARLY 1
 #endif
@@ -720,7 +723,8 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), (NARROW ? ((G > 8
                 }
                 if constexpr (K64) {
                     // two pairs (four groups) in lockstep: their 18 ring reads first, then four interleaved f64 chains
-                    constexpr int PBC = (GP % 2 == 0 && !NARROW) ? 2 : 1;   // (narrow form: 168 registers -- one pair at a time)
+                    constexpr bool BIG = !NARROW || (K64 && G > 8);   // 256-register budget (narrow f64 x 8 groups: 168 -- one pair at a time)
+                    constexpr int PBC = (C2_PBC > 0) ? C2_PBC : ((GP % 2 == 0 && BIG) ? 2 : 1);
 #pragma unroll
                     for (int p0 = 0; p0 < GP; p0 += PBC) {
 #pragma unroll
@@ -971,7 +975,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), (NARROW ? ((G > 8
                     // f64 iterate: (O1 + x) - fwd(O1) and the division by the gain in f64, one rounding to f32 at the end; C2_NBO groups in
                     // lockstep (their ring reads, then interleaved chains), the divisions together at the end.  Lanes that are not
                     // active (border pixels) evaluate on whatever the rings hold there and keep x.
-                    constexpr int NBO = (G % C2_NBO == 0) ? C2_NBO : 2;
+                    constexpr int NBO = (G > 8 && C2_NBO == 2) ? 4 : ((G % C2_NBO == 0) ? C2_NBO : 2);   // (16 groups: 256 registers, four in lockstep)
                     double o2v[G];
 #pragma unroll
                     for (int gb = 0; gb < G; gb += NBO) {
