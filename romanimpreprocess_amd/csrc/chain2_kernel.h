@@ -231,11 +231,16 @@ __device__ __forceinline__ void c2_div64_shared(const double (&a)[NG], float bf,
     }
 }
 
+// waves per SIMD an instantiation is compiled for (register budget 512 / waves) and launched with
+constexpr int c2_wps(int G, bool k64, int narrow) {
+    return !narrow ? ((G > 8 || k64) ? 2 : 4) : ((k64 && G > 8) ? 2 : ((k64 || G > 8) ? 3 : 4));
+}
+
 // NARROW = 1, the narrow form (f64 ipc4d): a workgroup of 256 threads on a 128-column window WITHOUT the K ring (the fit role loads
 // the nine coefficients itself: the second read of a line the ingest role fetched two steps earlier) -- 43 KB of LDS instead of
 // 120 KB, so that a CU holds THREE workgroups = 12 waves = 3 waves/SIMD at <= 168 VGPRs where the 256-column form has 2.
 template <int NP, int G, int START, typename KT = float, int NARROW = 0>
-__global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), (NARROW ? ((G > 8 && sizeof(KT) == 8) ? 2 : 3) : ((G > 8 || sizeof(KT) == 8) ? 2 : 4))) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
+__global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(KT) == 8, NARROW)) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
                                                                const RipVariant *__restrict__ vars,
                                                                const float *__restrict__ kvals,
                                                                const RipDiff *__restrict__ diffs, double guard) {
@@ -1150,7 +1155,7 @@ static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
     // 4 waves/SIMD at <= 128 VGPRs (2 at 256 for G = 16 / f64; 3 at 168 in the narrow form)
-    const int max_wg = (NARROW ? ((G > 8 && sizeof(KT) == 8) ? 8 : 12) : ((G > 8 || sizeof(KT) == 8) ? 8 : 16)) / (C2_THREADS / 64);
+    const int max_wg = 4 * c2_wps(G, sizeof(KT) == 8, NARROW) / (C2_THREADS / 64);
     if (per_cu > max_wg) per_cu = max_wg;
     if (a.nb < 2) return 1;   // (the frame-edge lanes of the first / last strip emit without neighbours: border pixels)
     const int nstrips = C2_NSTRIPS(a.nx);
