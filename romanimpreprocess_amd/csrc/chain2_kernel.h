@@ -69,7 +69,10 @@
 #ifndef C2_PBC   // f64 ipc4d: pairs the first iterate evaluates in lockstep (-1: per instantiation)
 #define C2_PBC -1
 #endif
-#ifndef C2_KFIT_EARLY   // narrow form: the fit role requests its coefficients at the end of the step before (1) or at the top of the step (0)
+// narrow forms: the fit role requests its coefficients at the top of the step (0), at the end of the step before (1), or two steps
+// ahead -- half a step after the ingest role's read of the same lines (2: fabric traffic 1.44 -> 1.19 x (f64), 1.50 -> 1.39 x (16
+// groups), 1.38 -> 1.27 x (both), and the kernels 3 % / 0 % / 10 % SLOWER: nine to eighteen more live registers; not bound by bytes)
+#ifndef C2_KFIT_EARLY
 #define C2_KFIT_EARLY 1
 #endif
 #ifndef C2_NBO   // f64 ipc4d: groups the second iterate evaluates in lockstep (2 or 4)
@@ -806,6 +809,12 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
         uint32_t qb_next[WRING ? 1 : G];   // NARROW = 2: the raw groupdq bytes of the next step's pixel
 #pragma unroll
         for (int g = 0; g < (WRING ? 1 : G); ++g) qb_next[g] = 0;
+        f2 kn2[5];      // (C2_KFIT_EARLY == 2: those of the row after)
+        double kn2_d[9];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) kn2[i] = f2{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) kn2_d[k] = 0.0;
         f2 kn[5];       // narrow form: the coefficients of the next step's row (C2_KFIT_EARLY)
         double kn_d[9];
 #pragma unroll
@@ -936,11 +945,17 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
             double kFd[9];
             kF[4].y = 0.0f;
             if constexpr (!KRING) {
-#if C2_KFIT_EARLY   // requested at the end of the step before (they land across the barrier)
+#if C2_KFIT_EARLY   // requested at the end of the step before (they land across the barrier); 2: two steps before
 #pragma unroll
                 for (int k = 0; k < 9; ++k) kFd[k] = kn_d[k];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) kF[i] = kn[i];
+#if C2_KFIT_EARLY == 2
+#pragma unroll
+                for (int k = 0; k < 9; ++k) kn_d[k] = kn2_d[k];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) kn[i] = kn2[i];
+#endif
 #else
                 if constexpr (K64)
                     (void)load_kd(C2Last{}, kf->a.kern, r, true, kFd);
@@ -1120,7 +1135,14 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
                     gain_next = c2_ld_f32<C2_NT_F>(c2_rsrc(kg->a.planes), cc4, (unsigned)(NP + 4) * pl4 + yl * row4);
                 }
             }
-#if C2_KFIT_EARLY
+#if C2_KFIT_EARLY == 2   // (row r + 2: the lines the ingest role fetched half a step ago)
+            if constexpr (!KRING) {
+                if constexpr (K64)
+                    (void)load_kd(C2Last{}, kg->a.kern, r + 2, true, kn2_d);
+                else
+                    (void)load_k(C2Last{}, kg->a.kern, r + 2, true, kn2);
+            }
+#elif C2_KFIT_EARLY
             if constexpr (!KRING) {
                 if constexpr (K64)
                     (void)load_kd(C2Last{}, kg->a.kern, r + 1, true, kn_d);
