@@ -1,4 +1,4 @@
-// Fused L1->L2 kernel, wave-specialised form (f32 gain; f32 ipc4d with 6, 8 or 16 groups, f64 ipc4d with 6 or 8): one launch per
+// The fused L1->L2 kernel (f32 gain; f32 or f64 ipc4d; 6, 8 or 16 groups), wave-specialised: one launch per
 // ramp does reference-pixel apply + bias + Legendre linearity + IPC deconvolution + ramp fit / jump detection / flag propagation
 // + dark rate + error split + flat (gen_cal_image.py:533-629; stage arithmetic and reference lines as in linearity.hip, ipc.hip,
 // rampfit.hip), every array read from HBM once.
@@ -12,8 +12,9 @@
 //     fit waves    (tid >= 256)  O2: second iterate of row r / gain (reads O1 rows r-1..r+1, x of its own column)
 //                                F: ramp fit with jump detection and saturated refits of pixel (r, c)
 //                                T: flag propagation, finish (dark rate, error split, flat), stores of pixel (r, c)
-// so each role needs <= 128 VGPRs and a CU holds 2 workgroups = 16 waves = 4 waves/SIMD (16 groups and f64 ipc4d: the rings
-// allow one workgroup per CU, 2 waves/SIMD at <= 256 VGPRs).  Per step:
+// so each role needs <= 128 VGPRs and a CU holds 2 workgroups = 16 waves = 4 waves/SIMD.  That is the 256-column form (f32 ipc4d
+// with 6 / 8 groups, the bench path); 16 groups and f64 ipc4d, whose rings would leave one such workgroup per CU or none, run the
+// NARROW forms (128-column workgroups that drop rings; see the template below).  Per step:
 //     S1: ingest A(r+3)   | fit O2(r), F(r) up to the half-step barrier (C2_BAR)       -- barrier --
 //     S2: ingest C(r+2)   | fit: the rest of F(r) and T(r), the ring words of row r+1  -- barrier --
 // Everything after O2 is register-only in a fit thread, so the half-step barrier can fall anywhere in it (C2_BAR, chosen per
@@ -239,9 +240,13 @@ constexpr int c2_wps(int G, bool k64, int narrow) {
     return !narrow ? ((G > 8 || k64) ? 2 : 4) : ((k64 && G > 8) ? 2 : ((k64 || G > 8) ? 3 : 4));
 }
 
-// NARROW = 1, the narrow form (f64 ipc4d): a workgroup of 256 threads on a 128-column window WITHOUT the K ring (the fit role loads
-// the nine coefficients itself: the second read of a line the ingest role fetched two steps earlier) -- 43 KB of LDS instead of
-// 120 KB, so that a CU holds THREE workgroups = 12 waves = 3 waves/SIMD at <= 168 VGPRs where the 256-column form has 2.
+// NARROW forms: a workgroup of 256 threads (two waves per role) on a 128-column window that drops rings, so that more workgroups
+// fit a CU; what the dropped ring carried, the fit role loads itself one step ahead (a second read of lines the ingest role
+// fetched 1.5 steps earlier: more fabric traffic, more waves -- these configurations are bound by waves per SIMD):
+//   NARROW = 1  no K ring                              f64 ipc4d x 6 / 8 groups: 43 KB (120 KB), 3 workgroups per CU, <= 168 VGPRs
+//   NARROW = 2  no K ring, no gain / groupdq rings     16 groups: 51 KB (132 KB), 3 per CU; f64 ipc4d x 16 groups: 76 KB (180 KB:
+//                                                      did not fit), 2 per CU at <= 256 VGPRs
+// Same arithmetic, same bits as the 256-column form.  For f32 ipc4d x 8 groups the narrow forms are slower (same 16 waves per CU).
 template <int NP, int G, int START, typename KT = float, int NARROW = 0>
 __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(KT) == 8, NARROW)) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
                                                                const RipVariant *__restrict__ vars,
