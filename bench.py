@@ -41,6 +41,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+PROFILE_EVERY = int(os.environ.get("BENCH_PROFILE_EVERY", "1"))   # 0: no events at all (kernel times then read 0)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
@@ -266,15 +267,22 @@ def run_steps(cb, calls, warmup, steps, fence, ramp_s=0.0):
     for i in range(warmup):
         calls[i % n]()
     fence()
-    cb.ctx.profile(True)
+    # HIP events round the kernels of every PROFILE_EVERY-th step of the timed region (each recorded event is a packet the
+    # command processor has to work through between two kernels: with events round every kernel of every call the event
+    # traffic itself costs wall time)
+    cb.ctx.profile(False)
     cb.ctx.profile_read()
     t0 = time.perf_counter()
     for i in range(steps):
-        calls[(warmup + i) % n]()
+        if PROFILE_EVERY and i % PROFILE_EVERY == 0:
+            cb.ctx.profile(True)
+            calls[(warmup + i) % n]()
+            cb.ctx.profile(False)
+        else:
+            calls[(warmup + i) % n]()
     fence()
     elapsed = time.perf_counter() - t0
     ms, ncalls = cb.ctx.profile_read()
-    cb.ctx.profile(False)
     return elapsed, ms, ncalls
 
 
@@ -356,6 +364,8 @@ def main():
                     help="dtype of the ipc4d coefficients (the reference's production writer stores f64)")
     ap.add_argument("--p-order", type=int, default=8, choices=(3, 8, 10), help="Legendre order of the linearity file")
     ap.add_argument("--tiled", action="store_true", help="the round-1 input: a 128-row strip repeated down the frame (numpy)")
+    ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE",
+                    help="rip_set_option before the run (A/B timing: overlap=0, prepass_one=0, ...)")
     ap.add_argument("--chain3", type=int, default=None, choices=(0, 1),
                     help="(rounds 1-2: A/B switch of the wave-private fused kernel, removed in round 3; accepted, without effect)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -413,6 +423,9 @@ def main():
     cb = pipeline.Calibrator(device=local_rank)
     if args.chain3 is not None:
         cb.ctx.set_option("chain3", args.chain3)
+    for kv in args.set:
+        k_, v_ = kv.split("=")
+        cb.ctx.set_option(k_, int(v_))
 
     def fence():
         cb.synchronize()

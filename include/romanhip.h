@@ -245,6 +245,16 @@ int rip_stage_refpix_row(rip_ctx *ctx, float *image, int ny, int width, int nsid
 int rip_stage_refpix_channel(rip_ctx *ctx, float *image, int ny, int width, int channel_start, int channel_end, int nchan,
                              const double *lines, float *bottom_top);
 
+/* The reference-pixel TABLES the chain applies to a ramp (gen_cal_image.py:531-556 through reference_subtraction.py:16-125,
+   with the reference output: use_ref_channel=True, slope given), from host arrays: data (ngrp,ny,nx) u16|f32, dark (>= ngrp,ny,nx)
+   f32, amp33 (ngrp,ny,128) u16, amp33_med (ny,128) f32 -> rowcorr (ngrp,ny) f64 = slope * f64(f32(row median - ctr)) and
+   lines (ngrp,nx/128,2) f64 = (m, c) of the science channels.  form: 1 = the single-launch kernel (refpix_one.hip; frames up to
+   4096 rows), 0 = the multi-launch kernels (refpix.hip), -1 = what rip_calibrate takes (option "prepass_one").  Both forms give
+   identical bits.  status out (may be NULL): != 0 when a group barrier of the single-launch kernel timed out. */
+int rip_stage_refpix_tables(rip_ctx *ctx, const void *data, int data_dtype, const float *dark, const uint16_t *amp33,
+                            const float *amp33_med, double slope, int ngrp, int ny, int nx, int form, double *rowcorr,
+                            double *lines, int *status);
+
 /* ipc_linearity.multilin: S (ngrp,ny,nx) f32 -> phi (ngrp,ny,nx) f32, dq (ny,nx) u32.
    attempt_corr (ngrp,ny,nx) u8 nonzero = flag when extrapolated, or NULL = all. */
 int rip_stage_multilin(rip_ctx *ctx, const float *S, int ngrp, int ny, int nx, int nplanes, const float *coefs,
@@ -394,6 +404,8 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value);
                 (rounds 1-2: a general fused kernel, dropped in round 3);
    "chain3"  -- accepted, without effect since round 3 (the wave-private fused kernel of round 2 was removed: the wave-specialised
                 kernel is the faster one in every configuration);
+   "prepass_one" -- (default 1) the reference-pixel tables by ONE launch (refpix_one.hip) where it covers the frame; 0 = the
+                multi-launch kernels of refpix.hip;
    "overlap" -- run the reference-pixel pre-pass of a ramp on a second stream so that it overlaps the previous ramp's
                 fused kernel. */
 

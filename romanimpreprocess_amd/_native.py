@@ -105,6 +105,7 @@ SYMBOLS = {
     "rip_stage_refpix_image": (_I, [_VP, _VP, _I, _I, C.c_double, _I, _I, _VP, _VP, _VP, _VP]),
     "rip_stage_refpix_row": (_I, [_VP, _VP, _I, _I, _I, _I, _I, C.c_double, _VP, _VP, _VP]),
     "rip_stage_refpix_channel": (_I, [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP]),
+    "rip_stage_refpix_tables": (_I, [_VP, _VP, _I, _VP, _VP, _VP, C.c_double, _I, _I, _I, _I, _VP, _VP, _VP]),
     "rip_synth_frames_ahead": (_I, [_VP, _I, _I, _I, C.c_uint64]),
     "rip_stage_jump_detect": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "rip_stage_multilin": (_I, [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP]),

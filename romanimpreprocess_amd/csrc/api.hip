@@ -149,6 +149,7 @@ void rip_ctx_destroy(rip_ctx *ctx) {
     for (void *p : ctx->batch_buf)
         if (p) (void)hipFree(p);
     if (ctx->chain_dbg_buf) (void)hipFree(ctx->chain_dbg_buf);
+    if (ctx->prepass_stamps) (void)hipFree(ctx->prepass_stamps);
     if (ctx->stream3) {
         (void)hipStreamSynchronize(ctx->stream3);
         (void)hipStreamDestroy(ctx->stream3);
@@ -205,6 +206,14 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value) {
         ctx->use_chain3 = (value < 0 || value > 2) ? 2 : value;
         return RIP_OK;
     }
+    if (name && strcmp(name, "chain_reserve") == 0) {
+        ctx->chain_reserve = value < 0 ? 0 : value;
+        return RIP_OK;
+    }
+    if (name && strcmp(name, "prepass_one") == 0) {
+        ctx->prepass_one = value != 0;
+        return RIP_OK;
+    }
     if (name && strcmp(name, "overlap") == 0) {
         ctx->use_overlap = value != 0 && ctx->stream2 != nullptr;
         return RIP_OK;
@@ -244,6 +253,21 @@ extern "C" int rip_chain_stamps_n(rip_ctx *ctx, int nw, double *out) {
     RIP_HIP(ctx, hipMemcpy(h.data(), ctx->chain_dbg_buf, n * 8, hipMemcpyDeviceToHost));
     for (size_t k = 0; k < n; ++k) out[((k / 9) % (size_t)nw) * 9 + k % 9] += (double)h[k];
     RIP_HIP(ctx, hipMemset(ctx->chain_dbg_buf, 0, n * 8));
+    return RIP_OK;
+}
+
+// diagnostic (tools/gpu_checks/prepass_stamps.py): clock stamps of the single-launch pre-pass, 16 per workgroup; the first call
+// switches them on (out may be NULL), later calls copy the last launch's stamps out (nwg workgroups)
+extern "C" int rip_prepass_stamps(rip_ctx *ctx, int nwg, unsigned long long *out) {
+    const size_t bytes = (size_t)4096 * 16 * 8;
+    if (!ctx->prepass_stamps) {
+        RIP_HIP(ctx, hipMalloc(&ctx->prepass_stamps, bytes));
+        RIP_HIP(ctx, hipMemset(ctx->prepass_stamps, 0, bytes));
+    }
+    if (out && nwg > 0 && nwg <= 4096) {
+        RIP_HIP(ctx, rip_synchronize(ctx) ? hipErrorUnknown : hipSuccess);
+        RIP_HIP(ctx, hipMemcpy(out, ctx->prepass_stamps, (size_t)nwg * 16 * 8, hipMemcpyDeviceToHost));
+    }
     return RIP_OK;
 }
 
@@ -1071,6 +1095,38 @@ int rip_stage_refpix_channel(rip_ctx *ctx, float *image, int ny, int width, int 
     RIP_HIP(ctx, hipMemcpyAsync(image, img.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (bottom_top) RIP_HIP(ctx, hipMemcpyAsync(bottom_top, bt.p, (size_t)nchan * 8, hipMemcpyDeviceToHost, ctx->stream));
     RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RIP_OK;
+}
+
+int rip_stage_refpix_tables(rip_ctx *ctx, const void *data, int data_dtype, const float *dark, const uint16_t *amp33,
+                            const float *amp33_med, double slope, int ngrp, int ny, int nx, int form, double *rowcorr,
+                            double *lines, int *status) {
+    RIP_HIP(ctx, hipSetDevice(ctx->device));
+    if (!data || !dark || !amp33 || !amp33_med || !rowcorr || !lines || ngrp < 1 || ngrp > RIP_MAX_GROUPS || ny < 8 || nx < RIP_CW ||
+        nx % RIP_CW || (data_dtype != RIP_U16 && data_dtype != RIP_F32))
+        return rip_fail(ctx, RIP_EINVAL, "refpix tables: bad argument");
+    const size_t npix = (size_t)ny * nx, nch = (size_t)nx / RIP_CW;
+    DevBuf d_data, d_dark, d_a33, d_med, d_rc, d_rt, d_ln;
+    int rc;
+    if ((rc = d_data.upload(ctx, data, (size_t)ngrp * npix * dsize(data_dtype))) || (rc = d_dark.upload(ctx, dark, (size_t)ngrp * npix * 4)) ||
+        (rc = d_a33.upload(ctx, amp33, (size_t)ngrp * ny * RIP_CW * 2)) || (rc = d_med.upload(ctx, amp33_med, (size_t)ny * RIP_CW * 4)) ||
+        (rc = d_rc.alloc(ctx, (size_t)ngrp * ny * 8)) || (rc = d_rt.alloc(ctx, (size_t)ngrp * ny * 8)) || (rc = d_ln.alloc(ctx, (size_t)ngrp * nch * 16)))
+        return rc;
+    RefpixArgs ra{d_data.p, data_dtype, d_dark.as<float>(), d_a33.as<uint16_t>(), d_med.as<float>(), slope, nullptr,
+                  d_rc.as<double>(), d_rt.as<double>(), d_ln.as<double>(), ny, nx, ngrp};
+    const bool keep = ctx->prepass_one;
+    if (form >= 0) ctx->prepass_one = form != 0;
+    if (form == 1 && !rip_refpix_one_supported(ra)) {
+        ctx->prepass_one = keep;
+        return rip_fail(ctx, RIP_EINVAL, "refpix tables: the single-launch kernel does not cover a %d x %d frame of %d groups", ny, nx, ngrp);
+    }
+    rc = rip_launch_refpix_prepass(ctx, ra);
+    ctx->prepass_one = keep;
+    if (rc) return rc;
+    RIP_HIP(ctx, hipMemcpyAsync(rowcorr, d_rc.p, (size_t)ngrp * ny * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipMemcpyAsync(lines, d_ln.p, (size_t)ngrp * nch * 16, hipMemcpyDeviceToHost, ctx->stream));
+    RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (status) return rip_refpix_one_status(ctx, status);
     return RIP_OK;
 }
 

@@ -307,14 +307,21 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
     }
 
     const int nstrips = C2_NSTRIPS(nx);
-    const int nranges = gridDim.x / nstrips;
-    const int rows_per = (ny + nranges - 1) / nranges;
     const int bid = c2_xcd_block((int)blockIdx.x, (int)gridDim.x);
-    const int strip = bid % nstrips;
-    const int R0 = (bid / nstrips) * rows_per;
-    const int R1 = min(ny, R0 + rows_per);
-    if (bid >= nstrips * nranges || R0 >= ny) return;
-    const int c = strip * C2_OUTW + col;
+    // (strip, row range) of this workgroup -- in QUAD mode (the last strip, when it has at most 64 live columns) of each of its four
+    // (narrow forms: two) wave columns: 64-column windows (2 + 2 halo lanes each) of the same strip that march down four different row ranges, so that
+    // a strip a quarter as wide takes a quarter of the workgroups (launcher: chain2_geometry)
+    const int nfull = a.geo_rows_q ? nstrips - 1 : nstrips;
+    const bool quad = bid >= nfull * a.geo_nr;
+    const int rows_wg = quad ? a.geo_rows_q : a.geo_rows;   // steps of every wave of the workgroup (barriers inside)
+    const int strip = quad ? nfull : bid % nfull;
+    const int wcol = quad ? (col & 63) : col;               // column inside the wave column's window
+    const int wl = quad ? 64 : C2_COLS;                     // ... and its width
+    const int R0 = min(ny, quad ? ((bid - nfull * a.geo_nr) * (C2_COLS / 64) + __builtin_amdgcn_readfirstlane(col >> 6)) * rows_wg
+                                : (bid / nfull) * rows_wg);
+    const int R1 = min(ny, R0 + rows_wg);
+    if (bid >= nfull * a.geo_nr + a.geo_nq) return;
+    const int c = strip * C2_OUTW + wcol;
     const bool col_ok = (c >= 0 && c < nx);
     const bool col_act = (c >= ax0 && c < ax1);
     const int cc = col_ok ? c : 0;
@@ -347,8 +354,8 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
         }
         if (!col_act) colmask = 0;
     }
-    const unsigned lane_mask = fit_role ? ((col >= 2 && col < C2_COLS - 2) ? colmask : 0u)
-                                        : ((col >= 1 && col < C2_COLS - 1) ? colmask : 0u);
+    const unsigned lane_mask = fit_role ? ((wcol >= 2 && wcol < wl - 2) ? colmask : 0u)
+                                        : ((wcol >= 1 && wcol < wl - 1) ? colmask : 0u);
     const unsigned row4 = (unsigned)nx * 4u;  // row pitch of an f32/u32 plane; offsets within a plane fit 32 bits
     // rows this (strip, row range) cell really uses: R0-2 .. R1+1 (two halo rows on each side).  The straight-line loads of the
     // warm-up and drain steps are clamped INTO that band, so that they touch lines the cell reads anyway instead of 3-5 rows of
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
 #pragma unroll
             for (int g = 0; g < G; ++g) rcn[g] = rt[g];
         }
-        for (int r = R0 - 5; r <= R1; ++r, so_c = (so_c == 2) ? 0 : so_c + 1) {
+        for (int r = R0 - 5; r <= R0 + rows_wg; ++r, so_c = (so_c == 2) ? 0 : so_c + 1) {
             const RIP_K ChainArgs *ka = &c2_args(kargs)->a;  // S1 copy of the argument block
             const int yi = r + 3, yc = r + 2;
             const bool do_a = (yi >= R0 - 2) && (yi <= R1 + 1);
@@ -534,9 +541,9 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
             kC[4].y = 0.0f;
             unsigned vC;
             if constexpr (K64)
-                vC = load_kd(C2Keep{}, ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kCd);
+                vC = load_kd(C2Keep{}, ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kCd);
             else
-                vC = load_k(C2Keep{}, ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
+                vC = load_k(C2Keep{}, ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kC);
 #endif
             const bool a_full = do_a && yi >= 0 && yi < ny;  // wave-uniform
             // A: two pairs of groups at a time -- reference-pixel/bias arithmetic and z of both pairs, then their two
@@ -706,9 +713,9 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
             kC[4].y = 0.0f;
             unsigned vC;
             if constexpr (K64)
-                vC = load_kd(C2Keep{}, ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kCd);
+                vC = load_kd(C2Keep{}, ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kCd);
             else
-                vC = load_k(C2Keep{}, ka->kern, yc, do_c && col >= 1 && col < C2_COLS - 1, kC);
+                vC = load_k(C2Keep{}, ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kC);
 #endif
             CH_T(2)
             C2_SYNC();
@@ -826,8 +833,8 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
         for (int i = 0; i < 5; ++i) kn[i] = f2{0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < 9; ++k) kn_d[k] = 0.0;
-        for (int r = R0 - 5; r <= R1; ++r, o0_r = (o0_r == 2) ? 0 : o0_r + 1) {
-            const bool emit = (r >= R0) && (r < R1) && col_ok && (col >= 2 || c < 2) && (col < C2_COLS - 2 || c >= nx - 2);
+        for (int r = R0 - 5; r <= R0 + rows_wg; ++r, o0_r = (o0_r == 2) ? 0 : o0_r + 1) {
+            const bool emit = (r >= R0) && (r < R1) && col_ok && (wcol >= 2 || c < 2) && (wcol < wl - 2 || c >= nx - 2);
             const RIP_K C2KernArgs *kf = c2_args(kargs);  // S1 copy of the argument block
             const unsigned rc_ = (unsigned)min(max(r, R0), yhi);   // (rows before R0 are warm-up steps: nothing is emitted there)
             const unsigned pe = rc_ * (unsigned)nx + cc1;
@@ -1174,6 +1181,40 @@ static inline size_t chain2_lds_bytes(int G, size_t ksize = 4, int cols = C2_COL
            (size_t)3 * G * 2 * 8 + (kring ? (size_t)2 * 9 * cols * ksize : 0);
 }
 
+// Launch geometry on `slots` co-resident workgroups, `reserve` of them left free where that costs nothing (the pre-pass of the NEXT
+// ramp runs in them beside this kernel): every strip gets the same number of row ranges -- except a last strip of at most 64 live
+// columns (nx = 4096 in the 256-column form: 16 strips of 252 + 64), which is covered in QUAD mode: nq workgroups whose four wave
+// columns take a row range each.  4096 x 4096: 16 x 31 ranges of 133 rows + 8 quad workgroups (32 ranges of 128 rows) = 504 workgroups
+// of 139 steps; before (17 x 30 ranges of 137 rows): 510 of 143.  Returns the grid size.
+static inline long chain2_geometry(ChainArgs &a, int nstrips, int live_last, int slots, int reserve, int wc = 4) {
+    const int maxr = (a.ny + 7) / 8;   // at least 8 rows per range
+    auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
+    int best_nr = 0, best_nq = 0, best_steps = 1 << 30;
+    if (nstrips > 1 && live_last <= 64) {
+        const int nfull = nstrips - 1;
+        for (int pass = 0; pass < 2 && !best_nr; ++pass) {   // (second pass: without the reserve, when it leaves no room)
+            const int avail = slots - (pass ? 0 : reserve);
+            for (int nq = 1; wc * nq <= maxr && nq < avail; ++nq) {
+                int nr = (avail - nq) / nfull;
+                if (nr > maxr) nr = maxr;
+                if (nr < 1) break;
+                const int steps = cdiv(a.ny, nr) > cdiv(a.ny, wc * nq) ? cdiv(a.ny, nr) : cdiv(a.ny, wc * nq);
+                if (steps < best_steps) best_steps = steps, best_nr = nr, best_nq = nq;
+            }
+        }
+    }
+    int nr_u = (slots - reserve) / nstrips;   // every strip alike
+    if (nr_u < 1) nr_u = slots / nstrips;
+    if (nr_u > maxr) nr_u = maxr;
+    if (nr_u < 1) nr_u = 1;
+    if (best_nr && best_steps < cdiv(a.ny, nr_u)) {
+        a.geo_nr = best_nr, a.geo_rows = cdiv(a.ny, best_nr), a.geo_nq = best_nq, a.geo_rows_q = cdiv(a.ny, wc * best_nq);
+        return (long)best_nr * (nstrips - 1) + best_nq;
+    }
+    a.geo_nr = nr_u, a.geo_rows = cdiv(a.ny, nr_u), a.geo_nq = 0, a.geo_rows_q = 0;
+    return (long)nr_u * nstrips;
+}
+
 template <int NP, int G, int START, typename KT = float, int NARROW = 0>
 static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
     constexpr int COLS = NARROW ? 128 : C2_COLS_DEF;
@@ -1185,15 +1226,13 @@ static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
     const int max_wg = 4 * c2_wps(G, sizeof(KT) == 8, NARROW) / (C2_THREADS / 64);
     if (per_cu > max_wg) per_cu = max_wg;
     if (a.nb < 2) return 1;   // (the frame-edge lanes of the first / last strip emit without neighbours: border pixels)
-    const int nstrips = C2_NSTRIPS(a.nx);
-    int nranges = (int)(((long)ncu * per_cu) / nstrips);
-    if (nranges > (a.ny + 7) / 8) nranges = (a.ny + 7) / 8;
-    if (nranges < 1) nranges = 1;
-    const long grid = (long)nranges * nstrips;
+    ChainArgs ag = a;
+    const long grid = chain2_geometry(ag, C2_NSTRIPS(a.nx), a.nx - (C2_NSTRIPS(a.nx) - 1) * C2_OUTW, ncu * per_cu,
+                                      NARROW ? 0 : ctx->chain_reserve, COLS / 64);
     if (lds > 48 * 1024)
         RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chain2_kernel<NP, G, START, KT, NARROW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((chain2_kernel<NP, G, START, KT, NARROW>), dim3((unsigned)grid), dim3(C2_THREADS), lds, ctx->stream, a,
+    hipLaunchKernelGGL((chain2_kernel<NP, G, START, KT, NARROW>), dim3((unsigned)grid), dim3(C2_THREADS), lds, ctx->stream, ag,
                        reinterpret_cast<const RipPlanHeader *>(plan->dev), plan->d_variants, plan->d_k, plan->d_diffs,
                        ctx->guard_band);
     RIP_HIP(ctx, hipGetLastError());

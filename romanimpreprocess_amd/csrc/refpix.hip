@@ -20,15 +20,7 @@
 // it from LAPACK gelsd, which agrees to ~1e-13 relative but not bit for bit -- the caller may pass
 // LAPACK's (m, c) instead (`lines_override`).  See DESIGN.md "channel line fit".
 #include "rip_common.h"
-
-__device__ __forceinline__ uint32_t f2key(float f) {
-    uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key2f(uint32_t k) {
-    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(u);
-}
+#include "refpix_keys.h"
 
 // np.median of vals[0..n) held in LDS, by rank counting; result broadcast through slot[0..1].
 // All threads of the block must call it.  Ties are ordered by index, so ranks are a permutation.
@@ -116,9 +108,6 @@ struct SelState {
     uint32_t rank[2];
 };
 
-#define SEL_BINS 2048
-__device__ __forceinline__ int sel_shift(int level) { return level == 0 ? 21 : (level == 1 ? 10 : 0); }
-__device__ __forceinline__ int sel_bits(int level) { return level == 2 ? 10 : 11; }
 
 __global__ __launch_bounds__(256) void sel_hist_kernel(const uint16_t *__restrict__ amp33, const float *__restrict__ med,
                                                        const SelState *__restrict__ st, uint32_t *__restrict__ ghist,
@@ -323,6 +312,7 @@ int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a) {
     if (a.nx % RIP_CW) return rip_fail(ctx, RIP_EINVAL, "refpix: nx=%d is not a multiple of 128", a.nx);
     if (a.ny < 8) return rip_fail(ctx, RIP_EINVAL, "refpix: ny=%d too small", a.ny);
     const int G = a.ngrp, ny = a.ny, nch = a.nx / RIP_CW;
+    if (ctx->prepass_one && rip_refpix_one_supported(a)) return rip_launch_refpix_one(ctx, a);
     if (a.amp33) {
         // scratch: lohi (G,ny,2) f32 | SelState[G]
         const size_t lohi_b = (size_t)G * ny * 2 * sizeof(float);

@@ -142,9 +142,13 @@ struct rip_ctx {
     double guard_band = 1e-5;  // relative half-width of the exact-order re-evaluation band of the jump test (rip_set_option_f64)
     bool prof = false;
     std::vector<hipEvent_t> prof_events;  // 6 per rip_calibrate call
-    void *ws[14] = {};          // 0-9: calibration path and stage entries; 10-12: Level-1 synthesis (synth.hip); 13: the pre-pass's
-                                // selection histograms (zero between calls)
-    size_t ws_bytes[14] = {};
+    void *ws[16] = {};          // 0-9: calibration path and stage entries; 10-12: Level-1 synthesis (synth.hip); 13: the multi-launch
+                                // pre-pass's selection histograms (zero between calls); 14: control words + histograms of the
+                                // single-launch pre-pass (zero between calls), 15: its row / channel scratch
+    size_t ws_bytes[16] = {};
+    void *prepass_stamps = nullptr;   // diagnostic: device buffer of 16 clock stamps per workgroup of the single-launch pre-pass
+    int chain_reserve = 8;      // workgroup slots the 256-column fused kernel leaves free (the next ramp's pre-pass runs in them)
+    bool prepass_one = true;    // reference-pixel tables by the single-launch kernel (refpix_one.hip) where it covers the frame
     // rip_calibrate_batch (batch.hip): download stream and the two sets of device buffers, kept between calls
     hipStream_t stream3 = nullptr;
     void *batch_buf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -262,6 +266,10 @@ struct ChainArgs {
     int merged_dq;     // plane index (relative to NP) of the flag word that already holds flat flags / dark dq as this call applies them
     int dbg;           // timing experiments only (rip_set_option "chain_dbg"): skips phases, results invalid
     int ny, nx, nb, ngrp;
+    // launch geometry (set by the launcher, chain2_kernel.h): geo_nr row ranges of geo_rows rows for each full-width strip; where
+    // the last strip has at most 64 live columns (nx = 4096: 17th strip of the 256-column form) it is covered by geo_nq workgroups
+    // whose four wave columns each march down their OWN range of geo_rows_q rows of that strip (0: every strip alike)
+    int geo_nr, geo_rows, geo_nq, geo_rows_q;
 };
 bool rip_chain_supported(const rip_ctx *ctx, int nplanes, int G, int k_dtype, int gain_dtype);
 int rip_launch_chain(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, int nplanes, int k_dtype);
@@ -296,6 +304,10 @@ struct RefpixArgs {
     int ny, nx, ngrp;
 };
 int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a);
+// refpix_one.hip: the same tables in one launch (frames up to 4096 rows with a reference output)
+bool rip_refpix_one_supported(const RefpixArgs &a);
+int rip_launch_refpix_one(rip_ctx *ctx, const RefpixArgs &a);
+int rip_refpix_one_status(rip_ctx *ctx, int *status);
 // the general forms (any argument of reference_subtraction.py's two functions); device pointers
 int rip_refpix_row_general(rip_ctx *ctx, float *d_image, int ny, int width, int nside, int use_ref_channel, int mode,
                            double slope, float *d_ref_med, float *d_sci_med, float *d_ctr);

@@ -104,3 +104,29 @@ def ref_subtraction_channel(image, channel_start=0, channel_end=128, use_ref_cha
     ctx.check(ctx.lib.rip_stage_refpix_channel(ctx.h, image.ctypes.data, ny, w, int(channel_start), int(channel_end), nchan,
                                                None if ln is None else ln.ctypes.data, None))
     return image
+
+
+def refpix_tables(data, dark, amp33, amp33_med, slope, form=-1, ctx=None):
+    """The tables the chain's reference-pixel step applies to a ramp (gen_cal_image.py:531-556): ``rowcorr`` (ngrp, ny) float64 =
+    ``slope * float64(float32(row median of the reference output - ctr))`` and ``lines`` (ngrp, nx // 128, 2) float64 = (m, c) of
+    the science channels (two-point formula, DESIGN.md "channel line fit").  ``form``: 1 the single-launch kernel, 0 the
+    multi-launch kernels, -1 the library's default; identical bits.  Returns (rowcorr, lines, status)."""
+    import ctypes
+
+    ctx = ctx or _native.default_context()
+    data = np.ascontiguousarray(data)
+    if data.dtype not in (np.uint16, np.float32):
+        raise TypeError("data must be uint16 or float32")
+    G, ny, nx = data.shape
+    dark = np.ascontiguousarray(dark[:G], dtype=np.float32)
+    amp33 = np.ascontiguousarray(amp33, dtype=np.uint16)
+    med = np.ascontiguousarray(amp33_med, dtype=np.float32)
+    if dark.shape != (G, ny, nx) or amp33.shape != (G, ny, 128) or med.shape != (ny, 128):
+        raise ValueError("shapes: data (G, ny, nx), dark (>= G, ny, nx), amp33 (G, ny, 128), amp33_med (ny, 128)")
+    rowcorr = np.empty((G, ny), np.float64)
+    lines = np.empty((G, nx // 128, 2), np.float64)
+    status = ctypes.c_int(0)
+    ctx.check(ctx.lib.rip_stage_refpix_tables(ctx.h, data.ctypes.data, _native.dtype_code(data), dark.ctypes.data, amp33.ctypes.data,
+                                              med.ctypes.data, float(slope), G, ny, nx, int(form), rowcorr.ctypes.data,
+                                              lines.ctypes.data, ctypes.addressof(status)))
+    return rowcorr, lines, status.value

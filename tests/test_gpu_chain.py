@@ -270,11 +270,13 @@ def test_specialised_kernel_vs_oracle(name, shape, rp, p, exclude_first, kdt):
     cb.ctx.drop_caldir(4)
 
 
-@pytest.mark.parametrize("kdt", [np.float32, np.float64])
-def test_fused_forms_agree_across_seams(kdt):
+@pytest.mark.parametrize("rp,kdt", [(synth.READ_PATTERN_8, np.float32), (synth.READ_PATTERN_8, np.float64),
+                                    (synth.READ_PATTERN_16, np.float32), (synth.READ_PATTERN_16, np.float64)],
+                         ids=["g8_f32", "g8_k64", "g16_f32", "g16_k64"])
+def test_fused_forms_agree_across_seams(rp, kdt):
     """A frame wider than several column strips and taller than several row ranges: the wave-specialised kernel and the stage
-    kernels must give identical bits (halo columns, range boundaries, frame edges)."""
-    rp = synth.READ_PATTERN_8
+    kernels must give identical bits (halo columns, range boundaries, frame edges) -- the 256-column form and every narrow
+    form (f64 ipc4d, 16 groups, both)."""
     ny, nx = 1160, 896
     cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=31, bias_amplitude=2.0, bad_lin_frac=0.005,
                             ipc_dtype=kdt)
@@ -351,6 +353,8 @@ FULL_FRAME = [
     # (13 truncated refits, O(G^2) variance passes), so it checks a 264-row frame of the full width and the full frame is
     # checked between the fused kernel and the stage kernels
     ("g16_f32", synth.READ_PATTERN_16, np.float32, 8, 264),
+    # f64 ipc4d x 16 groups: the 76 KB narrow form at 33 strips of the full width (frame-edge lanes emitting, 2 workgroups per CU)
+    ("g16_k64", synth.READ_PATTERN_16, np.float64, 8, 264),
 ]
 
 

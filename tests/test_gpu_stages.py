@@ -334,3 +334,80 @@ def test_ref_subtraction_default_arguments():
         reference_subtraction.ref_subtraction_channel(base[:, :4096].copy(), use_ref_channel=True, ctx=ctx)
     with pytest.raises(TypeError):
         reference_subtraction.ref_subtraction_row(base.astype(np.float64), ctx=ctx)
+
+
+# ---- the reference-pixel tables of the chain: the single-launch pre-pass (refpix_one.hip) and the multi-launch one (refpix.hip)
+
+
+def _tables_from_medians(ref_med, ctr, bottom_top, slope, ny):
+    """what the chain applies, from the reference's own medians: slope * f64(f32(ref_med - ctr)); the line through
+    (1.5, b), (ny - 2.5, t) by the device's two-point formula (channel line fit)"""
+    rowcorr = np.float64(slope) * (np.asarray(ref_med, np.float32) - np.float32(ctr)).astype(np.float64)
+    b = np.asarray(bottom_top, np.float32)[:, 0].astype(np.float64)
+    t = np.asarray(bottom_top, np.float32)[:, 1].astype(np.float64)
+    m = (t - b) / np.float64(ny - 4)
+    c = b - 1.5 * m
+    return rowcorr, np.stack([m, c], axis=-1)
+
+
+@pytest.mark.parametrize("name", ["refpix_full_a", "refpix_full_b"])
+def test_refpix_tables_fullframe_vs_reference_medians(name):
+    """Full 4096 x 4096 frame: both forms of the pre-pass against tables made from the medians the REFERENCE's
+    ref_subtraction_row / ref_subtraction_channel computed (golden fixture), bit for bit."""
+    g = load_golden(name)
+    c = gc.refpix_fullframe_inputs(int(g["seed"]))
+    n = 4096
+    slope = float(g["slope"])
+    want_rc, want_ln = _tables_from_medians(g["ref_med"], g["ctr"], g["bottom_top"][:32], slope, n)
+    for form in (1, 0):
+        rc, ln, status = reference_subtraction.refpix_tables(c["data"][None], c["dark"][None], c["amp33"][None], c["med"], slope,
+                                                             form=form, ctx=gpu_context())
+        assert status == 0
+        assert_same_bits(rc[0], want_rc, f"rowcorr (form {form})")
+        assert_same_bits(ln[0], want_ln, f"lines (form {form})")
+
+
+@pytest.mark.parametrize("ny,nx,G,kind", [(8, 128, 1, "noise"), (40, 256, 3, "noise"), (136, 384, 8, "ties"), (300, 128, 16, "noise"),
+                                          (1160, 256, 5, "drift"), (129, 128, 2, "const"), (4096, 512, 8, "noise"),
+                                          (520, 128, 64, "ties")])
+def test_refpix_tables_single_launch_equals_multi_launch_and_oracle(ny, nx, G, kind):
+    """Random frames -- ragged row counts (partial workgroups and slots), one to 32 workgroups per group, up to 64 groups, heavy
+    ties (few distinct values: every histogram level has crowded bins), constant blocks, drifting rows, f32 cubes: the two forms
+    agree bit for bit, and with the numpy oracle's medians."""
+    from oracle import refpix as orp
+
+    rng = np.random.default_rng(ny * 7 + nx + G)
+    dark = (13000 + rng.integers(0, 1600, size=(G, ny, nx)) / 8.0).astype(np.float32)
+    med = (29000 + rng.integers(0, 64, size=(ny, 128)) / 4.0).astype(np.float32)
+    if kind == "noise":
+        amp33 = (29000 + rng.normal(0, 4, size=(G, ny, 128))).astype(np.uint16)
+        data = (dark + rng.normal(0, 30, size=(G, ny, nx))).astype(np.uint16)
+    elif kind == "ties":
+        amp33 = (29000 + rng.integers(0, 3, size=(G, ny, 128))).astype(np.uint16)
+        med[:] = 29000.0
+        data = (dark + rng.integers(0, 2, size=(G, ny, nx))).astype(np.uint16)
+    elif kind == "const":
+        amp33 = np.full((G, ny, 128), 29003, np.uint16)
+        med[:] = 29001.5
+        data = np.full((G, ny, nx), 13100, np.uint16)
+    else:
+        drift = (np.arange(ny) * 0.05)[None, :, None]
+        amp33 = (29000 + drift + rng.normal(0, 4, size=(G, ny, 128))).astype(np.uint16)
+        data = (dark + drift + rng.normal(0, 30, size=(G, ny, nx))).astype(np.float32)   # an f32 cube
+    slope = np.float64(0.3371)
+    ctx = gpu_context()
+    rc1, ln1, st1 = reference_subtraction.refpix_tables(data, dark, amp33, med, slope, form=1, ctx=ctx)
+    rc0, ln0, st0 = reference_subtraction.refpix_tables(data, dark, amp33, med, slope, form=0, ctx=ctx)
+    assert st1 == 0 and st0 == 0
+    assert_same_bits(rc1, rc0, "rowcorr: single launch vs multi launch")
+    assert_same_bits(ln1, ln0, "lines: single launch vs multi launch")
+    # and twice in a row: the kernel leaves its histograms / counters as it found them
+    rc2, ln2, st2 = reference_subtraction.refpix_tables(data, dark, amp33, med, slope, form=1, ctx=ctx)
+    assert st2 == 0
+    assert_same_bits(rc2, rc1, "rowcorr: second call")
+    assert_same_bits(ln2, ln1, "lines: second call")
+    for g in range(min(G, 3)):
+        _, diag = orp.correct_group(data[g].astype(np.float32), dark[g], amp33[g], med, slope)
+        want_rc, want_ln = _tables_from_medians(diag["ref_med"], diag["ctr"], diag["channels"][:nx // 128, :2], slope, ny)
+        assert_same_bits(rc1[g], want_rc, f"rowcorr vs oracle, group {g}", zero_sign_ok=True)
+        assert_same_bits(ln1[g], want_ln, f"lines vs oracle, group {g}", zero_sign_ok=True)
