@@ -365,9 +365,7 @@ def main():
     ap.add_argument("--p-order", type=int, default=8, choices=(3, 8, 10), help="Legendre order of the linearity file")
     ap.add_argument("--tiled", action="store_true", help="the round-1 input: a 128-row strip repeated down the frame (numpy)")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE",
-                    help="rip_set_option before the run (A/B timing: overlap=0, prepass_one=0, ...)")
-    ap.add_argument("--chain3", type=int, default=None, choices=(0, 1),
-                    help="(rounds 1-2: A/B switch of the wave-private fused kernel, removed in round 3; accepted, without effect)")
+                    help="rip_set_option before the run (A/B timing: overlap=0, prepass_form=0, ...)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip pre-pass exclusive timing, variants and the 18-slot batch")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
@@ -421,8 +419,6 @@ def main():
         return rp_, cal, ramp
 
     cb = pipeline.Calibrator(device=local_rank)
-    if args.chain3 is not None:
-        cb.ctx.set_option("chain3", args.chain3)
     for kv in args.set:
         k_, v_ = kv.split("=")
         cb.ctx.set_option(k_, int(v_))

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ROMANHIP_LIB") or os.path.join(_HERE, "libromanhip.so")   # the env var: A/B timing of library variants
 
 RIP_MAX_GROUPS = 64
+RIP_TIMING_BUILD_FLAG = 1000000   # include/romanhip.h
 RIP_F32, RIP_F64, RIP_U16 = 0, 1, 2
 RIP_HOST, RIP_DEVICE = 0, 1
 RIP_INPUTS_STREAM_ORDERED, RIP_INPUTS_COMPLETE = 0, 1
@@ -164,6 +165,10 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
+    ver = lib.rip_version()
+    if ver >= RIP_TIMING_BUILD_FLAG and os.environ.get("ROMANHIP_ALLOW_TIMING_BUILD") != "1":
+        raise RuntimeError(f"{LIB_PATH} is a timing build (compiled with -DRIP_TIMING_BUILD: its kernels may skip phases, results "
+                           "invalid by construction); set ROMANHIP_ALLOW_TIMING_BUILD=1 to load it for timing experiments")
     _lib = lib
     return lib
 

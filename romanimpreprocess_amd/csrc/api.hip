@@ -28,6 +28,7 @@ void *rip_ws(rip_ctx *ctx, int slot, size_t bytes) {
     if (ctx->ws_bytes[slot] >= bytes && ctx->ws[slot]) return ctx->ws[slot];
     if (ctx->ws[slot]) {
         (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);   // (the overlapped pre-pass uses workspaces too)
         (void)hipFree(ctx->ws[slot]);
         ctx->ws[slot] = nullptr;
         ctx->ws_bytes[slot] = 0;
@@ -91,7 +92,11 @@ void free_cal(RipCal &c) {
 
 extern "C" {
 
+#ifdef RIP_TIMING_BUILD
+int rip_version(void) { return RIP_VERSION + RIP_TIMING_BUILD_FLAG; }
+#else
 int rip_version(void) { return RIP_VERSION; }
+#endif
 
 const char *rip_last_error(const rip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -202,16 +207,13 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value) {
         ctx->use_chain2 = value != 0;
         return RIP_OK;
     }
-    if (name && strcmp(name, "chain3") == 0) {
-        ctx->use_chain3 = (value < 0 || value > 2) ? 2 : value;
-        return RIP_OK;
-    }
     if (name && strcmp(name, "chain_reserve") == 0) {
         ctx->chain_reserve = value < 0 ? 0 : value;
         return RIP_OK;
     }
-    if (name && strcmp(name, "prepass_one") == 0) {
-        ctx->prepass_one = value != 0;
+    if (name && strcmp(name, "prepass_form") == 0) {
+        if (value < -1 || value > 2) return rip_fail(ctx, RIP_EINVAL, "prepass_form: -1 (by situation), 0, 1 or 2");
+        ctx->prepass_form = value;
         return RIP_OK;
     }
     if (name && strcmp(name, "overlap") == 0) {
@@ -772,6 +774,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
                     : nullptr;
     const int par = ctx->parity;
     const bool overlap = do_ref && !host && ctx->use_overlap;
+    hipStream_t pre = overlap ? ctx->stream2 : ctx->stream;   // where the pre-pass and the saturation pass of THIS call are launched
     double *rowcorr = nullptr, *rowcorr_t = nullptr, *lines = nullptr;
     // dq-init + saturation flagging into workspace copies of the flag arrays (the caller's inputs stay untouched), double
     // buffered by call parity like the reference-pixel tables because the pass may run ahead on the second stream
@@ -784,22 +787,29 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         uint32_t *p2 = (uint32_t *)(w + (size_t)par * one + al(b_gdq));
         const int dnu_first = (plan && plan->h.start == 1) ? 1 : 0;  // the plan excludes the first group
         const int rcs = rip_launch_satflag(ctx, d_data, in->data_dtype, c.sat_thr, c.sat_dq, d_gdq, d_pdq, g2, p2, G, ny, nx,
-                                           in->sat_backup, in->sat_skip_firstn, dnu_first, in->sat_dilution);
+                                           in->sat_backup, in->sat_skip_firstn, dnu_first, in->sat_dilution, pre);
         d_gdq = g2;
         d_pdq = p2;
         return rcs;
     };
     // pre-passes of consecutive calls share workspaces: one that runs on another stream than its predecessor waits for it
     auto pre_order = [&]() -> int {
-        if (ctx->ev_pre_valid && ctx->pre_stream != ctx->stream) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pre, 0));
+        if (ctx->ev_pre_valid && ctx->pre_stream != pre) RIP_HIP(ctx, hipStreamWaitEvent(pre, ctx->ev_pre, 0));
         return RIP_OK;
     };
     auto pre_done = [&]() -> int {
         if (!ctx->ev_pre) RIP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pre, hipEventDisableTiming));
-        RIP_HIP(ctx, hipEventRecord(ctx->ev_pre, ctx->stream));
-        ctx->pre_stream = ctx->stream;
+        RIP_HIP(ctx, hipEventRecord(ctx->ev_pre, pre));
+        ctx->pre_stream = pre;
         ctx->ev_pre_valid = true;
         return RIP_OK;
+    };
+    auto mark_on = [&](hipStream_t st) {
+        if (!ctx->prof) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, st);
+        ctx->prof_events.push_back(e);
     };
     if (do_ref) {
         if (nx % RIP_CW) return rip_fail(ctx, RIP_EINVAL, "calibrate: nx=%d is not a multiple of 128", nx);
@@ -809,38 +819,29 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         rowcorr_t = rowcorr + (size_t)G * ny;
         lines = rowcorr_t + (size_t)G * ny;
         RefpixArgs ra{d_data, in->data_dtype, c.dark_data, c.has_amp33 ? d_a33 : nullptr, c.amp33_med, c.refout_slope,
-                      d_lines_ovr, rowcorr, rowcorr_t, lines, ny, nx, G};
-        hipStream_t main_stream = ctx->stream;
+                      d_lines_ovr, rowcorr, rowcorr_t, lines, ny, nx, G, overlap ? 1 : 0, pre};
         if (overlap) {
             if (ctx->ev_done_valid[par]) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_done[par], 0));
-            // what the pre-pass stream waits for before it reads the inputs (rip_ramp_desc::inputs_ready / ready_event):
-            // the caller's event, or -- unless the caller vouches for complete inputs -- everything queued on the main stream
-            // so far (work of the caller's own, or of this library's device-pointer entry points: stream_dirty)
-            if (in->ready_event) {
-                RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, (hipEvent_t)in->ready_event, 0));
-            } else if (in->inputs_ready != RIP_INPUTS_COMPLETE || ctx->stream_dirty) {
+            // what the pre-pass stream waits for before it reads the inputs (rip_ramp_desc::inputs_ready / ready_event): the
+            // caller's event, and -- unless the caller vouches for complete inputs -- everything queued on the main stream so far
+            // (work of the caller's own, or of this library's device-pointer entry points: stream_dirty, which an event that
+            // guards only some of the inputs does not cover)
+            if (in->ready_event) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, (hipEvent_t)in->ready_event, 0));
+            if ((!in->ready_event && in->inputs_ready != RIP_INPUTS_COMPLETE) || ctx->stream_dirty) {
                 if (!ctx->ev_in) RIP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
                 RIP_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->stream));
                 RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_in, 0));
             }
-            ctx->stream = ctx->stream2;
         }
-        mark();
-        rc = pre_order();   // (no early return here: ctx->stream may be the second stream at this point)
-        if (!rc) rc = rip_launch_refpix_prepass(ctx, ra);
-        if (!rc && do_sat) rc = sat_pass();  // same stream as the pre-pass: overlaps the previous ramp's main kernel
-        if (!rc) rc = pre_done();
-        mark();
+        mark_on(pre);
+        if ((rc = pre_order()) || (rc = rip_launch_refpix_prepass(ctx, ra))) return rc;
+        if (do_sat && (rc = sat_pass())) return rc;  // same stream as the pre-pass: overlaps the previous ramp's main kernel
+        if ((rc = pre_done())) return rc;
+        mark_on(pre);
         if (overlap) {
-            if (!rc) {
-                hipError_t e1 = hipEventRecord(ctx->ev_tab[par], ctx->stream2);
-                ctx->stream = main_stream;
-                RIP_HIP(ctx, e1);
-                RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tab[par], 0));
-            }
-            ctx->stream = main_stream;
+            RIP_HIP(ctx, hipEventRecord(ctx->ev_tab[par], ctx->stream2));
+            RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tab[par], 0));
         }
-        if (rc) return rc;
     } else {
         mark();
         if (do_sat && ((rc = pre_order()) || (rc = sat_pass()) || (rc = pre_done()))) return rc;
@@ -1114,14 +1115,15 @@ int rip_stage_refpix_tables(rip_ctx *ctx, const void *data, int data_dtype, cons
         return rc;
     RefpixArgs ra{d_data.p, data_dtype, d_dark.as<float>(), d_a33.as<uint16_t>(), d_med.as<float>(), slope, nullptr,
                   d_rc.as<double>(), d_rt.as<double>(), d_ln.as<double>(), ny, nx, ngrp};
-    const bool keep = ctx->prepass_one;
-    if (form >= 0) ctx->prepass_one = form != 0;
-    if (form == 1 && !rip_refpix_one_supported(ra)) {
-        ctx->prepass_one = keep;
-        return rip_fail(ctx, RIP_EINVAL, "refpix tables: the single-launch kernel does not cover a %d x %d frame of %d groups", ny, nx, ngrp);
+    if (form < -1 || form > 2) return rip_fail(ctx, RIP_EINVAL, "refpix tables: form %d", form);
+    const int keep = ctx->prepass_form;
+    if (form >= 0) ctx->prepass_form = form;
+    if (form >= 1 && !rip_refpix_one_supported(ra)) {
+        ctx->prepass_form = keep;
+        return rip_fail(ctx, RIP_EINVAL, "refpix tables: the single-launch kernels do not cover a %d x %d frame of %d groups", ny, nx, ngrp);
     }
     rc = rip_launch_refpix_prepass(ctx, ra);
-    ctx->prepass_one = keep;
+    ctx->prepass_form = keep;
     if (rc) return rc;
     RIP_HIP(ctx, hipMemcpyAsync(rowcorr, d_rc.p, (size_t)ngrp * ny * 8, hipMemcpyDeviceToHost, ctx->stream));
     RIP_HIP(ctx, hipMemcpyAsync(lines, d_ln.p, (size_t)ngrp * nch * 16, hipMemcpyDeviceToHost, ctx->stream));

@@ -26,12 +26,16 @@
 #pragma once
 #include "chain_common.h"
 
-#ifndef C2_COLS_DEF
-#define C2_COLS_DEF 256
-#endif
+#define C2_COLS_DEF 256   // (128-column workgroups WITH every ring: 4 % slower, profiles/r03_summary.md; the narrow forms drop rings)
 // columns of a workgroup's window: a constant `COLS` of the enclosing template (256; 128 in the narrow form, see chain2_kernel)
 #define C2_COLS COLS
 #define C2_THREADS (2 * C2_COLS)
+// Diagnostic builds only (RIP_TIMING_BUILD: rip_version() then reports a timing build and the Python binding refuses the library
+// unless told otherwise): -DC2_DBG switches phases off by ChainArgs::dbg (results invalid by construction), -DCH_STAMP records
+// per-phase clock stamps.  Nothing else in this header changes what the kernel computes.
+#if (defined(C2_DBG) || defined(CH_STAMP)) && !defined(RIP_TIMING_BUILD)
+#error "C2_DBG / CH_STAMP are timing experiments: build them with -DRIP_TIMING_BUILD"
+#endif
 #ifdef CH_STAMP
 #define C2_DRAIN()                                \
     if (a.dbg & 2048) {                           \
@@ -40,20 +44,12 @@
 #else
 #define C2_DRAIN()
 #endif
-#ifdef C2_NOBARRIER  // timing experiment only (results are wrong)
-#define C2_SYNC()
-#else
 #define C2_SYNC() __syncthreads()
-#endif
 // Strip geometry: the window of strip s starts at column s * C2_OUTW; its lanes 2 .. C2_COLS-3 emit, lanes 0, 1 and C2_COLS-2,
 // C2_COLS-1 are the halo of the two 3 x 3 passes -- except at the frame's edge, where columns 0, 1 and nx-2, nx-1 are emitted
 // by those lanes themselves (border pixels: no IPC, no neighbours needed; nb >= 2).  So n strips cover n * C2_OUTW + 4 columns:
 // 33 strips of 128 columns cover 4096 exactly (34 with a uniform 2-column offset), 17 of 256.
-#ifdef C2_ALIGNED_TIMING   // TIMING experiment only (wrong strip edges): 16 aligned 256-column windows, no halo
-#define C2_OUTW C2_COLS
-#else
 #define C2_OUTW (C2_COLS - 4)
-#endif
 #define C2_NSTRIPS(nx) (((nx) - 4 + C2_OUTW - 1) / C2_OUTW < 1 ? 1 : ((nx) - 4 + C2_OUTW - 1) / C2_OUTW)
 // Where the half-step barrier falls in the fit role: 0 after the first half of the fit, 1 after its second half (and the saturated
 // refits), 2 after the flag propagation and the group-flag stores, 3 after the finish and the plane stores.  Same-box A/B on the
@@ -95,70 +91,30 @@ __device__ __forceinline__ unsigned c2_opaque(unsigned x) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t c2_rsrc(const void *p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
 }
-// Cache policy of the loads (experiment, off by default): every array but the IPC coefficients is read exactly once per
-// ramp, so those loads can carry the non-temporal hint (aux bit 1 = nt on gfx940+); the coefficients are read twice, one row
-// step apart (ingest role for C, fit role for O2), and the first read stays a normal one so that the second finds the lines
-// in L2.  Measured (profiles/r01_summary.md, item 8): HBM reads -8 %, kernel time +11 % -- the hint costs more than the
-// traffic it saves, so C2_NT* default to 0.
-#ifndef C2_NT
-#define C2_NT 0
-#endif
-#ifndef C2_NT_G   // per-group arrays of the ingest role: cube, groupdq, dark, bias
-#define C2_NT_G C2_NT
-#endif
-#ifndef C2_NT_C   // coefficient-type planes of the ingest role
-#define C2_NT_C C2_NT
-#endif
-#ifndef C2_NT_F   // loads of the fit role (second read of the IPC coefficients, tail planes)
-#define C2_NT_F C2_NT
-#endif
-template <int AUX = C2_NT>
+// (non-temporal hints on the once-read arrays: HBM reads -8 %, kernel time +11 %, profiles/r01_summary.md -- not used)
 __device__ __forceinline__ float c2_ld_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
-template <int AUX = C2_NT>
 __device__ __forceinline__ double c2_ld_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
-template <int AUX = C2_NT>
 __device__ __forceinline__ uint32_t c2_ld_u32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX);
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
 }
-template <int AUX = C2_NT>
 __device__ __forceinline__ uint32_t c2_ld_u16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, AUX);
+    return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
 }
-template <int AUX = C2_NT>
 __device__ __forceinline__ uint32_t c2_ld_u8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, AUX);
+    return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
 }
 // XCD-aware block order (the dispatcher deals consecutive block ids round the 8 XCDs, each with its own L2): block ids that
 // share an XCD get CONSECUTIVE cells of the (row range, strip) grid, so that neighbouring strips -- whose 256-column windows at
 // a 252-column pitch share cache lines and halo columns -- find each other's lines in their L2.  Bijective for any grid size;
-// a speed choice only (-DC2_XCD=0: identity).
-#ifndef C2_XCD
-#define C2_XCD 1
-#endif
-// when the ingest role requests the IPC coefficients of the row whose first iterate follows the half-step barrier: 1 = at
-// the top of the step (landed by the barrier), 0 = at the end of the first half (ten registers fewer during A)
-#ifndef C2_KEARLY
-#define C2_KEARLY 0   // same-box A/B (profiles/r03_summary.md): 0.949 (early) against 0.945 ms -- the latency is not on the critical path
-#endif
+// a speed choice only.
 __device__ __forceinline__ int c2_xcd_block(int b, int n) {
-#if C2_XCD
     const int q = n >> 3, r = n & 7, x = b & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-#else
-    return b;
-#endif
 }
-
-struct C2Keep {   // first of two reads: keep the line
-    static constexpr int value = 0;
-};
-struct C2Last {   // last read of the line
-    static constexpr int value = C2_NT_F;
-};
 
 // The kernel arguments re-read from the kernarg segment (scalar loads from the constant address space) through a
 // pointer made opaque once per phase: the ~25 pointers and sizes of ChainArgs then live in scalar registers only
@@ -364,7 +320,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
 
     // coefficient loader: raw loads at clamped source positions + validity mask for destination (y, c);
     // `want` is wave-uniform.  Planes are walked in memory order (plane = 3*(1+dy) + (1+dx)).
-    auto load_k = [&](auto pol, const void *kern_base, int y, bool want, f2 (&kk2)[5]) -> unsigned {
+    auto load_k = [&](const void *kern_base, int y, bool want, f2 (&kk2)[5]) -> unsigned {
         if (dbg & 128) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) kk2[k] = f2{(k == 0) ? 1.0f : 0.001f, 0.001f};
@@ -389,7 +345,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
             // 6 (1,-1), 7 (-1,1), 8 (-1,-1)
             const int k = (dy == 0) ? (dx == 0 ? 0 : dx == 1 ? 3 : 4) : (dy == 1) ? (dx == 0 ? 1 : dx == 1 ? 5 : 6)
                                                                                   : (dx == 0 ? 2 : dx == 1 ? 7 : 8);
-            const float kv_ = c2_ld_f32<decltype(pol)::value>(kr, cx4[dx + 1], pofs + rowoff[dy + 1]);
+            const float kv_ = c2_ld_f32(kr, cx4[dx + 1], pofs + rowoff[dy + 1]);
             if (k & 1)
                 kk2[k / 2].y = kv_;
             else
@@ -401,7 +357,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
     };
 
     // f64 coefficients: the same walk with 8-byte loads, nine scalars in the reference's term order
-    auto load_kd = [&](auto pol, const void *kern_base, int y, bool want, double (&kk)[9]) -> unsigned {
+    auto load_kd = [&](const void *kern_base, int y, bool want, double (&kk)[9]) -> unsigned {
         unsigned rowoff[3];
         bool rok[3];
 #pragma unroll
@@ -418,7 +374,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
             const int dy = p / 3 - 1, dx = p % 3 - 1;
             const int k = (dy == 0) ? (dx == 0 ? 0 : dx == 1 ? 3 : 4) : (dy == 1) ? (dx == 0 ? 1 : dx == 1 ? 5 : 6)
                                                                                   : (dx == 0 ? 2 : dx == 1 ? 7 : 8);
-            kk[k] = c2_ld_f64<decltype(pol)::value>(kr, cx4[dx + 1] * 2u, pofs + rowoff[dy + 1]);
+            kk[k] = c2_ld_f64(kr, cx4[dx + 1] * 2u, pofs + rowoff[dy + 1]);
             pofs += pl4 * 2u;
         }
         const unsigned um = (want && y >= ay0 && y < ay1) ? rowbits : 0u;
@@ -467,10 +423,10 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
                      o1 = yl * (row4 >> 2) + (unsigned)g0 * npix;
 #pragma unroll
             for (int g = g0; g < g1; ++g) {
-                rr.S[g] = c2_ld_u16<C2_NT_G>(rs, cc2, o2);
-                rr.q[g] = c2_ld_u8<C2_NT_G>(rq, cc1, o1);
-                rr.dk[g] = c2_ld_f32<C2_NT_G>(rd, cc4, o4);
-                rr.bs[g] = c2_ld_f32<C2_NT_G>(rb, cc4, o4);
+                rr.S[g] = c2_ld_u16(rs, cc2, o2);
+                rr.q[g] = c2_ld_u8(rq, cc1, o1);
+                rr.dk[g] = c2_ld_f32(rd, cc4, o4);
+                rr.bs[g] = c2_ld_f32(rb, cc4, o4);
                 o4 += pl4;
                 o2 += pl4 >> 1;
                 o1 += npix;
@@ -487,17 +443,17 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
 #pragma unroll
             for (int i = i0; i < i1; ++i) {
                 if (i < NP)
-                    rr.cf[i] = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
+                    rr.cf[i] = c2_ld_f32(rp, cc4, o4);
                 else if (i == NP)
-                    rr.smin = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
+                    rr.smin = c2_ld_f32(rp, cc4, o4);
                 else if (i == NP + 1)
-                    rr.smax = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
+                    rr.smax = c2_ld_f32(rp, cc4, o4);
                 else if (i == NP + 2)
-                    rr.sref = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
+                    rr.sref = c2_ld_f32(rp, cc4, o4);
                 else if (i == NP + 3)   // the flag word: linearity dq merged with what the finish step ORs into pixeldq (RipCal)
-                    rr.dq = c2_ld_u32<C2_NT_C>(rp, cc4, yl * row4 + (unsigned)(NP + ka->merged_dq) * pl4);
+                    rr.dq = c2_ld_u32(rp, cc4, yl * row4 + (unsigned)(NP + ka->merged_dq) * pl4);
                 else
-                    rr.gain = c2_ld_f32<C2_NT_C>(rp, cc4, o4);
+                    rr.gain = c2_ld_f32(rp, cc4, o4);
                 o4 += pl4;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -533,18 +489,6 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
 #pragma unroll
                 for (int g = 0; g < G; ++g) rcn[g] = rt[g];
             }
-#if C2_KEARLY
-            // IPC coefficients of row yc, consumed by C after the barrier: requested at the top of the step so that they have
-            // landed by then (their ten registers are live during A)
-            f2 kC[5];
-            double kCd[9];
-            kC[4].y = 0.0f;
-            unsigned vC;
-            if constexpr (K64)
-                vC = load_kd(C2Keep{}, ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kCd);
-            else
-                vC = load_k(C2Keep{}, ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kC);
-#endif
             const bool a_full = do_a && yi >= 0 && yi < ny;  // wave-uniform
             // A: two pairs of groups at a time -- reference-pixel/bias arithmetic and z of both pairs, then their two
             // Legendre recurrences interleaved (independent chains), then the raw loads of the same groups of the next
@@ -705,18 +649,16 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
                     GN[xslot * C2_COLS + col] = rr.gain;
                 }
             }
-#if !C2_KEARLY
             // IPC coefficients of row yc, consumed by C after the barrier; issued here so that their registers are not live
-            // during A
+            // during A (requested at the top of the step instead: 0.949 against 0.945 ms, the latency is not on the critical path)
             f2 kC[5];
             double kCd[9];
             kC[4].y = 0.0f;
             unsigned vC;
             if constexpr (K64)
-                vC = load_kd(C2Keep{}, ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kCd);
+                vC = load_kd(ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kCd);
             else
-                vC = load_k(C2Keep{}, ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kC);
-#endif
+                vC = load_k(ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kC);
             CH_T(2)
             C2_SYNC();
             CH_T(3)
@@ -842,16 +784,16 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
             const __amdgpu_buffer_rsrc_t rpl = c2_rsrc(kf->a.planes);
             const unsigned t_row = rc_ * row4;  // byte offset of row r in an f32 plane (uniform)
             const unsigned t_ld = (dbg & 256) ? 0u : t_row;   // timing experiment: the fit role's loads all hit row 0 (cached)
-            const float e_read = c2_ld_f32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 5) * pl4 + t_ld);
+            const float e_read = c2_ld_f32(rpl, cc4, (unsigned)(NP + 5) * pl4 + t_ld);
             const float e_gain = gain_next;
             // calibration planes of the tail (finish) of the same pixel, consumed after the barrier
             const size_t t_row4 = (size_t)t_row;
             const size_t pe_row = (size_t)(rc_ * (unsigned)nx);   // element offset of row r
-            const float e_dark = c2_ld_f32<C2_NT_F>(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_ld);
+            const float e_dark = c2_ld_f32(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_ld);
             // (flat flags and dark dq arrive with the linearity dq of the pixel: ChainArgs::merged_dq)
-            const uint32_t e_pdq = c2_ld_u32<C2_NT_F>(c2_rsrc(kf->a.pdq), cc4, t_ld);
+            const uint32_t e_pdq = c2_ld_u32(c2_rsrc(kf->a.pdq), cc4, t_ld);
             // flat / dark_dq == null: read the first slab plane instead (value unused), keeps the loads in one block
-            const float e_flat_raw = c2_ld_f32<C2_NT_F>(c2_rsrc(kf->a.flat ? (const void *)kf->a.flat : (const void *)kf->a.planes), cc4, t_ld);
+            const float e_flat_raw = c2_ld_f32(c2_rsrc(kf->a.flat ? (const void *)kf->a.flat : (const void *)kf->a.planes), cc4, t_ld);
             const float e_flat = kf->a.flat ? e_flat_raw : 1.0f;
             float d[G];
             f2 dpair[GP];
@@ -970,9 +912,9 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
 #endif
 #else
                 if constexpr (K64)
-                    (void)load_kd(C2Last{}, kf->a.kern, r, true, kFd);
+                    (void)load_kd(kf->a.kern, r, true, kFd);
                 else
-                    (void)load_k(C2Last{}, kf->a.kern, r, true, kF);
+                    (void)load_k(kf->a.kern, r, true, kF);
 #endif
             }
             if (emit) {
@@ -1141,25 +1083,25 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
                     unsigned o1 = yl * (row4 >> 2);
 #pragma unroll
                     for (int g = 0; g < G; ++g) {   // (raw: packed at the top of the next step, when they have landed)
-                        qb_next[g] = c2_ld_u8<C2_NT_F>(rq, cc1, o1);
+                        qb_next[g] = c2_ld_u8(rq, cc1, o1);
                         o1 += npix;
                     }
-                    gain_next = c2_ld_f32<C2_NT_F>(c2_rsrc(kg->a.planes), cc4, (unsigned)(NP + 4) * pl4 + yl * row4);
+                    gain_next = c2_ld_f32(c2_rsrc(kg->a.planes), cc4, (unsigned)(NP + 4) * pl4 + yl * row4);
                 }
             }
 #if C2_KFIT_EARLY == 2   // (row r + 2: the lines the ingest role fetched half a step ago)
             if constexpr (!KRING) {
                 if constexpr (K64)
-                    (void)load_kd(C2Last{}, kg->a.kern, r + 2, true, kn2_d);
+                    (void)load_kd(kg->a.kern, r + 2, true, kn2_d);
                 else
-                    (void)load_k(C2Last{}, kg->a.kern, r + 2, true, kn2);
+                    (void)load_k(kg->a.kern, r + 2, true, kn2);
             }
 #elif C2_KFIT_EARLY
             if constexpr (!KRING) {
                 if constexpr (K64)
-                    (void)load_kd(C2Last{}, kg->a.kern, r + 1, true, kn_d);
+                    (void)load_kd(kg->a.kern, r + 1, true, kn_d);
                 else
-                    (void)load_k(C2Last{}, kg->a.kern, r + 1, true, kn);
+                    (void)load_k(kg->a.kern, r + 1, true, kn);
             }
 #endif
             CH_T(6)
@@ -1229,9 +1171,12 @@ static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
     ChainArgs ag = a;
     const long grid = chain2_geometry(ag, C2_NSTRIPS(a.nx), a.nx - (C2_NSTRIPS(a.nx) - 1) * C2_OUTW, ncu * per_cu,
                                       NARROW ? 0 : ctx->chain_reserve, COLS / 64);
-    if (lds > 48 * 1024)
+    static bool lds_set[64] = {};   // per device, once per instantiation (contexts are used from one thread each)
+    if (lds > 48 * 1024 && !lds_set[ctx->device & 63]) {
         RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chain2_kernel<NP, G, START, KT, NARROW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set[ctx->device & 63] = true;
+    }
     hipLaunchKernelGGL((chain2_kernel<NP, G, START, KT, NARROW>), dim3((unsigned)grid), dim3(C2_THREADS), lds, ctx->stream, ag,
                        reinterpret_cast<const RipPlanHeader *>(plan->dev), plan->d_variants, plan->d_k, plan->d_diffs,
                        ctx->guard_band);

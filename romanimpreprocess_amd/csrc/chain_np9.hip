@@ -1,9 +1,6 @@
 // Instantiations of the wave-specialised fused kernel for 9 Legendre planes (chain2_kernel.h).
 #include "chain2_kernel.h"
 
-#ifndef C2_G8_NARROW   // 8 groups, f32 ipc4d: the 256-column form (0); the narrow forms measured slower there (profiles/r03_summary.md)
-#define C2_G8_NARROW 0
-#endif
 #ifndef C2_G16_NARROW   // 16 groups: 2 = 128-column workgroups without K / word rings (three per CU), 0 = the 256-column form
 #define C2_G16_NARROW 2
 #endif
@@ -16,10 +13,11 @@ int rip_launch_chain_np9(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a, 
     // (merged_dq < 0: this CALDIR set's flag words cannot be merged, RipCal)
     if (!ctx->use_chain2 || a.merged_dq < 0) return 1;
     int rc = 1;
+    // (8 / 6 groups with f32 ipc4d: the 256-column form; the narrow forms measured slower there, profiles/r03_summary.md)
     if (k_dtype == RIP_F64) {
         rc = rip_launch_chain2_k64_np9(ctx, plan, a);
     } else {
-        if (a.ngrp == 8) rc = launch_chain2<9, 8, float, C2_G8_NARROW>(ctx, plan, a);
+        if (a.ngrp == 8) rc = launch_chain2<9, 8>(ctx, plan, a);
         if (a.ngrp == 6) rc = launch_chain2<9, 6>(ctx, plan, a);
         if (a.ngrp == 16) rc = launch_chain2<9, 16, float, C2_G16_NARROW>(ctx, plan, a);
     }

@@ -210,7 +210,8 @@ int rip_launch_merge_dq(rip_ctx *ctx, const uint32_t *lin_dq, const uint32_t *fl
 
 int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const float *thr, const uint32_t *sat_dq,
                        const uint8_t *gdq_in, const uint32_t *pdq_in, uint8_t *gdq_out, uint32_t *pdq_out, int G, int ny,
-                       int nx, int backup, int skip_firstn, int dnu_first, const double *dilution) {
+                       int nx, int backup, int skip_firstn, int dnu_first, const double *dilution, hipStream_t stream) {
+    hipStream_t st = stream ? stream : ctx->stream;
     if (G < 1 || G > 64 || backup < 0 || skip_firstn < 0 || skip_firstn > G)
         return rip_fail(ctx, RIP_EINVAL, "saturation flagging: bad group / backup / skip arguments");
     if (nx % 4) return rip_fail(ctx, RIP_EINVAL, "saturation flagging: nx=%d is not a multiple of 4", nx);
@@ -222,12 +223,12 @@ int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const flo
     for (int g = 0; g < 64; ++g) dil.f[g] = (dilution && g < G) ? dilution[g] : 1.0;
     const int use_dil = dilution ? 1 : 0;
     if (data_dtype == RIP_U16)
-        hipLaunchKernelGGL(sat_exceed_kernel<uint16_t>, g1, block, 0, ctx->stream, (const uint16_t *)data, thr, sat_dq, ex, G, npix,
+        hipLaunchKernelGGL(sat_exceed_kernel<uint16_t>, g1, block, 0, st, (const uint16_t *)data, thr, sat_dq, ex, G, npix,
                            skip_firstn, dil, use_dil);
     else
-        hipLaunchKernelGGL(sat_exceed_kernel<float>, g1, block, 0, ctx->stream, (const float *)data, thr, sat_dq, ex, G, npix,
+        hipLaunchKernelGGL(sat_exceed_kernel<float>, g1, block, 0, st, (const float *)data, thr, sat_dq, ex, G, npix,
                            skip_firstn, dil, use_dil);
-    hipLaunchKernelGGL(sat_flags_kernel, dim3((nx / 4 + 255) / 256, ny), block, 0, ctx->stream, ex, gdq_in, pdq_in, gdq_out, pdq_out, G,
+    hipLaunchKernelGGL(sat_flags_kernel, dim3((nx / 4 + 255) / 256, ny), block, 0, st, ex, gdq_in, pdq_in, gdq_out, pdq_out, G,
                        ny, nx, backup, skip_firstn, dnu_first);
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;

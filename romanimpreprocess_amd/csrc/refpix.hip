@@ -312,7 +312,11 @@ int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a) {
     if (a.nx % RIP_CW) return rip_fail(ctx, RIP_EINVAL, "refpix: nx=%d is not a multiple of 128", a.nx);
     if (a.ny < 8) return rip_fail(ctx, RIP_EINVAL, "refpix: ny=%d too small", a.ny);
     const int G = a.ngrp, ny = a.ny, nch = a.nx / RIP_CW;
-    if (ctx->prepass_one && rip_refpix_one_supported(a)) return rip_launch_refpix_one(ctx, a);
+    hipStream_t strm = a.stream ? a.stream : ctx->stream;   // (the overlapped pre-pass: the context's second stream)
+    if (ctx->prepass_form != 0 && rip_refpix_one_supported(a)) {
+        const int form = ctx->prepass_form > 0 ? ctx->prepass_form : (a.background ? 2 : 1);
+        return form == 2 ? rip_launch_refpix_bg(ctx, a) : rip_launch_refpix_one(ctx, a);
+    }
     if (a.amp33) {
         // scratch: lohi (G,ny,2) f32 | SelState[G]
         const size_t lohi_b = (size_t)G * ny * 2 * sizeof(float);
@@ -327,16 +331,16 @@ int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a) {
         const void *had = ctx->ws[13];
         uint32_t *ghist = (uint32_t *)rip_ws(ctx, 13, gh_b);
         if (!ghist) return RIP_ENOMEM;
-        if ((const void *)ghist != had) RIP_HIP(ctx, hipMemsetAsync(ghist, 0, gh_b, ctx->stream));
+        if ((const void *)ghist != had) RIP_HIP(ctx, hipMemsetAsync(ghist, 0, gh_b, strm));
         const uint32_t n = (uint32_t)ny * RIP_CW;
-        hipLaunchKernelGGL(amp33_rows_kernel, dim3((unsigned)((G * ny + 3) / 4)), dim3(256), 0, ctx->stream, a.amp33,
+        hipLaunchKernelGGL(amp33_rows_kernel, dim3((unsigned)((G * ny + 3) / 4)), dim3(256), 0, strm, a.amp33,
                            a.amp33_med, lohi, ny, G * ny);
         const int chunk = 8192;
         const unsigned nblk = (unsigned)((n + chunk - 1) / chunk);
         for (int level = 0; level < 3; ++level) {
-            hipLaunchKernelGGL(sel_hist_kernel, dim3(nblk, G), dim3(256), 0, ctx->stream, a.amp33, a.amp33_med, st,
+            hipLaunchKernelGGL(sel_hist_kernel, dim3(nblk, G), dim3(256), 0, strm, a.amp33, a.amp33_med, st,
                                ghist, ny, level, chunk);
-            hipLaunchKernelGGL(sel_scan_kernel, dim3(G, 2), dim3(256), 0, ctx->stream, st, ghist, level, n);
+            hipLaunchKernelGGL(sel_scan_kernel, dim3(G, 2), dim3(256), 0, strm, st, ghist, level, n);
         }
         int npow2 = 1;
         while (npow2 < ny) npow2 <<= 1;
@@ -344,18 +348,18 @@ int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a) {
         if (lds > 48 * 1024)
             RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rowcorr_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(rowcorr_kernel, dim3(G), dim3(1024), lds, ctx->stream, st, lohi, a.slope, a.rowcorr,
+        hipLaunchKernelGGL(rowcorr_kernel, dim3(G), dim3(1024), lds, strm, st, lohi, a.slope, a.rowcorr,
                            a.rowcorr_t, (float *)nullptr, (float *)nullptr, ny, npow2);
     } else {
         // no reference output in the read file: the row step is the identity
-        RIP_HIP(ctx, hipMemsetAsync(a.rowcorr, 0, (size_t)G * ny * sizeof(double), ctx->stream));
-        if (a.rowcorr_t) RIP_HIP(ctx, hipMemsetAsync(a.rowcorr_t, 0, (size_t)G * ny * sizeof(double), ctx->stream));
+        RIP_HIP(ctx, hipMemsetAsync(a.rowcorr, 0, (size_t)G * ny * sizeof(double), strm));
+        if (a.rowcorr_t) RIP_HIP(ctx, hipMemsetAsync(a.rowcorr_t, 0, (size_t)G * ny * sizeof(double), strm));
     }
     if (a.data_dtype == RIP_U16)
-        hipLaunchKernelGGL(chan_kernel<uint16_t>, dim3(nch, G), dim3(1024), 0, ctx->stream, (const uint16_t *)a.data,
+        hipLaunchKernelGGL(chan_kernel<uint16_t>, dim3(nch, G), dim3(1024), 0, strm, (const uint16_t *)a.data,
                            a.dark_data, a.rowcorr, a.lines_override, a.lines, (float *)nullptr, ny, a.nx);
     else
-        hipLaunchKernelGGL(chan_kernel<float>, dim3(nch, G), dim3(1024), 0, ctx->stream, (const float *)a.data,
+        hipLaunchKernelGGL(chan_kernel<float>, dim3(nch, G), dim3(1024), 0, strm, (const float *)a.data,
                            a.dark_data, a.rowcorr, a.lines_override, a.lines, (float *)nullptr, ny, a.nx);
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;

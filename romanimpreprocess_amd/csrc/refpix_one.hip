@@ -32,6 +32,7 @@
 // poll with sc1 loads, pass a workgroup barrier and read with sc1 loads.
 #include "rip_common.h"
 #include "refpix_keys.h"
+#include <string.h>
 
 namespace {
 
@@ -81,21 +82,30 @@ __device__ __forceinline__ uint32_t med3u(uint32_t a, uint32_t b, uint32_t c) {
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a < b ? b : a; }
 
-// value of lane (lane ^ J): DPP inside a row of 16, ds_swizzle inside 32 lanes (LDS crossbar, no memory), ds_bpermute across
+// value of lane (lane ^ J), vector-ALU instructions only (ds_swizzle / ds_bpermute go through the LDS pipe, one per CU: with 16
+// waves exchanging lanes all the time it, not the four vector pipes, set the pace -- measured 2.5 x): DPP inside a row of 16
+// lanes, the gfx950 row / half swaps across rows
 template <int J>
 __device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane) {
-    if constexpr (J == 1)
+    if constexpr (J == 1) {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-    else if constexpr (J == 2)
+    } else if constexpr (J == 2) {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-    else if constexpr (J == 4)
-        return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);                    // bit mode: xor 4
-    else if constexpr (J == 8)
+    } else if constexpr (J == 4) {
+        // lanes with bit 2 clear (banks 0, 2) take lane + 4 (row_shl:4), the others lane - 4 (row_shr:4)
+        const int p = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0x5, false);
+        return (uint32_t)__builtin_amdgcn_update_dpp(p, (int)v, 0x114, 0xf, 0xA, false);
+    } else if constexpr (J == 8) {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);  // row_ror:8
-    else if constexpr (J == 16)
-        return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                    // bit mode: xor 16
-    else
-        return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)v);
+    } else if constexpr (J == 16) {
+        // v_permlane16_swap: odd rows of the first operand <-> even rows of the second: {[r0 r0 r2 r2], [r1 r1 r3 r3]}
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    } else {
+        // v_permlane32_swap: upper half of the first operand <-> lower half of the second: {[lo lo], [hi hi]}
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (lane & 32) ? r[0] : r[1];
+    }
 }
 template <int J>
 __device__ __forceinline__ uint32_t cmpx(uint32_t v, int lane, bool keep_min) {
@@ -132,22 +142,21 @@ __device__ __forceinline__ uint32_t merge64(uint32_t v, int lane, bool desc = fa
 __device__ __forceinline__ uint32_t rev64(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute((63 - lane) << 2, (int)v);
 }
-__device__ __forceinline__ uint32_t wave_umax(uint32_t v, int lane) {
-    v = umax(v, lane_xor<1>(v, lane));
-    v = umax(v, lane_xor<2>(v, lane));
-    v = umax(v, lane_xor<4>(v, lane));
-    v = umax(v, lane_xor<8>(v, lane));
-    v = umax(v, lane_xor<16>(v, lane));
-    return umax(v, lane_xor<32>(v, lane));
+// maximum / minimum over the wave (returned to every lane): running maximum along each row of 16 lanes by DPP shifts (lanes
+// without a source keep their own value), the row results passed on by the two row broadcasts; lane 63 holds the result
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_reduce(uint32_t v, int lane) {
+    auto op = [](uint32_t x, int y) { return MAX ? umax(x, (uint32_t)y) : umin(x, (uint32_t)y); };
+    v = op(v, __builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = op(v, __builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = op(v, __builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = op(v, __builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8: lane 15 of a row = its result
+    v = op(v, __builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
+    v = op(v, __builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ uint32_t wave_umin(uint32_t v, int lane) {
-    v = umin(v, lane_xor<1>(v, lane));
-    v = umin(v, lane_xor<2>(v, lane));
-    v = umin(v, lane_xor<4>(v, lane));
-    v = umin(v, lane_xor<8>(v, lane));
-    v = umin(v, lane_xor<16>(v, lane));
-    return umin(v, lane_xor<32>(v, lane));
-}
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v, int lane) { return wave_reduce<true>(v, lane); }
+__device__ __forceinline__ uint32_t wave_umin(uint32_t v, int lane) { return wave_reduce<false>(v, lane); }
 
 // One monotone (sorted either way) slot of 64 keys into the LDS histogram of a selection level: keys whose bits above the
 // level's digit equal the prefix's; lanes with the same digit are neighbours, the first of a run adds the run's length.
@@ -156,8 +165,9 @@ __device__ __forceinline__ void hist_slot(uint32_t key, bool live, int lv, uint3
     const int shift = sel_shift(lv), bits = sel_bits(lv), above = shift + bits;
     const bool inr = live && (above >= 32 || ((key ^ prefix) >> above) == 0);
     const uint32_t bin = inr ? ((key >> shift) & ((1u << bits) - 1u)) : 0xffffu;
-    const uint32_t prev = (uint32_t)__shfl_up((int)bin, 1, 64);
-    const bool head = inr && (lane == 0 || prev != bin);
+    // (the first lane of every row of 16 starts a run of its own: a DPP shift does not cross rows)
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~bin, (int)bin, 0x111, 0xf, 0xf, false);   // row_shr:1
+    const bool head = inr && prev != bin;
     const unsigned long long stop = __ballot(head || !inr);
     if (head) {
         const unsigned long long m = (stop >> 1) >> lane;   // bit t: lane + 1 + t ends the run
@@ -216,6 +226,104 @@ __device__ __forceinline__ void sort128(uint32_t k0, uint32_t k1, int lane, uint
     lo = merge64(umin(k0, k1), lane);
     hi = merge64(umax(k0, k1), lane);
 }
+
+// np.median of 4 x 128 keys: x[row][slot], rows 0 and 2 sorted ascending (slot 0: ranks 0..63 in lane order), rows 1 and 3
+// descending.  Rows (0, 1) -> P: 256 keys ascending in four slots; rows (2, 3) -> Q: descending.  Flip stage of the bitonic merge:
+// X[i] against Y[127 - i] (Y is held descending), the minima are the 128 smallest: a bitonic sequence over two slots, sorted by the
+// half-cleaner between the slots and the 64-lane merges.  Then P[i] against Q[255 - i]: the maximum of the minima is rank 255, the
+// minimum of the maxima rank 256.
+__device__ __forceinline__ void merge_rows(const uint32_t (&xa)[2], const uint32_t (&yd)[2], bool desc, uint32_t (&out)[4], int lane) {
+    const uint32_t l0 = umin(xa[0], yd[0]), l1 = umin(xa[1], yd[1]);
+    const uint32_t h0 = umax(xa[0], yd[0]), h1 = umax(xa[1], yd[1]);
+    const uint32_t la = umin(l0, l1), lb = umax(l0, l1), ha = umin(h0, h1), hb = umax(h0, h1);
+    if (!desc) {
+        out[0] = merge64(la, lane), out[1] = merge64(lb, lane), out[2] = merge64(ha, lane), out[3] = merge64(hb, lane);
+    } else {
+        out[0] = merge64(hb, lane, true), out[1] = merge64(ha, lane, true), out[2] = merge64(lb, lane, true),
+        out[3] = merge64(la, lane, true);
+    }
+}
+__device__ __forceinline__ float chan_median(const uint32_t (&x)[4][2], int lane) {
+    uint32_t P[4], Q[4];
+    merge_rows(x[0], x[1], false, P, lane);
+    merge_rows(x[2], x[3], true, Q, lane);
+    uint32_t lo = umin(P[0], Q[0]), hi = umax(P[0], Q[0]);
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+        lo = umax(lo, umin(P[s], Q[s]));
+        hi = umin(hi, umax(P[s], Q[s]));
+    }
+    lo = wave_umax(lo, lane);
+    hi = wave_umin(hi, lane);
+    return (key2f(lo) + key2f(hi)) * 0.5f;
+}
+// the line through (1.5, b), (ny - 2.5, t) (reference_subtraction.py:57-60; DESIGN.md "channel line fit")
+__device__ __forceinline__ void store_line(const R1Args &a, int g, int nch, int ch, float b, float t) {
+    const double m = ((double)t - (double)b) / (double)(a.ny - 4);
+    const double c = (double)b - 1.5 * m;
+    a.lines[((size_t)g * nch + ch) * 2] = m;
+    a.lines[((size_t)g * nch + ch) * 2 + 1] = c;
+}
+
+// Row tables of one group from its row medians (refmed[k]: row tid + 1024 k, already minus the block's median): ctr = their
+// np.median by the three-level selection inside the workgroup (histograms in LDS, zero on entry and on return),
+// rowcorr = slope * f64(f32(refmed - ctr)) (reference_subtraction.py:115-123), and the corrections of the 4 + 4 rows the channel
+// step reads in rc8.  All threads of the workgroup call; ends with a barrier.
+__device__ __forceinline__ void row_tables(const float (&refmed)[R1_NV], const R1Args &a, int g, uint32_t (*hist)[SEL_BINS],
+                                           uint32_t (*wtot)[8], uint32_t (*sel)[2], double *rc8) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ny = a.ny;
+    uint32_t rk[R1_NV];
+    int nlive[R1_NV];   // live lanes of the slot in this wave (rows tid + 1024 k: a slot's rows are consecutive)
+#pragma unroll
+    for (int k = 0; k < R1_NV; ++k) {
+        const int r = tid + R1_THREADS * k;
+        const int first = (w << 6) + R1_THREADS * k;   // row of lane 0
+        nlive[k] = min(max(ny - first, 0), 64);
+        // sorted ascending, the lanes without a row at the top (any key equal to the filler is interchangeable with it)
+        rk[k] = sort64(r < ny ? f2key(refmed[k]) : 0xffffffffu, lane);
+    }
+    uint32_t pre2[2] = {0u, 0u}, rank2[2] = {(uint32_t)((ny & 1) ? ny / 2 : ny / 2 - 1), (uint32_t)(ny / 2)};
+#pragma unroll 1
+    for (int lv = 0; lv < 3; ++lv) {
+        const bool same = pre2[0] == pre2[1];
+#pragma unroll
+        for (int k = 0; k < R1_NV; ++k) {
+            if (nlive[k] == 0) continue;
+            hist_slot(rk[k], lane < nlive[k], lv, pre2[0], hist[0], lane);
+            if (!same) hist_slot(rk[k], lane < nlive[k], lv, pre2[1], hist[1], lane);
+        }
+        __syncthreads();
+        {
+            const int q = tid >> 9, t = tid & 511;
+            uint32_t *src = hist[same ? 0 : q] + 4 * t;
+            uint32_t c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = src[k];
+            scan_find(c, rank2[q], wtot, sel, tid);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            pre2[q] |= sel[q][0] << sel_shift(lv);
+            rank2[q] = sel[q][1];
+        }
+        for (int i = tid; i < 2 * SEL_BINS; i += R1_THREADS) (&hist[0][0])[i] = 0;
+        __syncthreads();
+    }
+    const float ctr = (key2f(pre2[0]) + key2f(pre2[1])) * 0.5f;
+#pragma unroll
+    for (int k = 0; k < R1_NV; ++k) {
+        const int r = tid + R1_THREADS * k;
+        if (r < ny) {
+            const double v = a.slope * (double)(refmed[k] - ctr);
+            a.rowcorr[(size_t)g * ny + r] = v;
+            if (a.rowcorr_t) a.rowcorr_t[(size_t)r * a.G + g] = v;   // [row][group]: one scalar load per row in the fused kernel
+            if (r < 4) rc8[r] = v;
+            if (r >= ny - 4) rc8[4 + r - (ny - 4)] = v;
+        }
+    }
+    __syncthreads();
+}
+
 
 #define R1_STAMP(k)                                                                                    \
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();
@@ -357,62 +465,15 @@ __global__ __launch_bounds__(R1_THREADS) void refpix_one_kernel(R1Args a) {
 
     // ---- S2 (workgroup 0 of the group): row medians minus M, their median, the row table
     float refmed[R1_NV];
-    uint32_t rk[R1_NV];
-    int nlive[R1_NV];   // live lanes of the slot in this wave (rows tid + 1024 k: a slot's rows are consecutive)
 #pragma unroll
     for (int k = 0; k < R1_NV; ++k) {
         const int r = tid + R1_THREADS * k;
-        const bool ok = r < ny;
-        const int rr = ok ? r : ny - 1;
+        const int rr = r < ny ? r : ny - 1;
         const float lo = key2f(ld_sc1(a.lo + (size_t)g * ny + rr)) - M;
         const float hi = key2f(ld_sc1(a.hi + (size_t)g * ny + rr)) - M;
         refmed[k] = (lo + hi) * 0.5f;
-        const int first = (w << 6) + R1_THREADS * k;   // row of lane 0
-        nlive[k] = min(max(ny - first, 0), 64);
-        // sorted ascending, the lanes without a row at the top (any key equal to the filler is interchangeable with it)
-        rk[k] = sort64(ok ? f2key(refmed[k]) : 0xffffffffu, lane);
     }
-    uint32_t pre2[2] = {0u, 0u}, rank2[2] = {(uint32_t)((ny & 1) ? ny / 2 : ny / 2 - 1), (uint32_t)(ny / 2)};
-#pragma unroll 1
-    for (int lv = 0; lv < 3; ++lv) {
-        const bool same = pre2[0] == pre2[1];
-#pragma unroll
-        for (int k = 0; k < R1_NV; ++k) {
-            if (nlive[k] == 0) continue;
-            hist_slot(rk[k], lane < nlive[k], lv, pre2[0], hist[0], lane);
-            if (!same) hist_slot(rk[k], lane < nlive[k], lv, pre2[1], hist[1], lane);
-        }
-        __syncthreads();
-        {
-            const int q = tid >> 9, t = tid & 511;
-            uint32_t *src = hist[same ? 0 : q] + 4 * t;
-            uint32_t c[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) c[k] = src[k];
-            scan_find(c, rank2[q], wtot, sel, tid);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            pre2[q] |= sel[q][0] << sel_shift(lv);
-            rank2[q] = sel[q][1];
-        }
-        for (int i = tid; i < 2 * SEL_BINS; i += R1_THREADS) (&hist[0][0])[i] = 0;
-        __syncthreads();
-    }
-    R1_STAMP(12)
-    const float ctr = (key2f(pre2[0]) + key2f(pre2[1])) * 0.5f;
-#pragma unroll
-    for (int k = 0; k < R1_NV; ++k) {
-        const int r = tid + R1_THREADS * k;
-        if (r < ny) {
-            const double v = a.slope * (double)(refmed[k] - ctr);
-            a.rowcorr[(size_t)g * ny + r] = v;
-            if (a.rowcorr_t) a.rowcorr_t[(size_t)r * a.G + g] = v;   // [row][group]: one scalar load per row in the fused kernel
-            if (r < 4) rc8[r] = v;
-            if (r >= ny - 4) rc8[4 + r - (ny - 4)] = v;
-        }
-    }
-    __syncthreads();
+    row_tables(refmed, a, g, hist, wtot, sel, rc8);
     R1_STAMP(13)
 
     // ---- S3: channel lines.  A wave per channel: medians of the 4 x 128 row-corrected values of its bottom and top rows
@@ -436,42 +497,166 @@ __global__ __launch_bounds__(R1_THREADS) void refpix_one_kernel(R1Args a) {
                     x[jj][s] = f2key((float)((double)v - rc));
                 }
             }
-            // rows (0, 1) -> P: 256 keys ascending in four slots; rows (2, 3) -> Q: descending.  Flip stage of the bitonic merge:
-            // X[i] against Y[127 - i] (Y is stored descending), the minima are the 128 smallest: a bitonic sequence over two
-            // slots, sorted by the half-cleaner between the slots and the 64-lane merges.
-            uint32_t P[4], Q[4];
-            auto merge_rows = [&](const uint32_t (&xa)[2], const uint32_t (&yd)[2], bool desc, uint32_t (&out)[4]) {
-                const uint32_t l0 = umin(xa[0], yd[0]), l1 = umin(xa[1], yd[1]);
-                const uint32_t h0 = umax(xa[0], yd[0]), h1 = umax(xa[1], yd[1]);
-                const uint32_t la = umin(l0, l1), lb = umax(l0, l1), ha = umin(h0, h1), hb = umax(h0, h1);
-                if (!desc) {
-                    out[0] = merge64(la, lane), out[1] = merge64(lb, lane), out[2] = merge64(ha, lane), out[3] = merge64(hb, lane);
-                } else {
-                    out[0] = merge64(hb, lane, true), out[1] = merge64(ha, lane, true), out[2] = merge64(lb, lane, true),
-                    out[3] = merge64(la, lane, true);
-                }
-            };
-            merge_rows(x[0], x[1], false, P);
-            merge_rows(x[2], x[3], true, Q);
-            // P[i] against Q[255 - i]: the maximum of the minima is rank 255, the minimum of the maxima rank 256
-            uint32_t lo = umin(P[0], Q[0]), hi = umax(P[0], Q[0]);
-#pragma unroll
-            for (int s = 1; s < 4; ++s) {
-                lo = umax(lo, umin(P[s], Q[s]));
-                hi = umin(hi, umax(P[s], Q[s]));
-            }
-            lo = wave_umax(lo, lane);
-            hi = wave_umin(hi, lane);
-            bt[half] = (key2f(lo) + key2f(hi)) * 0.5f;
+            bt[half] = chan_median(x, lane);
         }
-        if (lane == 0) {
-            const double m = ((double)bt[1] - (double)bt[0]) / (double)(ny - 4);
-            const double c = (double)bt[0] - 1.5 * m;
-            a.lines[((size_t)g * nch + ch) * 2] = m;
-            a.lines[((size_t)g * nch + ch) * 2 + 1] = c;
-        }
+        if (lane == 0) store_line(a, g, nch, ch, bt[0], bt[1]);
     }
     R1_STAMP(14)
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same tables by ONE WORKGROUP PER GROUP, no dependence between workgroups: the form for the overlapped pre-pass.  The fused
+// kernel's grid leaves a few workgroup slots free (chain2_geometry: 504 of 512 on 4096 x 4096 frames, at no cost -- the kernel
+// is not bound by its steps); the pre-pass of the NEXT ramp, launched on the second stream, runs in those slots beside it: a
+// workgroup of 1024 threads at <= 64 registers and 50 KB of LDS fits next to one workgroup of the fused kernel.  It may take as
+// long as the fused kernel does (0.85 ms), so it simply walks its group's 4096 rows three times (row medians + level 0 of the
+// selection from the sorted rows; levels 1 and 2 from the re-read values, whose few matching lanes add to the LDS histogram one by
+// one), the row medians stay in LDS, then row_tables and the channel medians (the rows sorted after the row correction).
+__device__ __forceinline__ void hist_any(uint32_t key, int lv, uint32_t prefix, uint32_t *h, int lane) {
+    const int shift = sel_shift(lv), bits = sel_bits(lv), above = shift + bits;
+    const bool inr = ((key ^ prefix) >> above) == 0;
+    const unsigned long long m = __ballot(inr);
+    if (!m) return;
+    const uint32_t bin = (key >> shift) & ((1u << bits) - 1u);
+    const int fl = __ffsll((long long)m) - 1;
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, fl);
+    if (__ballot(inr && bin == b0) == m) {   // one bin for the whole wave (constant blocks: no 64-way contention)
+        if (lane == fl) atomicAdd(&h[b0], (uint32_t)__popcll(m));
+    } else if (inr) {
+        atomicAdd(&h[bin], 1u);
+    }
+}
+
+template <typename DT>
+__global__ __launch_bounds__(R1_THREADS, 8) void refpix_bg_kernel(R1Args a) {
+    __shared__ uint32_t hist[2][SEL_BINS];
+    __shared__ uint32_t wtot[2][8];
+    __shared__ uint32_t sel[2][2];
+    __shared__ uint32_t lo_s[R1_NV * R1_THREADS], hi_s[R1_NV * R1_THREADS];
+    __shared__ double rc8[8];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = (int)blockIdx.x;
+    const int ny = a.ny, nx = a.nx, nch = nx / RIP_CW;
+    for (int i = tid; i < 2 * SEL_BINS; i += R1_THREADS) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    const uint16_t *ap = a.amp33 + (size_t)g * ny * RIP_CW;
+    // RB rows of this wave at a time (rows w + 16 i): all their loads first -- a load takes a microsecond or two beside the fused
+    // kernel's traffic -- then RB independent chains of arithmetic (the lane exchanges of the sorting networks overlap)
+    constexpr int RB = 4;
+    auto batch_keys = [&](int rb, uint32_t (&k)[RB][2], bool (&ok)[RB]) {
+        uint32_t raw[RB][2];
+        float md[RB][2];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = rb + i * R1_WAVES;
+            ok[i] = r < ny;
+            const size_t o = (size_t)(ok[i] ? r : ny - 1) * RIP_CW + lane;
+            raw[i][0] = ap[o], raw[i][1] = ap[o + 64];
+            md[i][0] = a.med[o], md[i][1] = a.med[o + 64];
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            k[i][0] = f2key((float)raw[i][0] - md[i][0]);
+            k[i][1] = f2key((float)raw[i][1] - md[i][1]);
+        }
+    };
+    // ---- pass 1: rows w, w + 16, ...: middle elements into LDS, level 0 of the selection from the sorted keys
+    for (int rb = w; rb < ny; rb += RB * R1_WAVES) {
+        uint32_t k[RB][2];
+        bool ok[RB];
+        batch_keys(rb, k, ok);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            k[i][0] = sort64(k[i][0], lane);
+            k[i][1] = sort64(k[i][1], lane);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const uint32_t k1r = rev64(k[i][1], lane);
+            const uint32_t lo = wave_umax(umin(k[i][0], k1r), lane), hi = wave_umin(umax(k[i][0], k1r), lane);
+            if (lane == 0 && ok[i]) lo_s[rb + i * R1_WAVES] = lo, hi_s[rb + i * R1_WAVES] = hi;
+            hist_slot(k[i][0], ok[i], 0, 0u, hist[0], lane);
+            hist_slot(k[i][1], ok[i], 0, 0u, hist[0], lane);
+        }
+    }
+    __syncthreads();
+    const uint32_t n = (uint32_t)ny * RIP_CW;
+    uint32_t prefix[2] = {0u, 0u}, rank[2] = {n / 2 - 1, n / 2};
+#pragma unroll 1
+    for (int lv = 0; lv < 3; ++lv) {
+        const bool same = prefix[0] == prefix[1];
+        if (lv > 0) {
+            for (int rb = w; rb < ny; rb += RB * R1_WAVES) {
+                uint32_t k[RB][2];
+                bool ok[RB];
+                batch_keys(rb, k, ok);
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    if (!ok[i]) continue;
+                    hist_any(k[i][0], lv, prefix[0], hist[0], lane);
+                    hist_any(k[i][1], lv, prefix[0], hist[0], lane);
+                    if (!same) {
+                        hist_any(k[i][0], lv, prefix[1], hist[1], lane);
+                        hist_any(k[i][1], lv, prefix[1], hist[1], lane);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        {
+            const int q = tid >> 9, t = tid & 511;
+            uint32_t *src = hist[same ? 0 : q] + 4 * t;
+            uint32_t c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = src[k];
+            scan_find(c, rank[q], wtot, sel, tid);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            prefix[q] |= sel[q][0] << sel_shift(lv);
+            rank[q] = sel[q][1];
+        }
+        for (int i = tid; i < 2 * SEL_BINS; i += R1_THREADS) (&hist[0][0])[i] = 0;
+        __syncthreads();
+    }
+    const float M = (key2f(prefix[0]) + key2f(prefix[1])) * 0.5f;   // np.median of the block
+    float refmed[R1_NV];
+#pragma unroll
+    for (int k = 0; k < R1_NV; ++k) {
+        const int r = tid + R1_THREADS * k;
+        const int rr = r < ny ? r : ny - 1;
+        refmed[k] = ((key2f(lo_s[rr]) - M) + (key2f(hi_s[rr]) - M)) * 0.5f;
+    }
+    row_tables(refmed, a, g, hist, wtot, sel, rc8);
+    if (a.lines_override) {
+        for (int i = tid; i < nch * 2; i += R1_THREADS) a.lines[(size_t)g * nch * 2 + i] = a.lines_override[(size_t)g * nch * 2 + i];
+        return;
+    }
+    // ---- channel lines: a wave per channel, its 4 + 4 rows row-corrected, sorted (odd rows descending) and merged
+    const DT *dp = (const DT *)a.data;
+    for (int ch = w; ch < nch; ch += R1_WAVES) {
+        float bt[2];
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            uint32_t x[4][2];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = half * 4 + jj, row = j < 4 ? j : ny - 8 + j;
+                const size_t idx = ((size_t)g * ny + row) * nx + (size_t)ch * RIP_CW + lane;
+                const double rc = rc8[j];
+                const float v0 = (float)dp[idx] - a.dark[idx], v1 = (float)dp[idx + 64] - a.dark[idx + 64];
+                uint32_t k0 = sort64(f2key((float)((double)v0 - rc)), lane);
+                uint32_t k1 = rev64(sort64(f2key((float)((double)v1 - rc)), lane), lane);
+                const bool desc = jj & 1;
+                // ascending: slot 0 = the 64 smallest; descending: slot 0 = the 64 largest, largest first
+                x[jj][0] = merge64(desc ? umax(k0, k1) : umin(k0, k1), lane, desc);
+                x[jj][1] = merge64(desc ? umin(k0, k1) : umax(k0, k1), lane, desc);
+            }
+            bt[half] = chan_median(x, lane);
+        }
+        if (lane == 0) store_line(a, g, nch, ch, bt[0], bt[1]);
+    }
 }
 
 }  // namespace
@@ -484,6 +669,7 @@ bool rip_refpix_one_supported(const RefpixArgs &a) {
 }
 
 int rip_launch_refpix_one(rip_ctx *ctx, const RefpixArgs &a) {
+    hipStream_t st = a.stream ? a.stream : ctx->stream;
     if (!rip_refpix_one_supported(a)) return rip_fail(ctx, RIP_EINVAL, "refpix: frame not covered by the single-launch pre-pass");
     const int G = a.ngrp, ny = a.ny, nch = a.nx / RIP_CW;
     const int B = (ny + R1_ROWS - 1) / R1_ROWS;
@@ -494,7 +680,7 @@ int rip_launch_refpix_one(rip_ctx *ctx, const RefpixArgs &a) {
     const void *had = ctx->ws[14];
     char *z = (char *)rip_ws(ctx, 14, zero_b);
     if (!z) return RIP_ENOMEM;
-    if ((const void *)z != had) RIP_HIP(ctx, hipMemsetAsync(z, 0, zero_b, ctx->stream));
+    if ((const void *)z != had) RIP_HIP(ctx, hipMemsetAsync(z, 0, zero_b, st));
     const size_t lohi_b = ((size_t)G * ny * 4 + 255) / 256 * 256;
     const size_t chs_b = (size_t)G * nch * 8 * RIP_CW * 4;
     char *s = (char *)rip_ws(ctx, 15, 2 * lohi_b + chs_b);
@@ -521,9 +707,36 @@ int rip_launch_refpix_one(rip_ctx *ctx, const RefpixArgs &a) {
     r.B = B;
     r.stamps = (unsigned long long *)ctx->prepass_stamps;
     if (a.data_dtype == RIP_U16)
-        hipLaunchKernelGGL(refpix_one_kernel<uint16_t>, dim3((unsigned)(G * B)), dim3(R1_THREADS), 0, ctx->stream, r);
+        hipLaunchKernelGGL(refpix_one_kernel<uint16_t>, dim3((unsigned)(G * B)), dim3(R1_THREADS), 0, st, r);
     else
-        hipLaunchKernelGGL(refpix_one_kernel<float>, dim3((unsigned)(G * B)), dim3(R1_THREADS), 0, ctx->stream, r);
+        hipLaunchKernelGGL(refpix_one_kernel<float>, dim3((unsigned)(G * B)), dim3(R1_THREADS), 0, st, r);
+    RIP_HIP(ctx, hipGetLastError());
+    return RIP_OK;
+}
+
+// one workgroup per group, no dependence between them (the overlapped pre-pass: see refpix_bg_kernel)
+int rip_launch_refpix_bg(rip_ctx *ctx, const RefpixArgs &a) {
+    hipStream_t st = a.stream ? a.stream : ctx->stream;
+    if (!rip_refpix_one_supported(a)) return rip_fail(ctx, RIP_EINVAL, "refpix: frame not covered by the single-launch pre-pass");
+    R1Args r;
+    memset(&r, 0, sizeof r);
+    r.data = a.data;
+    r.dark = a.dark_data;
+    r.amp33 = a.amp33;
+    r.med = a.amp33_med;
+    r.lines_override = a.lines_override;
+    r.rowcorr = a.rowcorr;
+    r.rowcorr_t = a.rowcorr_t;
+    r.lines = a.lines;
+    r.slope = a.slope;
+    r.ny = a.ny;
+    r.nx = a.nx;
+    r.G = a.ngrp;
+    r.B = 1;
+    if (a.data_dtype == RIP_U16)
+        hipLaunchKernelGGL(refpix_bg_kernel<uint16_t>, dim3((unsigned)a.ngrp), dim3(R1_THREADS), 0, st, r);
+    else
+        hipLaunchKernelGGL(refpix_bg_kernel<float>, dim3((unsigned)a.ngrp), dim3(R1_THREADS), 0, st, r);
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
 }

@@ -126,10 +126,6 @@ struct rip_ctx {
     int parity = 0;
     bool use_overlap = true;
     bool use_chain2 = true;  // wave-specialised fused kernel where it applies
-    // (option "chain3" of rounds 1-2, still accepted, without effect: the wave-private fused kernel was removed in round 3 -- the
-    // wave-specialised kernel is the faster one in every configuration: 0.85 against 0.95 ms for f32, 1.17 against 1.38 ms for f64
-    // ipc4d, 2.47 against 3.45 ms for f64 ipc4d x 16 groups, profiles/r03_summary.md)
-    int use_chain3 = 2;
     int last_form = 0;       // diagnostic: how the last rip_calibrate ran (0 stage kernels, 2 the fused kernel; 1 and 3 were the general and the wave-private fused kernels of rounds 1-2)
     std::string err;
     std::vector<RipCal> cals;
@@ -148,7 +144,11 @@ struct rip_ctx {
     size_t ws_bytes[16] = {};
     void *prepass_stamps = nullptr;   // diagnostic: device buffer of 16 clock stamps per workgroup of the single-launch pre-pass
     int chain_reserve = 8;      // workgroup slots the 256-column fused kernel leaves free (the next ramp's pre-pass runs in them)
-    bool prepass_one = true;    // reference-pixel tables by the single-launch kernel (refpix_one.hip) where it covers the frame
+    // reference-pixel tables (frames the single-launch kernels cover: up to 4096 rows, with a reference output): -1 = by situation
+    // (a pre-pass that runs beside the previous ramp's fused kernel: one workgroup per group in the slots that kernel leaves free,
+    // form 2; a pre-pass in front of its own ramp: the multi-workgroup single launch, form 1); 0 = the multi-launch kernels of
+    // refpix.hip (any frame), 1, 2 = that form always
+    int prepass_form = -1;
     // rip_calibrate_batch (batch.hip): download stream and the two sets of device buffers, kept between calls
     hipStream_t stream3 = nullptr;
     void *batch_buf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -302,8 +302,11 @@ struct RefpixArgs {
     double *rowcorr_t;  // out (ny, G): the same values, row-major (may be null)
     double *lines;    // out (G, nch, 2)
     int ny, nx, ngrp;
+    int background = 0;   // 1: launched beside the previous ramp's fused kernel (second stream)
+    hipStream_t stream = nullptr;   // where the launches go (null: the context's main stream)
 };
 int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a);
+int rip_launch_refpix_bg(rip_ctx *ctx, const RefpixArgs &a);
 // refpix_one.hip: the same tables in one launch (frames up to 4096 rows with a reference output)
 bool rip_refpix_one_supported(const RefpixArgs &a);
 int rip_launch_refpix_one(rip_ctx *ctx, const RefpixArgs &a);
@@ -327,4 +330,5 @@ int rip_launch_merge_dq(rip_ctx *ctx, const uint32_t *lin_dq, const uint32_t *fl
 // dq-init + saturation flagging (misc.hip): gdq_in / pdq_in may be null (= zeros)
 int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const float *thr, const uint32_t *sat_dq,
                        const uint8_t *gdq_in, const uint32_t *pdq_in, uint8_t *gdq_out, uint32_t *pdq_out, int G, int ny,
-                       int nx, int backup, int skip_firstn, int dnu_first, const double *dilution = nullptr);
+                       int nx, int backup, int skip_firstn, int dnu_first, const double *dilution = nullptr,
+                       hipStream_t stream = nullptr);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of library options on the bench workload: tools/gpu_checks/ab_options.sh "overlap=0" "prepass_one=0" ...
+# same-box A/B of library options on the bench workload: tools/gpu_checks/ab_options.sh "overlap=0" "prepass_form=0" ...
 # (each argument is one configuration: comma-separated OPTION=VALUE pairs, "-" = defaults; ENV:NAME=VALUE sets an environment
 # variable of the bench process instead); two rounds, alternating
 for round in 1 2; do

@@ -18,8 +18,6 @@ KDT = np.float64 if os.environ.get("IPC64") == "1" else np.float32  # IPC64=1: f
 cal, ramp = synth.make_tiled_inputs(N, N, read_pattern=rp, p_order=8, seed=1, strip_rows=64, ipc_dtype=KDT)
 cb = pipeline.Calibrator(device=0)
 cb.ctx.set_option("chain2", int(os.environ.get("CHAIN2", "1")))
-if "CHAIN3" in os.environ:   # unset: the library default (0 = wave-specialised kernel)
-    cb.ctx.set_option("chain3", int(os.environ["CHAIN3"]))
 cb.load_caldir(0, cal)
 pid, meta = cb.plan_for(rp, ramp["frame_time"])
 dev = torch.device("cuda", 0)

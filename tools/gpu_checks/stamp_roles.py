@@ -31,7 +31,6 @@ lib.rip_chain_stamps.restype = C.c_int
 lib.rip_chain_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 lib.rip_chain_stamps_n.restype = C.c_int
 lib.rip_chain_stamps_n.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
-cb.ctx.set_option("chain3", 0)
 cb.load_caldir(0, cal)
 pid, meta = cb.plan_for(rp, ramp["frame_time"])
 dev = torch.device("cuda", 0)
