@@ -252,9 +252,9 @@ int rip_stage_refpix_channel(rip_ctx *ctx, float *image, int ny, int width, int 
 /* The reference-pixel TABLES the chain applies to a ramp (gen_cal_image.py:531-556 through reference_subtraction.py:16-125,
    with the reference output: use_ref_channel=True, slope given), from host arrays: data (ngrp,ny,nx) u16|f32, dark (>= ngrp,ny,nx)
    f32, amp33 (ngrp,ny,128) u16, amp33_med (ny,128) f32 -> rowcorr (ngrp,ny) f64 = slope * f64(f32(row median - ctr)) and
-   lines (ngrp,nx/128,2) f64 = (m, c) of the science channels.  form: 1 = one launch of several workgroups per group, 2 = one
-   launch of one workgroup per group (refpix_one.hip; frames up to 4096 rows), 0 = the multi-launch kernels (refpix.hip), -1 = what
-   rip_calibrate takes for a pre-pass in front of its own ramp (option "prepass_form").  Every form gives identical bits.  status out (may be NULL): != 0 when a group barrier of the single-launch kernel timed out. */
+   lines (ngrp,nx/128,2) f64 = (m, c) of the science channels.  form: 1 = the single-launch kernel (refpix_one.hip; frames up to
+   4096 rows), 0 = the multi-launch kernels (refpix.hip), -1 = what rip_calibrate takes for a pre-pass in front of its own ramp
+   (option "prepass_form").  Both forms give identical bits.  status out (may be NULL): != 0 when a group barrier of the single-launch kernel timed out. */
 int rip_stage_refpix_tables(rip_ctx *ctx, const void *data, int data_dtype, const float *dark, const uint16_t *amp33,
                             const float *amp33_med, double slope, int ngrp, int ny, int nx, int form, double *rowcorr,
                             double *lines, int *status);
@@ -406,11 +406,14 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value);
 /* further options (results identical either way; they exist for A/B timing and tests):
    "chain2"  -- (default 1) the fused kernel (chain2_kernel.h: f32 or f64 ipc4d with 6, 8 or 16 groups); 0 = the stage kernels
                 (rounds 1-2: a general fused kernel, dropped in round 3);
-   "prepass_form" -- how the reference-pixel tables are made where the single-launch kernels cover the frame (up to 4096 rows, a
-                reference output): -1 (default) by situation -- a pre-pass that overlaps the previous ramp's fused kernel runs
-                as one workgroup per group in the workgroup slots that kernel leaves free (2), a pre-pass in front of its own
-                ramp as one launch of several workgroups per group (1); 0 = the multi-launch kernels of refpix.hip;
-   "chain_reserve" -- (default 8) workgroup slots the fused kernel's grid leaves free for that overlapped pre-pass;
+   "prepass_form" -- how the reference-pixel tables are made: -1 (default) by situation -- a pre-pass that overlaps the previous
+                ramp's fused kernel as the nine small launches of refpix.hip (they slip into that kernel's tail), a pre-pass in
+                front of its own ramp on the same stream as the single launch of refpix_one.hip (0.068 against 0.094 ms) where
+                it covers the frame (up to 4096 rows, a reference output); 0 = refpix.hip always; 1 = refpix_one.hip wherever
+                it covers the frame;
+   "chain_reserve" -- (default 8) workgroup slots the 256-column fused kernel's grid leaves free; "chain_quad" -- (default 1) a
+                last strip of at most 64 live columns is covered by workgroups whose four wave columns take a row range each
+                (4096 x 4096: 504 workgroups of 139 steps instead of 510 of 143; timing-neutral, profiles/r04_summary.md);
    "overlap" -- run the reference-pixel pre-pass of a ramp on a second stream so that it overlaps the previous ramp's
                 fused kernel. */
 

@@ -147,7 +147,7 @@ void rip_ctx_destroy(rip_ctx *ctx) {
             delete p;
         }
     rip_pink_release(ctx);
-    for (hipEvent_t e : {ctx->ev_tab[0], ctx->ev_tab[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_in, ctx->ev_pre, ctx->ev_frames, ctx->ev_fill})
+    for (hipEvent_t e : {ctx->ev_tab[0], ctx->ev_tab[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_in, ctx->ev_pre, ctx->ev_frames, ctx->ev_fill, ctx->ev_pink})
         if (e) (void)hipEventDestroy(e);
     for (void *p : ctx->ws)   // every workspace slot, the Level-1 synthesis ones included
         if (p) (void)hipFree(p);
@@ -207,12 +207,16 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value) {
         ctx->use_chain2 = value != 0;
         return RIP_OK;
     }
+    if (name && strcmp(name, "chain_quad") == 0) {
+        ctx->chain_quad = value != 0;
+        return RIP_OK;
+    }
     if (name && strcmp(name, "chain_reserve") == 0) {
         ctx->chain_reserve = value < 0 ? 0 : value;
         return RIP_OK;
     }
     if (name && strcmp(name, "prepass_form") == 0) {
-        if (value < -1 || value > 2) return rip_fail(ctx, RIP_EINVAL, "prepass_form: -1 (by situation), 0, 1 or 2");
+        if (value < -1 || value > 1) return rip_fail(ctx, RIP_EINVAL, "prepass_form: -1 (by situation), 0 or 1");
         ctx->prepass_form = value;
         return RIP_OK;
     }
@@ -1115,12 +1119,12 @@ int rip_stage_refpix_tables(rip_ctx *ctx, const void *data, int data_dtype, cons
         return rc;
     RefpixArgs ra{d_data.p, data_dtype, d_dark.as<float>(), d_a33.as<uint16_t>(), d_med.as<float>(), slope, nullptr,
                   d_rc.as<double>(), d_rt.as<double>(), d_ln.as<double>(), ny, nx, ngrp};
-    if (form < -1 || form > 2) return rip_fail(ctx, RIP_EINVAL, "refpix tables: form %d", form);
+    if (form < -1 || form > 1) return rip_fail(ctx, RIP_EINVAL, "refpix tables: form %d", form);
     const int keep = ctx->prepass_form;
     if (form >= 0) ctx->prepass_form = form;
     if (form >= 1 && !rip_refpix_one_supported(ra)) {
         ctx->prepass_form = keep;
-        return rip_fail(ctx, RIP_EINVAL, "refpix tables: the single-launch kernels do not cover a %d x %d frame of %d groups", ny, nx, ngrp);
+        return rip_fail(ctx, RIP_EINVAL, "refpix tables: the single-launch kernel does not cover a %d x %d frame of %d groups", ny, nx, ngrp);
     }
     rc = rip_launch_refpix_prepass(ctx, ra);
     ctx->prepass_form = keep;

@@ -1128,11 +1128,11 @@ static inline size_t chain2_lds_bytes(int G, size_t ksize = 4, int cols = C2_COL
 // columns (nx = 4096 in the 256-column form: 16 strips of 252 + 64), which is covered in QUAD mode: nq workgroups whose four wave
 // columns take a row range each.  4096 x 4096: 16 x 31 ranges of 133 rows + 8 quad workgroups (32 ranges of 128 rows) = 504 workgroups
 // of 139 steps; before (17 x 30 ranges of 137 rows): 510 of 143.  Returns the grid size.
-static inline long chain2_geometry(ChainArgs &a, int nstrips, int live_last, int slots, int reserve, int wc = 4) {
+static inline long chain2_geometry(ChainArgs &a, int nstrips, int live_last, int slots, int reserve, int wc = 4, bool quad_ok = true) {
     const int maxr = (a.ny + 7) / 8;   // at least 8 rows per range
     auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
     int best_nr = 0, best_nq = 0, best_steps = 1 << 30;
-    if (nstrips > 1 && live_last <= 64) {
+    if (quad_ok && nstrips > 1 && live_last <= 64) {
         const int nfull = nstrips - 1;
         for (int pass = 0; pass < 2 && !best_nr; ++pass) {   // (second pass: without the reserve, when it leaves no room)
             const int avail = slots - (pass ? 0 : reserve);
@@ -1170,7 +1170,7 @@ static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a
     if (a.nb < 2) return 1;   // (the frame-edge lanes of the first / last strip emit without neighbours: border pixels)
     ChainArgs ag = a;
     const long grid = chain2_geometry(ag, C2_NSTRIPS(a.nx), a.nx - (C2_NSTRIPS(a.nx) - 1) * C2_OUTW, ncu * per_cu,
-                                      NARROW ? 0 : ctx->chain_reserve, COLS / 64);
+                                      NARROW ? 0 : ctx->chain_reserve, COLS / 64, ctx->chain_quad);
     static bool lds_set[64] = {};   // per device, once per instantiation (contexts are used from one thread each)
     if (lds > 48 * 1024 && !lds_set[ctx->device & 63]) {
         RIP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(chain2_kernel<NP, G, START, KT, NARROW>),

@@ -119,10 +119,14 @@ __global__ __launch_bounds__(256) void pink_out_kernel(const double *__restrict_
 
 // out: host memory (frames copied back chunk by chunk, call synchronous) or, out_dev, device memory (asynchronous: the transform
 // plan and buffers are kept with the context between calls of the same frame length and batch)
-int noise_1f_impl(rip_ctx *ctx, int rows, int width, int nframes, const double *normals, uint64_t seed, uint32_t stream_id, float *out,
-                  bool out_dev) {
+// `st`: the stream of this call (the context's main stream, or its second one for frames made ahead).  Every call shares the
+// transform plan and the pink_z / pink_s buffers: a call that runs on another stream than the call before waits for it first
+// (ev_pink, recorded at the end of every call on the stream that ran it).
+int noise_1f_impl(rip_ctx *ctx, hipStream_t st, int rows, int width, int nframes, const double *normals, uint64_t seed,
+                  uint32_t stream_id, float *out, bool out_dev) {
     if (rows < 1 || width < 1 || nframes < 1 || !out) return rip_fail(ctx, RIP_EINVAL, "noise_1f: bad arguments");
     RIP_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->ev_pink_valid && ctx->pink_stream != st) RIP_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_pink, 0));
     const size_t L = (size_t)2 * rows * width, half = L / 2;
     double *d_n = nullptr;
     float *d_o = nullptr;
@@ -143,13 +147,14 @@ int noise_1f_impl(rip_ctx *ctx, int rows, int width, int nframes, const double *
     // frames are transformed in chunks so that the complex buffer stays below ~1 GB
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nframes, ((size_t)1 << 30) / (L * sizeof(hipfftDoubleComplex))));
     if (ctx->pink_L != L || ctx->pink_chunk != chunk) {   // another frame length or batch: new plan and buffers
-        PK_HIP(hipStreamSynchronize(ctx->stream));
+        PK_HIP(hipStreamSynchronize(ctx->stream));       // (either stream may still be using the old ones)
+        if (ctx->stream2) PK_HIP(hipStreamSynchronize(ctx->stream2));
         rip_pink_release(ctx);
         // one buffer: the folded coefficients (chunk x (L/2+1) complex), then the real series (chunk x L), then the block sums
         PK_HIP(hipMalloc(&ctx->pink_z, (size_t)chunk * (half + 1) * sizeof(hipfftDoubleComplex) + (size_t)chunk * L * sizeof(double)));
         PK_HIP(hipMalloc(&ctx->pink_s, ((size_t)chunk * 256 + L) * sizeof(double)));   // the block sums, then the amplitudes a_k
-        hipLaunchKernelGGL(pink_amp_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, (double *)ctx->pink_s + (size_t)chunk * 256, L);
-        PK_HIP(hipStreamSynchronize(ctx->stream));   // (once per frame length: later calls may come on the context's other stream)
+        hipLaunchKernelGGL(pink_amp_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, (double *)ctx->pink_s + (size_t)chunk * 256, L);
+        PK_HIP(hipStreamSynchronize(st));   // (once per frame length: later calls may come on the context's other stream)
         int n1 = (int)L;
         hipfftHandle made = 0;
         if (hipfftPlanMany(&made, 1, &n1, nullptr, 1, (int)(half + 1), nullptr, 1, n1, HIPFFT_Z2D, chunk) != HIPFFT_SUCCESS) {
@@ -169,7 +174,7 @@ int noise_1f_impl(rip_ctx *ctx, int rows, int width, int nframes, const double *
     hipfftHandle plan = (hipfftHandle)ctx->pink_plan;
     if (!out_dev) PK_HIP(hipMalloc((void **)&d_o, (size_t)chunk * half * sizeof(float)));
     if (normals) PK_HIP(hipMalloc((void **)&d_n, (size_t)chunk * 2 * L * sizeof(double)));
-    if (hipfftSetStream(plan, ctx->stream) != HIPFFT_SUCCESS) {
+    if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS) {
         rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftSetStream failed");
         done();
         return rc;
@@ -177,24 +182,28 @@ int noise_1f_impl(rip_ctx *ctx, int rows, int width, int nframes, const double *
     for (int f0 = 0; f0 < nframes; f0 += chunk) {
         const int nf = std::min(chunk, nframes - f0);
         if (normals)
-            PK_HIP(hipMemcpyAsync(d_n, normals + (size_t)f0 * 2 * L, (size_t)nf * 2 * L * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(pink_fill_kernel, dim3((unsigned)((half + 1 + 255) / 256), nf), dim3(256), 0, ctx->stream, (const double *)d_n, d_amp, z, L,
+            PK_HIP(hipMemcpyAsync(d_n, normals + (size_t)f0 * 2 * L, (size_t)nf * 2 * L * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(pink_fill_kernel, dim3((unsigned)((half + 1 + 255) / 256), nf), dim3(256), 0, st, (const double *)d_n, d_amp, z, L,
                            nf, seed, stream_id + (uint32_t)f0);
         if (nf < chunk)
-            PK_HIP(hipMemsetAsync(z + (size_t)nf * (half + 1), 0, (size_t)(chunk - nf) * (half + 1) * sizeof(hipfftDoubleComplex), ctx->stream));
+            PK_HIP(hipMemsetAsync(z + (size_t)nf * (half + 1), 0, (size_t)(chunk - nf) * (half + 1) * sizeof(hipfftDoubleComplex), st));
         if (hipfftExecZ2D(plan, z, x) != HIPFFT_SUCCESS) {
             rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftExecZ2D failed");
             done();
             return rc;
         }
-        hipLaunchKernelGGL(pink_sum_kernel, dim3(256, nf), dim3(256), 0, ctx->stream, (const double *)x, L, d_s);
+        hipLaunchKernelGGL(pink_sum_kernel, dim3(256, nf), dim3(256), 0, st, (const double *)x, L, d_s);
         float *dst = out_dev ? out + (size_t)f0 * half : d_o;
-        hipLaunchKernelGGL(pink_out_kernel, dim3((unsigned)((half + 255) / 256), nf), dim3(256), 0, ctx->stream, (const double *)x, L,
+        hipLaunchKernelGGL(pink_out_kernel, dim3((unsigned)((half + 255) / 256), nf), dim3(256), 0, st, (const double *)x, L,
                            (const double *)d_s, dst);
         PK_HIP(hipGetLastError());
-        if (!out_dev) PK_HIP(hipMemcpyAsync(out + (size_t)f0 * half, d_o, (size_t)nf * half * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        if (!out_dev) PK_HIP(hipStreamSynchronize(ctx->stream));   // device output: the next chunk follows in stream order
+        if (!out_dev) PK_HIP(hipMemcpyAsync(out + (size_t)f0 * half, d_o, (size_t)nf * half * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (!out_dev) PK_HIP(hipStreamSynchronize(st));   // device output: the next chunk follows in stream order
     }
+    if (!ctx->ev_pink) PK_HIP(hipEventCreateWithFlags(&ctx->ev_pink, hipEventDisableTiming));
+    PK_HIP(hipEventRecord(ctx->ev_pink, st));
+    ctx->pink_stream = st;
+    ctx->ev_pink_valid = true;
 #undef PK_HIP
     done();
     return RIP_OK;
@@ -214,7 +223,7 @@ void rip_pink_release(rip_ctx *ctx) {
 extern "C" int rip_stage_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, const double *normals, uint64_t seed,
                                   uint32_t stream_id, float *out) {
     if (ctx->frames_pending && ctx->ev_frames) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_frames, 0);
-    return noise_1f_impl(ctx, rows, width, nframes, normals, seed, stream_id, out, false);
+    return noise_1f_impl(ctx, ctx->stream, rows, width, nframes, normals, seed, stream_id, out, false);
 }
 
 // frames made ahead on the second stream share the transform buffers with every other 1/f call: those wait for them first
@@ -227,7 +236,7 @@ extern "C" int rip_synth_noise_1f(rip_ctx *ctx, int rows, int width, int nframes
     ctx->stream_dirty = true;
     int rc = frames_drain(ctx);
     if (rc) return rc;
-    return noise_1f_impl(ctx, rows, width, nframes, nullptr, seed, stream_id, out, true);
+    return noise_1f_impl(ctx, ctx->stream, rows, width, nframes, nullptr, seed, stream_id, out, true);
 }
 
 extern "C" int rip_synth_frames_ahead(rip_ctx *ctx, int rows, int width, int nframes, uint64_t seed) {
@@ -239,13 +248,9 @@ extern "C" int rip_synth_frames_ahead(rip_ctx *ctx, int rows, int width, int nfr
     if (!ctx->ev_frames) RIP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_frames, hipEventDisableTiming));
     // behind the previous exposure's fill kernels (they read the frames this call overwrites)
     if (ctx->ev_fill_valid) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fill, 0));
-    hipStream_t main_stream = ctx->stream;
-    ctx->stream = ctx->stream2;
-    const int rc = noise_1f_impl(ctx, rows, width, nframes, nullptr, seed, 0x31660000u, made, true);
-    hipError_t e = rc ? hipSuccess : hipEventRecord(ctx->ev_frames, ctx->stream2);
-    ctx->stream = main_stream;
+    const int rc = noise_1f_impl(ctx, ctx->stream2, rows, width, nframes, nullptr, seed, 0x31660000u, made, true);
     if (rc) return rc;
-    RIP_HIP(ctx, e);
+    RIP_HIP(ctx, hipEventRecord(ctx->ev_frames, ctx->stream2));
     ctx->frames_pending = true;
     ctx->frames_seed = seed;
     ctx->frames_geom[0] = rows, ctx->frames_geom[1] = width, ctx->frames_geom[2] = nframes;

@@ -313,10 +313,8 @@ int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a) {
     if (a.ny < 8) return rip_fail(ctx, RIP_EINVAL, "refpix: ny=%d too small", a.ny);
     const int G = a.ngrp, ny = a.ny, nch = a.nx / RIP_CW;
     hipStream_t strm = a.stream ? a.stream : ctx->stream;   // (the overlapped pre-pass: the context's second stream)
-    if (ctx->prepass_form != 0 && rip_refpix_one_supported(a)) {
-        const int form = ctx->prepass_form > 0 ? ctx->prepass_form : (a.background ? 2 : 1);
-        return form == 2 ? rip_launch_refpix_bg(ctx, a) : rip_launch_refpix_one(ctx, a);
-    }
+    if ((ctx->prepass_form == 1 || (ctx->prepass_form < 0 && !a.background)) && rip_refpix_one_supported(a))
+        return rip_launch_refpix_one(ctx, a);
     if (a.amp33) {
         // scratch: lohi (G,ny,2) f32 | SelState[G]
         const size_t lohi_b = (size_t)G * ny * 2 * sizeof(float);

@@ -8,8 +8,12 @@
 //                                            128-column channel, line through them
 // (all medians exact: np.median of an even count = f32 mean of the two middle elements).
 //
-// Why one launch: the nine launches of refpix.hip take 0.09 ms alone and cannot run beside the fused kernel, whose grid fills
-// every CU (they queue behind its retiring workgroups: 0.08 ms of every 0.91 ms ramp, profiles/r03_summary.md).  Here the
+// Where it is used: a pre-pass that runs in front of its own ramp on the same stream (single calls, host arrays, "overlap" off):
+// 0.068 ms against the 0.094 ms of the nine launches of refpix.hip.  A pre-pass that OVERLAPS the previous ramp's fused kernel
+// (device-resident ramps back to back: the bench) keeps the nine small launches: they slip into the fused kernel's tail and cost
+// 0.03 ms of wall time per ramp, which neither this kernel in-stream (+0.07 ms) nor a one-workgroup-per-group variant of it
+// running beside the fused kernel in the workgroup slots that kernel leaves free (0.58 ms alone on its 8 CUs, 0.93 ms beside
+// the fused kernel: longer than the kernel it hides behind) beats -- same-box A/B in profiles/r04_summary.md.  Here the
 // phases of one group (= one resultant of the ramp) are separated by barriers among the workgroups of THAT group only; groups are
 // independent.  Workgroups are numbered group-major, and a workgroup only ever waits for workgroups of its own group, all of
 // which precede every later group's in each XCD's dispatch queue -- so a partially resident grid (a busy or shared device) cannot
@@ -107,41 +111,90 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane) {
         return (lane & 32) ? r[0] : r[1];
     }
 }
-template <int J>
-__device__ __forceinline__ uint32_t cmpx(uint32_t v, int lane, bool keep_min) {
-    return med3u(v, lane_xor<J>(v, lane), keep_min ? 0u : 0xffffffffu);
-}
-template <int J>
-__device__ __forceinline__ uint32_t stage(uint32_t v, int lane, int k, bool desc) {
+// One compare-exchange stage (distance J) of the bitonic network on NS independent slots of 64 keys (a key per lane and slot),
+// slot loop innermost so that the lane exchanges of one slot fill the wait states of the next.  Blocks of k lanes alternate
+// between ascending and descending (k = 64: one direction, `desc`).  Distances 16 and 32 take the slots in PAIRS: one row / half
+// swap puts the partners of both slots side by side ({[X.r0 Y.r0 X.r2 Y.r2], [X.r1 Y.r1 X.r3 Y.r3]}), a minimum and a maximum
+// (direction per lane: v_med3 against 0 / ~0) and the same swap puts them back -- 2 instructions per slot, no copies.
+template <int J, int NS>
+__device__ __forceinline__ void stageN(uint32_t (&v)[NS], int lane, int k, bool desc) {
     bool up = (k == 64) ? true : ((lane & k) == 0);
     if (desc) up = !up;
-    return cmpx<J>(v, lane, ((lane & J) == 0) == up);
+    if constexpr (J >= 16 && NS % 2 == 0) {
+        const uint32_t cA = up ? 0u : 0xffffffffu;
+#pragma unroll
+        for (int s = 0; s < NS; s += 2) {
+            uint32_t P, Q;
+            if constexpr (J == 16) {
+                const auto r = __builtin_amdgcn_permlane16_swap(v[s], v[s + 1], false, false);
+                P = med3u(r[0], r[1], cA), Q = med3u(r[0], r[1], ~cA);
+                const auto r2 = __builtin_amdgcn_permlane16_swap(P, Q, false, false);
+                v[s] = r2[0], v[s + 1] = r2[1];
+            } else {
+                const auto r = __builtin_amdgcn_permlane32_swap(v[s], v[s + 1], false, false);
+                P = med3u(r[0], r[1], cA), Q = med3u(r[0], r[1], ~cA);
+                const auto r2 = __builtin_amdgcn_permlane32_swap(P, Q, false, false);
+                v[s] = r2[0], v[s + 1] = r2[1];
+            }
+        }
+    } else {
+        const uint32_t c = (((lane & J) == 0) == up) ? 0u : 0xffffffffu;
+        uint32_t p[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) p[s] = lane_xor<J>(v[s], lane);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) v[s] = med3u(v[s], p[s], c);
+    }
 }
-// the 64 keys of a wave (one per lane) sorted across the lanes: bitonic network, 21 compare-exchange stages
-__device__ __forceinline__ uint32_t sort64(uint32_t v, int lane, bool desc = false) {
+// NS slots of 64 keys, each sorted across the lanes: bitonic network, 21 compare-exchange stages
+template <int NS>
+__device__ __forceinline__ void sortN(uint32_t (&v)[NS], int lane, bool desc = false) {
 #pragma unroll
     for (int k = 2; k <= 64; k <<= 1) {
-        if (k >= 64) v = stage<32>(v, lane, k, desc);
-        if (k >= 32) v = stage<16>(v, lane, k, desc);
-        if (k >= 16) v = stage<8>(v, lane, k, desc);
-        if (k >= 8) v = stage<4>(v, lane, k, desc);
-        if (k >= 4) v = stage<2>(v, lane, k, desc);
-        v = stage<1>(v, lane, k, desc);
+        if (k >= 64) stageN<32, NS>(v, lane, k, desc);
+        if (k >= 32) stageN<16, NS>(v, lane, k, desc);
+        if (k >= 16) stageN<8, NS>(v, lane, k, desc);
+        if (k >= 8) stageN<4, NS>(v, lane, k, desc);
+        if (k >= 4) stageN<2, NS>(v, lane, k, desc);
+        stageN<1, NS>(v, lane, k, desc);
     }
-    return v;
 }
-// a bitonic sequence of 64 keys -> sorted (the last merge of the network alone)
+// NS bitonic sequences of 64 keys -> sorted (the last merge of the network alone)
+template <int NS>
+__device__ __forceinline__ void mergeN(uint32_t (&v)[NS], int lane, bool desc = false) {
+    stageN<32, NS>(v, lane, 64, desc);
+    stageN<16, NS>(v, lane, 64, desc);
+    stageN<8, NS>(v, lane, 64, desc);
+    stageN<4, NS>(v, lane, 64, desc);
+    stageN<2, NS>(v, lane, 64, desc);
+    stageN<1, NS>(v, lane, 64, desc);
+}
+__device__ __forceinline__ uint32_t sort64(uint32_t v, int lane, bool desc = false) {
+    uint32_t a[1] = {v};
+    sortN<1>(a, lane, desc);
+    return a[0];
+}
 __device__ __forceinline__ uint32_t merge64(uint32_t v, int lane, bool desc = false) {
-    v = stage<32>(v, lane, 64, desc);
-    v = stage<16>(v, lane, 64, desc);
-    v = stage<8>(v, lane, 64, desc);
-    v = stage<4>(v, lane, 64, desc);
-    v = stage<2>(v, lane, 64, desc);
-    return stage<1>(v, lane, 64, desc);
+    uint32_t a[1] = {v};
+    mergeN<1>(a, lane, desc);
+    return a[0];
 }
 __device__ __forceinline__ uint32_t rev64(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute((63 - lane) << 2, (int)v);
 }
+// The two middle elements of 128 keys held as k0 (64 keys ascending across the lanes) and k1r (the other 64, descending): the 64
+// smallest are min(k0[i], k1r[i]) -- k0 up to the lane x where the sequences cross, k1r from there -- so their maximum sits at the
+// crossing, and so does the minimum of the 64 largest.  One wave vote and four lane reads.
+__device__ __forceinline__ void middle_pair(uint32_t k0, uint32_t k1r, uint32_t &lo, uint32_t &hi) {
+    const int x = __popcll(__ballot(k0 <= k1r));   // lanes [0, x): k0 <= k1r (monotone: k0 rises, k1r falls)
+    const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)k0, x > 0 ? x - 1 : 0);
+    const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)k0, x < 64 ? x : 63);
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)k1r, x > 0 ? x - 1 : 0);
+    const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)k1r, x < 64 ? x : 63);
+    lo = x == 0 ? b1 : (x == 64 ? a0 : umax(a0, b1));
+    hi = x == 0 ? a1 : (x == 64 ? b0 : umin(b0, a1));
+}
+
 // maximum / minimum over the wave (returned to every lane): running maximum along each row of 16 lanes by DPP shifts (lanes
 // without a source keep their own value), the row results passed on by the two row broadcasts; lane 63 holds the result
 template <bool MAX>
@@ -219,12 +272,15 @@ __device__ __forceinline__ void group_barrier(uint32_t *ctr, uint32_t target, ui
     __syncthreads();
 }
 
-// a row of 128 keys (k0: elements 0..63, k1: 64..127 of the row, one per lane) sorted ascending: lo holds ranks 0..63, hi 64..127
-__device__ __forceinline__ void sort128(uint32_t k0, uint32_t k1, int lane, uint32_t &lo, uint32_t &hi) {
-    k0 = sort64(k0, lane);
-    k1 = rev64(sort64(k1, lane), lane);
-    lo = merge64(umin(k0, k1), lane);
-    hi = merge64(umax(k0, k1), lane);
+// a row of 128 keys (k0: elements 0..63, k1: 64..127 of the row, one per lane) sorted: ascending -- lo holds ranks 0..63 in lane
+// order, hi 64..127 -- or descending (lo: the 64 largest, largest first)
+__device__ __forceinline__ void sort128(uint32_t k0, uint32_t k1, int lane, uint32_t &lo, uint32_t &hi, bool desc = false) {
+    uint32_t k[2] = {k0, k1};
+    sortN<2>(k, lane);
+    const uint32_t k1r = rev64(k[1], lane);
+    uint32_t m[2] = {desc ? umax(k[0], k1r) : umin(k[0], k1r), desc ? umin(k[0], k1r) : umax(k[0], k1r)};
+    mergeN<2>(m, lane, desc);
+    lo = m[0], hi = m[1];
 }
 
 // np.median of 4 x 128 keys: x[row][slot], rows 0 and 2 sorted ascending (slot 0: ranks 0..63 in lane order), rows 1 and 3
@@ -236,12 +292,11 @@ __device__ __forceinline__ void merge_rows(const uint32_t (&xa)[2], const uint32
     const uint32_t l0 = umin(xa[0], yd[0]), l1 = umin(xa[1], yd[1]);
     const uint32_t h0 = umax(xa[0], yd[0]), h1 = umax(xa[1], yd[1]);
     const uint32_t la = umin(l0, l1), lb = umax(l0, l1), ha = umin(h0, h1), hb = umax(h0, h1);
-    if (!desc) {
-        out[0] = merge64(la, lane), out[1] = merge64(lb, lane), out[2] = merge64(ha, lane), out[3] = merge64(hb, lane);
-    } else {
-        out[0] = merge64(hb, lane, true), out[1] = merge64(ha, lane, true), out[2] = merge64(lb, lane, true),
-        out[3] = merge64(la, lane, true);
-    }
+    if (!desc)
+        out[0] = la, out[1] = lb, out[2] = ha, out[3] = hb;
+    else
+        out[0] = hb, out[1] = ha, out[2] = lb, out[3] = la;
+    mergeN<4>(out, lane, desc);
 }
 __device__ __forceinline__ float chan_median(const uint32_t (&x)[4][2], int lane) {
     uint32_t P[4], Q[4];
@@ -279,9 +334,10 @@ __device__ __forceinline__ void row_tables(const float (&refmed)[R1_NV], const R
         const int r = tid + R1_THREADS * k;
         const int first = (w << 6) + R1_THREADS * k;   // row of lane 0
         nlive[k] = min(max(ny - first, 0), 64);
-        // sorted ascending, the lanes without a row at the top (any key equal to the filler is interchangeable with it)
-        rk[k] = sort64(r < ny ? f2key(refmed[k]) : 0xffffffffu, lane);
+        // (sorted ascending below: the lanes without a row at the top -- any key equal to the filler is interchangeable with it)
+        rk[k] = r < ny ? f2key(refmed[k]) : 0xffffffffu;
     }
+    sortN<R1_NV>(rk, lane);
     uint32_t pre2[2] = {0u, 0u}, rank2[2] = {(uint32_t)((ny & 1) ? ny / 2 : ny / 2 - 1), (uint32_t)(ny / 2)};
 #pragma unroll 1
     for (int lv = 0; lv < 3; ++lv) {
@@ -383,20 +439,22 @@ __global__ __launch_bounds__(R1_THREADS) void refpix_one_kernel(R1Args a) {
                 }
             }
         }
+        uint32_t ks[2 * R1_RPW];
 #pragma unroll
         for (int i = 0; i < R1_RPW; ++i) {
-            uint32_t k0 = f2key((float)raw[i][0] - md[i][0]);
-            uint32_t k1 = f2key((float)raw[i][1] - md[i][1]);
-            k0 = sort64(k0, lane);
-            k1 = sort64(k1, lane);
-            // the 64 smallest of the row are min(k0[i], k1[63 - i]); its middle elements: their maximum, and the minimum of the rest
-            const uint32_t k1r = rev64(k1, lane);
-            const uint32_t lo = wave_umax(umin(k0, k1r), lane), hi = wave_umin(umax(k0, k1r), lane);
+            ks[2 * i] = f2key((float)raw[i][0] - md[i][0]);
+            ks[2 * i + 1] = f2key((float)raw[i][1] - md[i][1]);
+        }
+        sortN<2 * R1_RPW>(ks, lane);
+#pragma unroll
+        for (int i = 0; i < R1_RPW; ++i) {
+            uint32_t lo, hi;
+            middle_pair(ks[2 * i], rev64(ks[2 * i + 1], lane), lo, hi);
             if (lane == 0) {
                 lohi_s[0][i * R1_WAVES + w] = lo;
                 lohi_s[1][i * R1_WAVES + w] = hi;
             }
-            key[i][0] = k0, key[i][1] = k1;
+            key[i][0] = ks[2 * i], key[i][1] = ks[2 * i + 1];
         }
     }
     __syncthreads();
@@ -505,160 +563,6 @@ __global__ __launch_bounds__(R1_THREADS) void refpix_one_kernel(R1Args a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// The same tables by ONE WORKGROUP PER GROUP, no dependence between workgroups: the form for the overlapped pre-pass.  The fused
-// kernel's grid leaves a few workgroup slots free (chain2_geometry: 504 of 512 on 4096 x 4096 frames, at no cost -- the kernel
-// is not bound by its steps); the pre-pass of the NEXT ramp, launched on the second stream, runs in those slots beside it: a
-// workgroup of 1024 threads at <= 64 registers and 50 KB of LDS fits next to one workgroup of the fused kernel.  It may take as
-// long as the fused kernel does (0.85 ms), so it simply walks its group's 4096 rows three times (row medians + level 0 of the
-// selection from the sorted rows; levels 1 and 2 from the re-read values, whose few matching lanes add to the LDS histogram one by
-// one), the row medians stay in LDS, then row_tables and the channel medians (the rows sorted after the row correction).
-__device__ __forceinline__ void hist_any(uint32_t key, int lv, uint32_t prefix, uint32_t *h, int lane) {
-    const int shift = sel_shift(lv), bits = sel_bits(lv), above = shift + bits;
-    const bool inr = ((key ^ prefix) >> above) == 0;
-    const unsigned long long m = __ballot(inr);
-    if (!m) return;
-    const uint32_t bin = (key >> shift) & ((1u << bits) - 1u);
-    const int fl = __ffsll((long long)m) - 1;
-    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, fl);
-    if (__ballot(inr && bin == b0) == m) {   // one bin for the whole wave (constant blocks: no 64-way contention)
-        if (lane == fl) atomicAdd(&h[b0], (uint32_t)__popcll(m));
-    } else if (inr) {
-        atomicAdd(&h[bin], 1u);
-    }
-}
-
-template <typename DT>
-__global__ __launch_bounds__(R1_THREADS, 8) void refpix_bg_kernel(R1Args a) {
-    __shared__ uint32_t hist[2][SEL_BINS];
-    __shared__ uint32_t wtot[2][8];
-    __shared__ uint32_t sel[2][2];
-    __shared__ uint32_t lo_s[R1_NV * R1_THREADS], hi_s[R1_NV * R1_THREADS];
-    __shared__ double rc8[8];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int g = (int)blockIdx.x;
-    const int ny = a.ny, nx = a.nx, nch = nx / RIP_CW;
-    for (int i = tid; i < 2 * SEL_BINS; i += R1_THREADS) (&hist[0][0])[i] = 0;
-    __syncthreads();
-    const uint16_t *ap = a.amp33 + (size_t)g * ny * RIP_CW;
-    // RB rows of this wave at a time (rows w + 16 i): all their loads first -- a load takes a microsecond or two beside the fused
-    // kernel's traffic -- then RB independent chains of arithmetic (the lane exchanges of the sorting networks overlap)
-    constexpr int RB = 4;
-    auto batch_keys = [&](int rb, uint32_t (&k)[RB][2], bool (&ok)[RB]) {
-        uint32_t raw[RB][2];
-        float md[RB][2];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int r = rb + i * R1_WAVES;
-            ok[i] = r < ny;
-            const size_t o = (size_t)(ok[i] ? r : ny - 1) * RIP_CW + lane;
-            raw[i][0] = ap[o], raw[i][1] = ap[o + 64];
-            md[i][0] = a.med[o], md[i][1] = a.med[o + 64];
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            k[i][0] = f2key((float)raw[i][0] - md[i][0]);
-            k[i][1] = f2key((float)raw[i][1] - md[i][1]);
-        }
-    };
-    // ---- pass 1: rows w, w + 16, ...: middle elements into LDS, level 0 of the selection from the sorted keys
-    for (int rb = w; rb < ny; rb += RB * R1_WAVES) {
-        uint32_t k[RB][2];
-        bool ok[RB];
-        batch_keys(rb, k, ok);
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            k[i][0] = sort64(k[i][0], lane);
-            k[i][1] = sort64(k[i][1], lane);
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const uint32_t k1r = rev64(k[i][1], lane);
-            const uint32_t lo = wave_umax(umin(k[i][0], k1r), lane), hi = wave_umin(umax(k[i][0], k1r), lane);
-            if (lane == 0 && ok[i]) lo_s[rb + i * R1_WAVES] = lo, hi_s[rb + i * R1_WAVES] = hi;
-            hist_slot(k[i][0], ok[i], 0, 0u, hist[0], lane);
-            hist_slot(k[i][1], ok[i], 0, 0u, hist[0], lane);
-        }
-    }
-    __syncthreads();
-    const uint32_t n = (uint32_t)ny * RIP_CW;
-    uint32_t prefix[2] = {0u, 0u}, rank[2] = {n / 2 - 1, n / 2};
-#pragma unroll 1
-    for (int lv = 0; lv < 3; ++lv) {
-        const bool same = prefix[0] == prefix[1];
-        if (lv > 0) {
-            for (int rb = w; rb < ny; rb += RB * R1_WAVES) {
-                uint32_t k[RB][2];
-                bool ok[RB];
-                batch_keys(rb, k, ok);
-#pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    if (!ok[i]) continue;
-                    hist_any(k[i][0], lv, prefix[0], hist[0], lane);
-                    hist_any(k[i][1], lv, prefix[0], hist[0], lane);
-                    if (!same) {
-                        hist_any(k[i][0], lv, prefix[1], hist[1], lane);
-                        hist_any(k[i][1], lv, prefix[1], hist[1], lane);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        {
-            const int q = tid >> 9, t = tid & 511;
-            uint32_t *src = hist[same ? 0 : q] + 4 * t;
-            uint32_t c[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) c[k] = src[k];
-            scan_find(c, rank[q], wtot, sel, tid);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            prefix[q] |= sel[q][0] << sel_shift(lv);
-            rank[q] = sel[q][1];
-        }
-        for (int i = tid; i < 2 * SEL_BINS; i += R1_THREADS) (&hist[0][0])[i] = 0;
-        __syncthreads();
-    }
-    const float M = (key2f(prefix[0]) + key2f(prefix[1])) * 0.5f;   // np.median of the block
-    float refmed[R1_NV];
-#pragma unroll
-    for (int k = 0; k < R1_NV; ++k) {
-        const int r = tid + R1_THREADS * k;
-        const int rr = r < ny ? r : ny - 1;
-        refmed[k] = ((key2f(lo_s[rr]) - M) + (key2f(hi_s[rr]) - M)) * 0.5f;
-    }
-    row_tables(refmed, a, g, hist, wtot, sel, rc8);
-    if (a.lines_override) {
-        for (int i = tid; i < nch * 2; i += R1_THREADS) a.lines[(size_t)g * nch * 2 + i] = a.lines_override[(size_t)g * nch * 2 + i];
-        return;
-    }
-    // ---- channel lines: a wave per channel, its 4 + 4 rows row-corrected, sorted (odd rows descending) and merged
-    const DT *dp = (const DT *)a.data;
-    for (int ch = w; ch < nch; ch += R1_WAVES) {
-        float bt[2];
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            uint32_t x[4][2];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j = half * 4 + jj, row = j < 4 ? j : ny - 8 + j;
-                const size_t idx = ((size_t)g * ny + row) * nx + (size_t)ch * RIP_CW + lane;
-                const double rc = rc8[j];
-                const float v0 = (float)dp[idx] - a.dark[idx], v1 = (float)dp[idx + 64] - a.dark[idx + 64];
-                uint32_t k0 = sort64(f2key((float)((double)v0 - rc)), lane);
-                uint32_t k1 = rev64(sort64(f2key((float)((double)v1 - rc)), lane), lane);
-                const bool desc = jj & 1;
-                // ascending: slot 0 = the 64 smallest; descending: slot 0 = the 64 largest, largest first
-                x[jj][0] = merge64(desc ? umax(k0, k1) : umin(k0, k1), lane, desc);
-                x[jj][1] = merge64(desc ? umin(k0, k1) : umax(k0, k1), lane, desc);
-            }
-            bt[half] = chan_median(x, lane);
-        }
-        if (lane == 0) store_line(a, g, nch, ch, bt[0], bt[1]);
-    }
-}
-
 }  // namespace
 
 // whether the single-launch form covers a frame (otherwise: the multi-launch form of refpix.hip)
@@ -710,33 +614,6 @@ int rip_launch_refpix_one(rip_ctx *ctx, const RefpixArgs &a) {
         hipLaunchKernelGGL(refpix_one_kernel<uint16_t>, dim3((unsigned)(G * B)), dim3(R1_THREADS), 0, st, r);
     else
         hipLaunchKernelGGL(refpix_one_kernel<float>, dim3((unsigned)(G * B)), dim3(R1_THREADS), 0, st, r);
-    RIP_HIP(ctx, hipGetLastError());
-    return RIP_OK;
-}
-
-// one workgroup per group, no dependence between them (the overlapped pre-pass: see refpix_bg_kernel)
-int rip_launch_refpix_bg(rip_ctx *ctx, const RefpixArgs &a) {
-    hipStream_t st = a.stream ? a.stream : ctx->stream;
-    if (!rip_refpix_one_supported(a)) return rip_fail(ctx, RIP_EINVAL, "refpix: frame not covered by the single-launch pre-pass");
-    R1Args r;
-    memset(&r, 0, sizeof r);
-    r.data = a.data;
-    r.dark = a.dark_data;
-    r.amp33 = a.amp33;
-    r.med = a.amp33_med;
-    r.lines_override = a.lines_override;
-    r.rowcorr = a.rowcorr;
-    r.rowcorr_t = a.rowcorr_t;
-    r.lines = a.lines;
-    r.slope = a.slope;
-    r.ny = a.ny;
-    r.nx = a.nx;
-    r.G = a.ngrp;
-    r.B = 1;
-    if (a.data_dtype == RIP_U16)
-        hipLaunchKernelGGL(refpix_bg_kernel<uint16_t>, dim3((unsigned)a.ngrp), dim3(R1_THREADS), 0, st, r);
-    else
-        hipLaunchKernelGGL(refpix_bg_kernel<float>, dim3((unsigned)a.ngrp), dim3(R1_THREADS), 0, st, r);
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
 }

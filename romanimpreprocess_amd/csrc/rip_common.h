@@ -143,11 +143,11 @@ struct rip_ctx {
                                 // single-launch pre-pass (zero between calls), 15: its row / channel scratch
     size_t ws_bytes[16] = {};
     void *prepass_stamps = nullptr;   // diagnostic: device buffer of 16 clock stamps per workgroup of the single-launch pre-pass
+    bool chain_quad = true;     // a last strip of <= 64 live columns in quad mode (chain2_geometry); false: every strip alike (A/B timing)
     int chain_reserve = 8;      // workgroup slots the 256-column fused kernel leaves free (the next ramp's pre-pass runs in them)
-    // reference-pixel tables (frames the single-launch kernels cover: up to 4096 rows, with a reference output): -1 = by situation
-    // (a pre-pass that runs beside the previous ramp's fused kernel: one workgroup per group in the slots that kernel leaves free,
-    // form 2; a pre-pass in front of its own ramp: the multi-workgroup single launch, form 1); 0 = the multi-launch kernels of
-    // refpix.hip (any frame), 1, 2 = that form always
+    // reference-pixel tables: -1 = by situation (a pre-pass that overlaps the previous ramp's fused kernel: the nine small launches
+    // of refpix.hip, which slip into that kernel's tail; a pre-pass in front of its own ramp on the same stream: the single launch
+    // of refpix_one.hip where it covers the frame); 0 = refpix.hip always, 1 = refpix_one.hip wherever it covers the frame
     int prepass_form = -1;
     // rip_calibrate_batch (batch.hip): download stream and the two sets of device buffers, kept between calls
     hipStream_t stream3 = nullptr;
@@ -155,6 +155,9 @@ struct rip_ctx {
     size_t batch_bytes[4] = {0, 0, 0, 0};
     // 1/f frames (pink.hip): transform plan and buffers of the last (length, batch) kept between calls
     void *pink_plan = nullptr, *pink_z = nullptr, *pink_s = nullptr;
+    hipEvent_t ev_pink = nullptr;   // end of the last 1/f call, on pink_stream: the next call on the OTHER stream waits for it
+    hipStream_t pink_stream = nullptr;
+    bool ev_pink_valid = false;
     size_t pink_L = 0;
     int pink_chunk = 0;
     // set by the entry points that queue work on `stream` with device pointers (rip_synth_*, rip_stats_*): the next overlapped
@@ -306,7 +309,6 @@ struct RefpixArgs {
     hipStream_t stream = nullptr;   // where the launches go (null: the context's main stream)
 };
 int rip_launch_refpix_prepass(rip_ctx *ctx, const RefpixArgs &a);
-int rip_launch_refpix_bg(rip_ctx *ctx, const RefpixArgs &a);
 // refpix_one.hip: the same tables in one launch (frames up to 4096 rows with a reference output)
 bool rip_refpix_one_supported(const RefpixArgs &a);
 int rip_launch_refpix_one(rip_ctx *ctx, const RefpixArgs &a);

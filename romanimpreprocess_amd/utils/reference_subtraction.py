@@ -109,9 +109,8 @@ def ref_subtraction_channel(image, channel_start=0, channel_end=128, use_ref_cha
 def refpix_tables(data, dark, amp33, amp33_med, slope, form=-1, ctx=None):
     """The tables the chain's reference-pixel step applies to a ramp (gen_cal_image.py:531-556): ``rowcorr`` (ngrp, ny) float64 =
     ``slope * float64(float32(row median of the reference output - ctr))`` and ``lines`` (ngrp, nx // 128, 2) float64 = (m, c) of
-    the science channels (two-point formula, DESIGN.md "channel line fit").  ``form``: 1 one launch of several
-    workgroups per group, 2 one launch of one workgroup per group, 0 the multi-launch kernels, -1 the library's default;
-    identical bits.  Returns (rowcorr, lines, status)."""
+    the science channels (two-point formula, DESIGN.md "channel line fit").  ``form``: 1 the single-launch kernel, 0 the
+    multi-launch kernels, -1 the library's default; identical bits.  Returns (rowcorr, lines, status)."""
     import ctypes
 
     ctx = ctx or _native.default_context()

@@ -359,7 +359,7 @@ def test_refpix_tables_fullframe_vs_reference_medians(name):
     n = 4096
     slope = float(g["slope"])
     want_rc, want_ln = _tables_from_medians(g["ref_med"], g["ctr"], g["bottom_top"][:32], slope, n)
-    for form in (1, 2, 0):
+    for form in (1, 0):
         rc, ln, status = reference_subtraction.refpix_tables(c["data"][None], c["dark"][None], c["amp33"][None], c["med"], slope,
                                                              form=form, ctx=gpu_context())
         assert status == 0
@@ -371,8 +371,7 @@ def test_refpix_tables_fullframe_vs_reference_medians(name):
                                           (1160, 256, 5, "drift"), (129, 128, 2, "const"), (4096, 512, 8, "noise"),
                                           (520, 128, 64, "ties")])
 def test_refpix_tables_single_launch_equals_multi_launch_and_oracle(ny, nx, G, kind):
-    """The three forms of the pre-pass (multi-launch; one launch of several workgroups per group; one launch of one workgroup per
-    group, the overlapped form).  Random frames -- ragged row counts (partial workgroups and slots), one to 32 workgroups per group, up to 64 groups, heavy
+    """The two forms of the pre-pass (multi-launch, single launch).  Random frames -- ragged row counts (partial workgroups and slots), one to 32 workgroups per group, up to 64 groups, heavy
     ties (few distinct values: every histogram level has crowded bins), constant blocks, drifting rows, f32 cubes: the two forms
     agree bit for bit, and with the numpy oracle's medians."""
     from oracle import refpix as orp
@@ -402,10 +401,6 @@ def test_refpix_tables_single_launch_equals_multi_launch_and_oracle(ny, nx, G, k
     assert st1 == 0 and st0 == 0
     assert_same_bits(rc1, rc0, "rowcorr: single launch vs multi launch")
     assert_same_bits(ln1, ln0, "lines: single launch vs multi launch")
-    rcb, lnb, stb = reference_subtraction.refpix_tables(data, dark, amp33, med, slope, form=2, ctx=ctx)
-    assert stb == 0
-    assert_same_bits(rcb, rc0, "rowcorr: one workgroup per group vs multi launch")
-    assert_same_bits(lnb, ln0, "lines: one workgroup per group vs multi launch")
     # and twice in a row: the kernel leaves its histograms / counters as it found them
     rc2, ln2, st2 = reference_subtraction.refpix_tables(data, dark, amp33, med, slope, form=1, ctx=ctx)
     assert st2 == 0

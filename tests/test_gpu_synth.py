@@ -248,3 +248,50 @@ def test_frames_made_ahead_give_the_same_exposure():
     assert np.array_equal(got[0], want[13][0]) and np.array_equal(got[1], want[13][1])
     # and the exposures do differ by seed
     assert not np.array_equal(want[11][0], want[12][0])
+
+
+def test_one_over_f_calls_on_both_streams_do_not_share_scratch_unordered():
+    """The 1/f transforms keep one plan and one set of scratch buffers per context.  An asynchronous rip_synth_noise_1f (device
+    output, main stream) followed WITHOUT a host synchronisation by rip_synth_frames_ahead (second stream, another seed) must
+    leave both frame sets as serial runs make them (round-3 advisor: the second call used to start while the first was still
+    in the scratch)."""
+    rp = synth.READ_PATTERN_8
+    ny, nx, nb = 264, 512, 4
+    cal = synth.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=9)
+    ctx = _native.default_context(0)
+    s = sim_to_isim.L1Synth(cal, rp, synth.FRAME_TIME, ctx=ctx)
+    dev = s.dev
+    nfr = len(rp) * (nx // s.cw + 2)
+    counts = torch.full((ny - 2 * nb, nx - 2 * nb), 2500.0, dtype=torch.float32, device=dev)
+
+    def frames(seed):
+        out = torch.empty((nfr, ny, s.cw), dtype=torch.float32, device=dev)
+        ctx.check(ctx.lib.rip_synth_noise_1f(ctx.h, ny, s.cw, nfr, seed, 7, out.data_ptr()))
+        return out
+
+    def exposure(seed, ahead):
+        reads_e = s.apportion(counts, seed, poisson=True)
+        cube = s.resultants(reads_e, seed)["cube"]
+        a33 = torch.zeros((len(rp), ny, s.cw), dtype=torch.int16, device=dev)
+        torch.cuda.current_stream(dev).synchronize()   # torch's zero fill runs on torch's stream (the context's streams are not waited for)
+        if ahead:
+            ahead()
+        s.fill(cube, a33, seed)
+        ctx.synchronize()
+        return cube.cpu().numpy(), a33.cpu().numpy()
+
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    want_frames = frames(21).cpu().numpy()
+    ctx.synchronize()
+    want_exp = exposure(22, None)
+    for _ in range(3):
+        holder = {}
+
+        def both():
+            holder["f"] = frames(21)                                                  # main stream, asynchronous
+            ctx.check(ctx.lib.rip_synth_frames_ahead(ctx.h, ny, s.cw, nfr, 22))       # second stream, straight away
+
+        got_exp = exposure(22, both)
+        assert np.array_equal(holder["f"].cpu().numpy().view(np.uint32), want_frames.view(np.uint32))
+        assert np.array_equal(got_exp[0], want_exp[0]) and np.array_equal(got_exp[1], want_exp[1])
