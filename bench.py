@@ -286,6 +286,48 @@ def run_steps(cb, calls, warmup, steps, fence, ramp_s=0.0):
     return elapsed, ms, ncalls
 
 
+def host_path(cb, ramp, N, G, batch=8):
+    """ramps/s through the host-array entry points (rip_calibrate / rip_calibrate_batch with location = RIP_HOST) on CALDIR slot 0."""
+    def best_ms(fn, reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return 1e3 * min(ts)
+
+    shapes = {"slope": ((N, N), np.float32), "err_read": ((N, N), np.float32), "err_poisson": ((N, N), np.float32),
+              "pixeldq": ((N, N), np.uint32), "groupdq": ((G, N, N), np.uint8)}
+    h = {k: np.ascontiguousarray(ramp[k]) for k in ("data", "amp33", "groupdq", "pixeldq")}
+    host_ramp = dict(ramp, **h)
+    out_pg = {k: np.zeros(sh, dt) for k, (sh, dt) in shapes.items()}   # pageable, touched once (steady state of a caller's loop)
+    in_bytes = sum(v.nbytes for v in h.values())
+    out_bytes = sum(v.nbytes for v in out_pg.values())
+    res = {"pcie_bytes_in": in_bytes, "pcie_bytes_out": out_bytes, "pcie_bytes_out_without_groupdq": out_bytes - out_pg["groupdq"].nbytes}
+    for want_gdq in (True, False):
+        ms = best_ms(lambda: cb.calibrate(0, host_ramp, want_groupdq=want_gdq, out=out_pg), 5)
+        res["pageable" + ("" if want_gdq else "_no_groupdq_out")] = {"ms_per_ramp": ms, "ramps_per_s": 1e3 / ms}
+    cb.ctx.set_option("stage_pageable", 0)
+    ms = best_ms(lambda: cb.calibrate(0, host_ramp, want_groupdq=True, out=out_pg), 3)
+    cb.ctx.set_option("stage_pageable", 1)
+    res["pageable_plain_hipMemcpy"] = {"ms_per_ramp": ms, "ramps_per_s": 1e3 / ms}
+    pin = {k: cb.pinned_empty(v.shape, v.dtype) for k, v in h.items()}
+    for k in pin:
+        pin[k][...] = h[k]
+    pin_ramp = dict(ramp, **pin)
+    outs = [{k: cb.pinned_empty(sh, dt) for k, (sh, dt) in shapes.items()} for _ in range(batch)]
+    ms = best_ms(lambda: cb.calibrate(0, pin_ramp, want_groupdq=True, out=outs[0]), 5)
+    res["page_locked"] = {"ms_per_ramp": ms, "ramps_per_s": 1e3 / ms}
+    for k in ("slope", "pixeldq", "groupdq"):
+        if not np.array_equal(outs[0][k], out_pg[k], equal_nan=True):
+            raise SystemExit(f"bench: host path, {k} differs between pageable and page-locked arrays")
+    ms = best_ms(lambda: cb.calibrate_many(0, [pin_ramp] * batch, want_groupdq=True, out=outs), 3) / batch
+    res["batch_page_locked"] = {"ramps": batch, "ms_per_ramp": ms, "ramps_per_s": 1e3 / ms}
+    res["note"] = ("wall time of Calibrator.calibrate / calibrate_many on numpy arrays, best of 3-5, results into preallocated arrays; "
+                   "PCIe Gen5 x16: 63 GB/s per direction (spec)")
+    return res
+
+
 def partition(n_items, rank, world):
     """BASELINE config 4 / SURVEY 8e: item i belongs to rank i mod world."""
     return [i for i in range(n_items) if i % world == rank]
@@ -573,6 +615,11 @@ def main():
             out["chain"]["kernel_ms_sum_exclusive"] = ex + ms0[1] / max(nc0, 1)
             out["chain"]["frac_of_peak_sum_of_kernels"] = total / ((ex + ms0[1] / max(nc0, 1)) * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["chain"]["wall_ms_per_ramp_no_overlap"] = 1e3 * el0 / 30
+
+            # ---- the host-array boundary (what a drop-in user of calibrateimage sees: numpy arrays in, numpy arrays out over
+            # PCIe; never `value`): one ramp from pageable numpy arrays (staged through the context's page-locked ring,
+            # hostcopy.hip), from page-locked arrays, and a batch of 8 page-locked ramps through rip_calibrate_batch
+            out["host_path"] = host_path(cb, ramp, N, G)
 
             # ---- production-representative variants (measured by the driver's run, not only by the builder)
             variants = {}

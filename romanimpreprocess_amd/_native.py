@@ -61,7 +61,7 @@ class RampDesc(C.Structure):
         ("channel_lines", C.c_void_p),
         ("flag_saturation", C.c_int32), ("sat_backup", C.c_int32), ("sat_skip_firstn", C.c_int32),
         ("sat_dilution", C.c_void_p),
-        ("inputs_ready", C.c_int32), ("ready_event", C.c_void_p),
+        ("inputs_ready", C.c_int32), ("ready_event", C.c_void_p), ("or_first_group", C.c_int32),
     ]
 
 

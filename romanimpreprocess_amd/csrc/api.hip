@@ -147,6 +147,7 @@ void rip_ctx_destroy(rip_ctx *ctx) {
             delete p;
         }
     rip_pink_release(ctx);
+    rip_hostcopy_release(ctx);
     for (hipEvent_t e : {ctx->ev_tab[0], ctx->ev_tab[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_in, ctx->ev_pre, ctx->ev_frames, ctx->ev_fill, ctx->ev_pink})
         if (e) (void)hipEventDestroy(e);
     for (void *p : ctx->ws)   // every workspace slot, the Level-1 synthesis ones included
@@ -205,6 +206,10 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value) {
     }
     if (name && strcmp(name, "chain2") == 0) {
         ctx->use_chain2 = value != 0;
+        return RIP_OK;
+    }
+    if (name && strcmp(name, "stage_pageable") == 0) {
+        ctx->stage_pageable = value != 0;
         return RIP_OK;
     }
     if (name && strcmp(name, "chain_quad") == 0) {
@@ -726,11 +731,12 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         char *w = (char *)rip_ws(ctx, 2, tot);
         if (!w) return RIP_ENOMEM;
         size_t o = 0;
+        int rc_up = RIP_OK;
         auto put = [&](const void *src, size_t bytes) -> const void * {
             if (!src) return nullptr;
             void *dst = w + o;
             o += al(bytes);
-            (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+            if (!rc_up) rc_up = rip_host_to_device(ctx, dst, src, bytes, ctx->stream);   // (pageable arrays: staged, hostcopy.hip)
             return dst;
         };
         d_data = put(in->data, b_data);
@@ -739,7 +745,14 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         d_pdq = (const uint32_t *)put(in->pixeldq, b_pdq);
         d_area = (const double *)put(in->area_factor, b_area);
         d_lines_ovr = (const double *)put(in->channel_lines, (size_t)G * nch * 16);
+        if (rc_up) return rc_up;
         RIP_HIP(ctx, hipGetLastError());
+        // gen_cal_image.py:142-143 (rdq[0] |= DO_NOT_USE with EXCLUDE_FIRST) on the device copy, so that the host need not copy a
+        // 134 MB array to set one plane's bit
+        if (in->or_first_group && d_gdq) {
+            const int rco = rip_launch_or_bytes(ctx, (uint8_t *)d_gdq, npix, (uint8_t)DQ_DO_NOT_USE);
+            if (rco) return rco;
+        }
     }
     // ---- outputs on the device
     float *o_slope = out->slope, *o_er = out->err_read, *o_ep = out->err_poisson, *o_cube = out->cube;
@@ -1020,16 +1033,24 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     ctx->parity ^= 1;
     // ---- results back
     if (host) {
+        void *dsts[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        const void *srcs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        size_t nbytes[6] = {0, 0, 0, 0, 0, 0};
+        int nd = 0;
+        auto get = [&](void *dst, const void *src, size_t bytes) {
+            if (dst) dsts[nd] = dst, srcs[nd] = src, nbytes[nd] = bytes, ++nd;
+        };
         if (do_fit) {
-            RIP_HIP(ctx, hipMemcpyAsync(out->slope, o_slope, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
-            RIP_HIP(ctx, hipMemcpyAsync(out->err_read, o_er, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
-            RIP_HIP(ctx, hipMemcpyAsync(out->err_poisson, o_ep, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
-            RIP_HIP(ctx, hipMemcpyAsync(out->pixeldq, o_pdq, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
-            if (out->groupdq) RIP_HIP(ctx, hipMemcpyAsync(out->groupdq, o_gdq, b_gdq, hipMemcpyDeviceToHost, ctx->stream));
-        } else if (out->pixeldq) {
-            RIP_HIP(ctx, hipMemcpyAsync(out->pixeldq, pdq_mid, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+            get(out->slope, o_slope, npix * 4);
+            get(out->err_read, o_er, npix * 4);
+            get(out->err_poisson, o_ep, npix * 4);
+            get(out->pixeldq, o_pdq, npix * 4);
+            get(out->groupdq, o_gdq, b_gdq);
+        } else {
+            get(out->pixeldq, pdq_mid, npix * 4);
         }
-        if (out->cube) RIP_HIP(ctx, hipMemcpyAsync(out->cube, cur, (size_t)G * npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+        get(out->cube, cur, (size_t)G * npix * 4);
+        if ((rc = rip_device_to_host_many(ctx, nd, dsts, srcs, nbytes, ctx->stream))) return rc;   // (pageable arrays: staged)
         RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     } else {
         if (!do_fit && out->pixeldq && out->pixeldq != pdq_mid)

@@ -103,7 +103,7 @@ extern "C" int rip_calibrate_batch(rip_ctx *ctx, int slot, int plan_id, unsigned
             void *dst = b.in + o;
             o += slot_bytes;
             if (!src) return nullptr;
-            if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s_in) != hipSuccess) rc = RIP_EHIP;
+            if (rc == RIP_OK && rip_host_to_device(ctx, dst, src, bytes, s_in) != RIP_OK) rc = RIP_EHIP;   // (pageable: staged)
             return dst;
         };
         rd.data = put(ri.data, (size_t)G * npix * esz, b_data);
@@ -112,6 +112,8 @@ extern "C" int rip_calibrate_batch(rip_ctx *ctx, int slot, int plan_id, unsigned
         rd.pixeldq = (const uint32_t *)put(ri.pixeldq, npix * 4, b_pdq);
         rd.area_factor = (const double *)put(ri.area_factor, npix * 8, b_area);
         rd.channel_lines = (const double *)put(ri.channel_lines, (size_t)G * nch * 16, b_lines);
+        if (rc == RIP_OK && ri.or_first_group && rd.groupdq) rc = rip_launch_or_bytes(ctx, (uint8_t *)rd.groupdq, npix, (uint8_t)DQ_DO_NOT_USE, s_in);
+        rd.or_first_group = 0;
         if (rc != RIP_OK) {
             rc = rip_fail(ctx, RIP_EHIP, "calibrate_batch: upload of ramp %d failed", i);
             cleanup();
@@ -136,11 +138,15 @@ extern "C" int rip_calibrate_batch(rip_ctx *ctx, int slot, int plan_id, unsigned
         BATCH_HIP(hipEventRecord(b.ev_done, ctx->stream));
         // download
         BATCH_HIP(hipStreamWaitEvent(s_out, b.ev_done, 0));
-        BATCH_HIP(hipMemcpyAsync(ro.slope, od.slope, npix * 4, hipMemcpyDeviceToHost, s_out));
-        BATCH_HIP(hipMemcpyAsync(ro.err_read, od.err_read, npix * 4, hipMemcpyDeviceToHost, s_out));
-        BATCH_HIP(hipMemcpyAsync(ro.err_poisson, od.err_poisson, npix * 4, hipMemcpyDeviceToHost, s_out));
-        BATCH_HIP(hipMemcpyAsync(ro.pixeldq, od.pixeldq, npix * 4, hipMemcpyDeviceToHost, s_out));
-        if (ro.groupdq) BATCH_HIP(hipMemcpyAsync(ro.groupdq, od.groupdq, (size_t)G * npix, hipMemcpyDeviceToHost, s_out));
+        {   // (page-locked arrays: queued; pageable ones: staged through the context's ring, complete on return)
+            void *dsts[5] = {ro.slope, ro.err_read, ro.err_poisson, ro.pixeldq, ro.groupdq};
+            const void *srcs[5] = {od.slope, od.err_read, od.err_poisson, od.pixeldq, od.groupdq};
+            const size_t nbytes[5] = {npix * 4, npix * 4, npix * 4, npix * 4, ro.groupdq ? (size_t)G * npix : 0};
+            if ((rc = rip_device_to_host_many(ctx, 5, dsts, srcs, nbytes, s_out)) != RIP_OK) {
+                cleanup();
+                return rc;
+            }
+        }
         BATCH_HIP(hipEventRecord(b.ev_out, s_out));
         b.used = true;
         ctx->batch_completed = i + 1;

@@ -233,3 +233,18 @@ int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const flo
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
 }
+
+// bytes[0 .. n) |= bit (the DO_NOT_USE flag of an excluded first group on the library's device copy of groupdq)
+__global__ __launch_bounds__(256) void or_bytes_kernel(uint32_t *__restrict__ w, size_t n4, uint32_t bits) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) w[i] |= bits;
+}
+int rip_launch_or_bytes(rip_ctx *ctx, uint8_t *bytes, size_t n, uint8_t bit, hipStream_t stream) {
+    if ((n & 3) || ((uintptr_t)bytes & 3)) return rip_fail(ctx, RIP_EINVAL, "or_bytes: plane of %zu bytes is not a whole number of words", n);
+    hipStream_t st = stream ? stream : ctx->stream;
+    const uint32_t b = bit;
+    hipLaunchKernelGGL(or_bytes_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (uint32_t *)bytes, n / 4,
+                       b | (b << 8) | (b << 16) | (b << 24));
+    RIP_HIP(ctx, hipGetLastError());
+    return RIP_OK;
+}

@@ -117,8 +117,12 @@ struct RipCal {
     size_t bytes = 0;
 };
 
+struct RipHostCopy;   // hostcopy.hip: page-locked staging ring + copy threads for pageable host arrays
+
 struct rip_ctx {
     int device = 0;
+    RipHostCopy *hostcopy = nullptr;   // made at the first pageable host array
+    int stage_pageable = 1;            // option "stage_pageable": 0 = plain hipMemcpy from / to pageable memory
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;          // reference-pixel pre-pass of the NEXT ramp (device-resident inputs)
     hipEvent_t ev_tab[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -183,6 +187,11 @@ struct rip_ctx {
 };
 
 // ---------------------------------------------------------------- host helpers
+// hostcopy.hip: host <-> device copies that stage PAGEABLE host memory through the context's page-locked ring (PCIe rate);
+// page-locked host memory is copied directly.  rip_host_to_device returns once the host array has been read.
+int rip_host_to_device(rip_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t st);
+int rip_device_to_host_many(rip_ctx *ctx, int n, void *const *dst, const void *const *src, const size_t *bytes, hipStream_t st);
+void rip_hostcopy_release(rip_ctx *ctx);
 int rip_fail(rip_ctx *ctx, int code, const char *fmt, ...);
 void rip_pink_release(rip_ctx *ctx);   // pink.hip: drops the cached transform plan and buffers
 void *rip_ws(rip_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error recorded)
@@ -329,6 +338,7 @@ int rip_launch_flat_area(rip_ctx *ctx, const float *flat_dn, const double *area,
 // out = lin_dq | (flat_flags or 0) | (dark_dq on the active region or 0); *d_clash |= added bits & (NO_LIN_CORR | REFERENCE_PIXEL)
 int rip_launch_merge_dq(rip_ctx *ctx, const uint32_t *lin_dq, const uint32_t *flat_flags, const uint32_t *dark_dq, uint32_t *out, int ny,
                         int nx, int nb, uint32_t *d_clash);
+int rip_launch_or_bytes(rip_ctx *ctx, uint8_t *bytes, size_t n, uint8_t bit, hipStream_t stream = nullptr);
 // dq-init + saturation flagging (misc.hip): gdq_in / pdq_in may be null (= zeros)
 int rip_launch_satflag(rip_ctx *ctx, const void *data, int data_dtype, const float *thr, const uint32_t *sat_dq,
                        const uint8_t *gdq_in, const uint32_t *pdq_in, uint8_t *gdq_out, uint32_t *pdq_out, int G, int ny,

@@ -83,10 +83,8 @@ class Calibrator:
             raise ValueError(f"ramp shape {data.shape} does not match the CALDIR frame {(ny, nx)}")
         gdq = None
         if ramp.get("groupdq") is not None:
-            gdq = np.ascontiguousarray(ramp["groupdq"], dtype=np.uint8)
-            if exclude_first and not np.all(gdq[0] & np.uint8(1)):
-                gdq = gdq.copy()  # the caller's array stays as it is
-                gdq[0] |= np.uint8(1)  # gen_cal_image.py:142-143
+            gdq = np.ascontiguousarray(ramp["groupdq"], dtype=np.uint8)   # (DO_NOT_USE on an excluded first group: set on the
+            #                                                              library's device copy, rd.or_first_group below)
         elif not flag_saturation:
             raise ValueError("ramp['groupdq'] is required unless flag_saturation is set")
         pdq = np.ascontiguousarray(ramp["pixeldq"], dtype=np.uint32)
@@ -100,6 +98,7 @@ class Calibrator:
         rd.amp33 = None if amp33 is None else amp33.ctypes.data
         rd.groupdq, rd.pixeldq = (None if gdq is None else gdq.ctypes.data), pdq.ctypes.data
         rd.flag_saturation = 1 if flag_saturation else 0
+        rd.or_first_group = 1 if (exclude_first and gdq is not None) else 0   # gen_cal_image.py:142-143, the caller's array untouched
         rd.sat_backup, rd.sat_skip_firstn = int(saturation_backup), int(saturation_skip_firstn)
         dil = read_pattern_dilution(ramp["read_pattern"]) if (flag_saturation and saturation_read_pattern) else None
         rd.sat_dilution = None if dil is None else dil.ctypes.data
@@ -166,10 +165,7 @@ class Calibrator:
                 raise ValueError(f"ramp {i}: shape {data.shape} does not match the CALDIR frame {(ny, nx)}")
             gdq = None
             if ramp.get("groupdq") is not None:
-                gdq = np.ascontiguousarray(ramp["groupdq"], dtype=np.uint8)
-                if exclude_first and not np.all(gdq[0] & np.uint8(1)):
-                    gdq = gdq.copy()
-                    gdq[0] |= np.uint8(1)  # gen_cal_image.py:142-143
+                gdq = np.ascontiguousarray(ramp["groupdq"], dtype=np.uint8)   # (DO_NOT_USE on an excluded first group: rd.or_first_group)
             elif not flag_saturation:
                 raise ValueError(f"ramp {i}: groupdq is required unless flag_saturation is set")
             pdq = np.ascontiguousarray(ramp["pixeldq"], dtype=np.uint32)
@@ -181,6 +177,7 @@ class Calibrator:
             rd.amp33 = None if amp33 is None else amp33.ctypes.data
             rd.groupdq, rd.pixeldq = (None if gdq is None else gdq.ctypes.data), pdq.ctypes.data
             rd.flag_saturation = 1 if flag_saturation else 0
+            rd.or_first_group = 1 if (exclude_first and gdq is not None) else 0   # gen_cal_image.py:142-143 on the device copy
             rd.sat_backup, rd.sat_skip_firstn = int(saturation_backup), int(saturation_skip_firstn)
             if dil is not None:
                 rd.sat_dilution = dil.ctypes.data

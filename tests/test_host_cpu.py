@@ -34,7 +34,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
                             "saturation_dq"],
         "rip_plan_desc": ["ngrp", "tbar", "nreads", "K", "nvariants", "variant_coef", "sthresh_a", "ithresh_b"],
         "rip_ramp_desc": ["location", "data", "data_dtype", "amp33", "area_factor", "channel_lines", "flag_saturation",
-                          "sat_skip_firstn", "sat_dilution"],
+                          "sat_skip_firstn", "sat_dilution", "inputs_ready", "ready_event", "or_first_group"],
         "rip_outputs": ["location", "slope", "pixeldq", "groupdq", "cube"],
         "rip_synth_cal": ["ny", "channelwidth", "amp33_valid", "gain", "dark", "smax", "ipc4d", "biascorr", "tbias", "amp33_std",
                           "m_pink", "c_pink"],
