@@ -307,10 +307,8 @@ def host_path(cb, ramp, N, G, batch=8):
     for want_gdq in (True, False):
         ms = best_ms(lambda: cb.calibrate(0, host_ramp, want_groupdq=want_gdq, out=out_pg), 5)
         res["pageable" + ("" if want_gdq else "_no_groupdq_out")] = {"ms_per_ramp": ms, "ramps_per_s": 1e3 / ms}
-    cb.ctx.set_option("stage_pageable", 0)
-    ms = best_ms(lambda: cb.calibrate(0, host_ramp, want_groupdq=True, out=out_pg), 3)
-    cb.ctx.set_option("stage_pageable", 1)
-    res["pageable_plain_hipMemcpy"] = {"ms_per_ramp": ms, "ramps_per_s": 1e3 / ms}
+    ms = best_ms(lambda: cb.calibrate(0, host_ramp, want_groupdq=True), 3)   # results into fresh numpy arrays (first-touch page faults)
+    res["pageable_fresh_result_arrays"] = {"ms_per_ramp": ms, "ramps_per_s": 1e3 / ms}
     pin = {k: cb.pinned_empty(v.shape, v.dtype) for k, v in h.items()}
     for k in pin:
         pin[k][...] = h[k]
@@ -326,6 +324,58 @@ def host_path(cb, ramp, N, G, batch=8):
     res["note"] = ("wall time of Calibrator.calibrate / calibrate_many on numpy arrays, best of 3-5, results into preallocated arrays; "
                    "PCIe Gen5 x16: 63 GB/s per direction (spec)")
     return res
+
+
+def gather_elapsed(torch, dist, elapsed, world, cdev):
+    """(maximum over the ranks, list of every rank's elapsed seconds)"""
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    if world == 1:
+        return elapsed, [elapsed]
+    all_t = [torch.empty_like(t_el) for _ in range(world)]
+    dist.all_gather(all_t, t_el)
+    per_rank = [float(t.item()) for t in all_t]
+    return max(per_rank), per_rank
+
+
+def run_realizations(args, cb, torch, dist, fence, rank, world, local_rank, cdev):
+    """--workload realizations: BASELINE config 5 through harness/many_realizations.py -- `--realizations` noise seeds of one scene
+    generated on the device (the reference's synthesis steps as HIP kernels), calibrated, stacked in HBM, exchanged (all-to-all:
+    realisations -> rows) and reduced to the eight statistics planes on rank 0.  Strong scaling: the seeds are shared by the ranks."""
+    from romanimpreprocess_amd import synth, synth_gpu
+    from romanimpreprocess_amd.harness import many_realizations as mr
+
+    N, n = args.side, args.realizations
+    rp = synth.READ_PATTERN_8 if args.groups == 8 else synth.READ_PATTERN_16
+    cal = synth_gpu.make_caldir(N, N, read_pattern=rp, p_order=args.p_order, seed=1001,
+                                ipc_dtype=np.float64 if args.ipc_dtype == "f64" else np.float32, device=local_rank)
+    cb.load_caldir(0, cal)
+    mr.run(cb, 0, cal, nseeds=max(world, 2), seed0=900, read_pattern=rp, generator="hip")   # warm-up: plans, workspaces, clocks
+    fence()
+    tm = {}
+    t0 = time.perf_counter()
+    planes = mr.run(cb, 0, cal, nseeds=n, seed0=100, read_pattern=rp, generator="hip", timings=tm)
+    fence()
+    elapsed, per_rank = gather_elapsed(torch, dist, time.perf_counter() - t0, world, cdev)
+    if rank == 0:
+        good = planes[3][4:-4, 4:-4]
+        ok = good > n // 2
+        if not (ok.mean() > 0.5 and np.isfinite(planes[6][4:-4, 4:-4][ok]).all()):
+            raise SystemExit("bench sanity check failed: statistics planes of the realisations")
+        print(json.dumps({
+            "metric": f"noise realisations/s ({N}x{N}x{len(rp)}grp: generate + calibrate + stack + exchange + reduce)",
+            "value": n / elapsed, "unit": "realisations/s", "n_gpus": world, "steps": n, "warmup": max(world, 2),
+            "ms_per_step": 1e3 * elapsed / n, "elapsed_s_per_rank": per_rank, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"many_realizations: {n} noise seeds of one {N}x{N}x{len(rp)}-group scene, seed j on rank j mod {world}; "
+                                   "stacks (13 B per pixel and realisation) resident in HBM, one all-to-all per stack, planes gathered on rank 0",
+                       "sharding": ("RCCL" if args.dist_backend == "nccl" else "gloo (rehearsal)")
+                                   + ("; ranks share one GPU (rehearsal, not a scaling measurement)" if args.share_gpu else "")},
+            "phases_rank0_s": tm,
+            "median_bias_DN_per_s": float(np.median(planes[6][4:-4, 4:-4][ok])),
+            "median_scatter_over_pipeline_error": float(np.median((planes[5] / np.maximum(planes[7], 1e-9))[4:-4, 4:-4][ok]))}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def partition(n_items, rank, world):
@@ -371,18 +421,17 @@ def dry_run(args, rank, world):
     for _ in range(args.steps):
         time.sleep(0.001)
     fence()
-    t_el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    elapsed, per_rank = gather_elapsed(torch, dist, time.perf_counter() - t0, world, "cpu")
     all_items = [None] * world
     if world > 1:
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_gather_object(all_items, mine)
     else:
         all_items = [mine]
-    elapsed = float(t_el.item())
     if rank == 0:
         print(json.dumps({
             "metric": "SCA ramps/sec (dry run: no device work)", "value": world * args.steps / elapsed, "unit": "ramps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "elapsed_s_per_rank": per_rank,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none", "dry_run": True,
             "config": {"workload": f"dry run of --workload {args.workload}: a step is a 1 ms sleep",
                        "sharding": f"items round-robin over {world} rank(s), index list broadcast over gloo",
@@ -399,7 +448,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--clock-ramp-s", type=float, default=0.5,
                     help="seconds of untimed calls before the warm-up steps, so that the timed steps run at the steady clock")
-    ap.add_argument("--workload", default="single", choices=("single", "batch72"))
+    ap.add_argument("--workload", default="single", choices=("single", "batch72", "realizations"))
+    ap.add_argument("--realizations", type=int, default=256,
+                    help="--workload realizations (BASELINE config 5): noise realisations of one scene in all, shared by the ranks")
     ap.add_argument("--groups", type=int, default=8, choices=(8, 16))
     ap.add_argument("--side", type=int, default=4096)
     ap.add_argument("--ipc-dtype", default="f32", choices=("f32", "f64"),
@@ -419,6 +470,15 @@ def main():
                          "as they are, a step is a 1 ms sleep; the line carries dry_run: true and is not a measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and not args.share_gpu and not args.dry_run:
+        # one GPU per rank: checked before any rendezvous (counting devices does not initialise the GPU on this image), by the
+        # spawning process and by every rank a launcher started
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, {have} visible here "
+                             "(rehearsal on fewer GPUs: --dist-backend gloo --share-gpu; no GPU at all: --dry-run)")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -471,6 +531,9 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    if args.workload == "realizations":
+        return run_realizations(args, cb, torch, dist, fence, rank, world, local_rank, cdev)
 
     def call_for(slot, pid, G, res):
         o = res.outs
@@ -548,10 +611,7 @@ def main():
     assert len(mine) >= 1 and mine == partition(n_items, rank, world)
 
     elapsed, ms, ncalls = run_steps(cb, calls, args.warmup, args.steps, fence, ramp_s=args.clock_ramp_s)
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-    elapsed = float(t_el.item())
+    elapsed, per_rank = gather_elapsed(torch, dist, elapsed, world, cdev)
     frac_good = sane(res)
 
     if rank == 0:
@@ -581,6 +641,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "elapsed_s_per_rank": per_rank,   # the timed region of every rank (value uses the maximum): imbalance is visible
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -617,8 +678,8 @@ def main():
             out["chain"]["wall_ms_per_ramp_no_overlap"] = 1e3 * el0 / 30
 
             # ---- the host-array boundary (what a drop-in user of calibrateimage sees: numpy arrays in, numpy arrays out over
-            # PCIe; never `value`): one ramp from pageable numpy arrays (staged through the context's page-locked ring,
-            # hostcopy.hip), from page-locked arrays, and a batch of 8 page-locked ramps through rip_calibrate_batch
+            # PCIe; never `value`): one ramp from pageable numpy arrays, from page-locked arrays, and a batch of 8 page-locked
+            # ramps through rip_calibrate_batch
             out["host_path"] = host_path(cb, ramp, N, G)
 
             # ---- production-representative variants (measured by the driver's run, not only by the builder)

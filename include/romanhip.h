@@ -415,8 +415,6 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value);
                 front of its own ramp on the same stream as the single launch of refpix_one.hip (0.068 against 0.094 ms) where
                 it covers the frame (up to 4096 rows, a reference output); 0 = refpix.hip always; 1 = refpix_one.hip wherever
                 it covers the frame;
-   "stage_pageable" -- (default 1) pageable host arrays go through the context's page-locked staging ring (hostcopy.hip: PCIe
-                rate whatever memory the caller's arrays live in); 0 = plain hipMemcpy;
    "chain_reserve" -- (default 8) workgroup slots the 256-column fused kernel's grid leaves free; "chain_quad" -- (default 1) a
                 last strip of at most 64 live columns is covered by workgroups whose four wave columns take a row range each
                 (4096 x 4096: 504 workgroups of 139 steps instead of 510 of 143; timing-neutral, profiles/r04_summary.md);

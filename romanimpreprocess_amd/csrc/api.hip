@@ -147,7 +147,6 @@ void rip_ctx_destroy(rip_ctx *ctx) {
             delete p;
         }
     rip_pink_release(ctx);
-    rip_hostcopy_release(ctx);
     for (hipEvent_t e : {ctx->ev_tab[0], ctx->ev_tab[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_in, ctx->ev_pre, ctx->ev_frames, ctx->ev_fill, ctx->ev_pink})
         if (e) (void)hipEventDestroy(e);
     for (void *p : ctx->ws)   // every workspace slot, the Level-1 synthesis ones included
@@ -206,10 +205,6 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value) {
     }
     if (name && strcmp(name, "chain2") == 0) {
         ctx->use_chain2 = value != 0;
-        return RIP_OK;
-    }
-    if (name && strcmp(name, "stage_pageable") == 0) {
-        ctx->stage_pageable = value != 0;
         return RIP_OK;
     }
     if (name && strcmp(name, "chain_quad") == 0) {
@@ -736,7 +731,9 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
             if (!src) return nullptr;
             void *dst = w + o;
             o += al(bytes);
-            if (!rc_up) rc_up = rip_host_to_device(ctx, dst, src, bytes, ctx->stream);   // (pageable arrays: staged, hostcopy.hip)
+            // (pageable arrays too: the runtime's own staging runs at the page-locked rate -- 16.7 against 16.5 ms per 4096 x 4096 x 8
+            // ramp; a ring of page-locked slots fed by copy threads was measured SLOWER, 18.0 ms: profiles/r04_summary.md)
+            if (!rc_up && hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc_up = RIP_EHIP;
             return dst;
         };
         d_data = put(in->data, b_data);
@@ -745,7 +742,7 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
         d_pdq = (const uint32_t *)put(in->pixeldq, b_pdq);
         d_area = (const double *)put(in->area_factor, b_area);
         d_lines_ovr = (const double *)put(in->channel_lines, (size_t)G * nch * 16);
-        if (rc_up) return rc_up;
+        if (rc_up) return rip_fail(ctx, RIP_EHIP, "calibrate: upload of the ramp failed: %s", hipGetErrorString(hipGetLastError()));
         RIP_HIP(ctx, hipGetLastError());
         // gen_cal_image.py:142-143 (rdq[0] |= DO_NOT_USE with EXCLUDE_FIRST) on the device copy, so that the host need not copy a
         // 134 MB array to set one plane's bit
@@ -1033,24 +1030,16 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
     ctx->parity ^= 1;
     // ---- results back
     if (host) {
-        void *dsts[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        const void *srcs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        size_t nbytes[6] = {0, 0, 0, 0, 0, 0};
-        int nd = 0;
-        auto get = [&](void *dst, const void *src, size_t bytes) {
-            if (dst) dsts[nd] = dst, srcs[nd] = src, nbytes[nd] = bytes, ++nd;
-        };
         if (do_fit) {
-            get(out->slope, o_slope, npix * 4);
-            get(out->err_read, o_er, npix * 4);
-            get(out->err_poisson, o_ep, npix * 4);
-            get(out->pixeldq, o_pdq, npix * 4);
-            get(out->groupdq, o_gdq, b_gdq);
-        } else {
-            get(out->pixeldq, pdq_mid, npix * 4);
+            RIP_HIP(ctx, hipMemcpyAsync(out->slope, o_slope, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+            RIP_HIP(ctx, hipMemcpyAsync(out->err_read, o_er, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+            RIP_HIP(ctx, hipMemcpyAsync(out->err_poisson, o_ep, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+            RIP_HIP(ctx, hipMemcpyAsync(out->pixeldq, o_pdq, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (out->groupdq) RIP_HIP(ctx, hipMemcpyAsync(out->groupdq, o_gdq, b_gdq, hipMemcpyDeviceToHost, ctx->stream));
+        } else if (out->pixeldq) {
+            RIP_HIP(ctx, hipMemcpyAsync(out->pixeldq, pdq_mid, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
-        get(out->cube, cur, (size_t)G * npix * 4);
-        if ((rc = rip_device_to_host_many(ctx, nd, dsts, srcs, nbytes, ctx->stream))) return rc;   // (pageable arrays: staged)
+        if (out->cube) RIP_HIP(ctx, hipMemcpyAsync(out->cube, cur, (size_t)G * npix * 4, hipMemcpyDeviceToHost, ctx->stream));
         RIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     } else {
         if (!do_fit && out->pixeldq && out->pixeldq != pdq_mid)

@@ -103,7 +103,7 @@ extern "C" int rip_calibrate_batch(rip_ctx *ctx, int slot, int plan_id, unsigned
             void *dst = b.in + o;
             o += slot_bytes;
             if (!src) return nullptr;
-            if (rc == RIP_OK && rip_host_to_device(ctx, dst, src, bytes, s_in) != RIP_OK) rc = RIP_EHIP;   // (pageable: staged)
+            if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s_in) != hipSuccess) rc = RIP_EHIP;
             return dst;
         };
         rd.data = put(ri.data, (size_t)G * npix * esz, b_data);
@@ -138,15 +138,11 @@ extern "C" int rip_calibrate_batch(rip_ctx *ctx, int slot, int plan_id, unsigned
         BATCH_HIP(hipEventRecord(b.ev_done, ctx->stream));
         // download
         BATCH_HIP(hipStreamWaitEvent(s_out, b.ev_done, 0));
-        {   // (page-locked arrays: queued; pageable ones: staged through the context's ring, complete on return)
-            void *dsts[5] = {ro.slope, ro.err_read, ro.err_poisson, ro.pixeldq, ro.groupdq};
-            const void *srcs[5] = {od.slope, od.err_read, od.err_poisson, od.pixeldq, od.groupdq};
-            const size_t nbytes[5] = {npix * 4, npix * 4, npix * 4, npix * 4, ro.groupdq ? (size_t)G * npix : 0};
-            if ((rc = rip_device_to_host_many(ctx, 5, dsts, srcs, nbytes, s_out)) != RIP_OK) {
-                cleanup();
-                return rc;
-            }
-        }
+        BATCH_HIP(hipMemcpyAsync(ro.slope, od.slope, npix * 4, hipMemcpyDeviceToHost, s_out));
+        BATCH_HIP(hipMemcpyAsync(ro.err_read, od.err_read, npix * 4, hipMemcpyDeviceToHost, s_out));
+        BATCH_HIP(hipMemcpyAsync(ro.err_poisson, od.err_poisson, npix * 4, hipMemcpyDeviceToHost, s_out));
+        BATCH_HIP(hipMemcpyAsync(ro.pixeldq, od.pixeldq, npix * 4, hipMemcpyDeviceToHost, s_out));
+        if (ro.groupdq) BATCH_HIP(hipMemcpyAsync(ro.groupdq, od.groupdq, (size_t)G * npix, hipMemcpyDeviceToHost, s_out));
         BATCH_HIP(hipEventRecord(b.ev_out, s_out));
         b.used = true;
         ctx->batch_completed = i + 1;

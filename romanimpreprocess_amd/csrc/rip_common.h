@@ -117,12 +117,8 @@ struct RipCal {
     size_t bytes = 0;
 };
 
-struct RipHostCopy;   // hostcopy.hip: page-locked staging ring + copy threads for pageable host arrays
-
 struct rip_ctx {
     int device = 0;
-    RipHostCopy *hostcopy = nullptr;   // made at the first pageable host array
-    int stage_pageable = 1;            // option "stage_pageable": 0 = plain hipMemcpy from / to pageable memory
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;          // reference-pixel pre-pass of the NEXT ramp (device-resident inputs)
     hipEvent_t ev_tab[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -187,11 +183,6 @@ struct rip_ctx {
 };
 
 // ---------------------------------------------------------------- host helpers
-// hostcopy.hip: host <-> device copies that stage PAGEABLE host memory through the context's page-locked ring (PCIe rate);
-// page-locked host memory is copied directly.  rip_host_to_device returns once the host array has been read.
-int rip_host_to_device(rip_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t st);
-int rip_device_to_host_many(rip_ctx *ctx, int n, void *const *dst, const void *const *src, const size_t *bytes, hipStream_t st);
-void rip_hostcopy_release(rip_ctx *ctx);
 int rip_fail(rip_ctx *ctx, int code, const char *fmt, ...);
 void rip_pink_release(rip_ctx *ctx);   // pink.hip: drops the cached transform plan and buffers
 void *rip_ws(rip_ctx *ctx, int slot, size_t bytes);  // nullptr on failure (error recorded)

@@ -276,3 +276,26 @@ def test_bench_gpus_n_spawns_its_own_ranks():
     out1, lines1 = _bench_json([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run"],
                                env=dict(env, WORLD_SIZE="1", RANK="0"))
     assert out1.returncode != 0 and not lines1 and "WORLD_SIZE=1" in (out1.stderr + out1.stdout)
+
+
+def test_bench_refuses_more_ranks_than_gpus_before_any_rendezvous():
+    """`--gpus N` with fewer than N GPUs visible (and no --share-gpu rehearsal) ends with ONE clear line -- from the spawning process
+    and from a rank a launcher started -- instead of a rendezvous that fails in every rank."""
+    import json  # noqa: F401
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out, lines = _bench_json([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env)
+    assert out.returncode != 0 and not lines
+    msg = out.stderr + out.stdout
+    assert "--gpus 2 needs 2 GPUs" in msg and msg.count("needs 2 GPUs") == 1
+    out, lines = _bench_json([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                             env=dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1"))
+    assert out.returncode != 0 and not lines and "--gpus 2 needs 2 GPUs" in (out.stderr + out.stdout)
+    # the dry run carries every rank's elapsed time
+    out, lines = _bench_json([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"], env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert len(d["elapsed_s_per_rank"]) == 2 and max(d["elapsed_s_per_rank"]) * 1e3 / 3 == pytest.approx(d["ms_per_step"])
