@@ -72,7 +72,9 @@ def kernel_source_hash():
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("chain2_kernel.h", "chain_common.h", "device_rampfit.h", "rip_common.h", "Makefile"):
+    names = ["chain2_kernel.h", "chain_common.h", "device_rampfit.h", "rip_common.h", "Makefile", "chain.hip"]
+    names += [f"chain_np{n}{k}.hip" for n in (4, 9, 11) for k in ("", "_k64")]   # they select the instantiation that runs
+    for name in names:
         with open(os.path.join(REPO, "romanimpreprocess_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -1274,6 +1274,7 @@ int rip_stage_jump_detect(rip_ctx *ctx, int plan_id, const float *data, uint8_t 
     if (!data || !rdq || !gain || !read_noise || !slope || !err_read || !err_poisson || !smap)
         return rip_fail(ctx, RIP_EINVAL, "jump_detect: NULL array");
     const int G = plan->h.ngrp, nd = plan->variants[0].ndiff;
+    if (G < 2 || nd <= 0) return rip_fail(ctx, RIP_EINVAL, "jump_detect: a plan of %d groups has no difference to test", G);
     const size_t npix = (size_t)ny * nx;
     DevBuf dd, dr, dg, dn, ds, de, dp, dm;
     int rc;

@@ -116,9 +116,13 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
     st_thread = threading.Thread(target=_alloc_stacks, daemon=True)
     st_thread.start()
 
+    join_wait = [0.0]
+
     def stacks():
         if st_thread.is_alive():
+            tj = time.perf_counter()
             st_thread.join()
+            join_wait[0] += time.perf_counter() - tj   # reported on its own ("stack_allocation_wait_s"), not as calibration time
         if "exc" in st_box:
             raise st_box["exc"]
         return st_box["st"]
@@ -144,7 +148,7 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
         raise ValueError(f"generator {generator!r}: host, device or hip")
     t_gen = t_cal = 0.0
     torch.cuda.synchronize(device)
-    t_setup = time.perf_counter() - t_start   # rate image, stacks in HBM, generator state
+    t_setup = time.perf_counter() - t_start   # rate image, generator state (the stacks are still being allocated by the helper thread)
     for k, sd in enumerate(seeds):
         t0 = time.perf_counter()
         if hip_synth is not None:
@@ -189,6 +193,7 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
                          ctx=calibrator.ctx)
     full = sharding.gather_rows(planes, ny)
     if timings is not None:
-        timings.update({"setup_s": t_setup, "generate_s": t_gen, "calibrate_and_stack_s": t_cal,
+        timings.update({"setup_s": t_setup, "generate_s": t_gen, "calibrate_and_stack_s": t_cal - join_wait[0],
+                        "stack_allocation_wait_s": join_wait[0],
                         "exchange_and_reduce_s": time.perf_counter() - t_red, "realisations_on_this_rank": len(seeds)})
     return None if full is None else full.cpu().numpy()

@@ -12,6 +12,9 @@ from .. import _native, calio, plan as planmod
 from ..plan import construct_weights  # noqa: F401  (re-exported: same name and meaning as the reference)
 
 
+_JUMP_DET = 4   # dqflags.group.JUMP_DET
+
+
 def ramp_fit(data, rdq, pdq, meta, caldir, mylog, exclude_first=True, ctx=None):
     """Fit slopes to ``data`` (ngrp,ny,nx) f32; ``rdq`` (u8) and ``pdq`` (u32) are updated in place.
 
@@ -49,8 +52,8 @@ def ramp_fit(data, rdq, pdq, meta, caldir, mylog, exclude_first=True, ctx=None):
 
 
 def jump_detect(data, rdq, pdq, meta, caldir, mylog, exclude_first=True, truncate_ramp=None, ctx=None):
-    """One pass of slope fit + jump flagging (``fitting.py:89-255``).  ``data`` (ngrp,ny,nx) f32; ``rdq`` (uint8 cube of
-    at least the fitted groups) gets JUMP_DET OR-ed in place on the active region; ``pdq`` only gives the frame shape, as
+    """One pass of slope fit + jump flagging (``fitting.py:89-255``).  ``data`` (ngrp,ny,nx) f32; ``rdq`` (uint8 -- or, as the
+    reference's own cube, uint32 -- of at least the fitted groups) gets JUMP_DET OR-ed in place on the active region; ``pdq`` only gives the frame shape, as
     in the reference.  ``truncate_ramp=t``: groups [0, t) with the two-point weights of ``fitting.py:162-167``.
     Returns (slope, slope_err_read, slope_err_poisson, smap); ``smap`` is (2*(g-start)-3, ny, nx) float32."""
     ctx = ctx or _native.default_context()
@@ -62,8 +65,8 @@ def jump_detect(data, rdq, pdq, meta, caldir, mylog, exclude_first=True, truncat
         raise ValueError(f"data {data.shape} does not hold {g} groups of {(ny, nx)}")
     if 2 * (g - start) - 3 < 0 or g > int(meta["ngrp"]):
         raise ValueError(f"cannot fit {g} groups (exclude_first={exclude_first}, ngrp={meta['ngrp']})")
-    if rdq.dtype != np.uint8 or not rdq.flags.c_contiguous or rdq.shape[0] < g or rdq.shape[1:] != (ny, nx):
-        raise TypeError("rdq must be a C-contiguous uint8 cube of at least the fitted groups (updated in place)")
+    if not isinstance(rdq, np.ndarray) or rdq.dtype not in (np.uint8, np.uint32) or rdq.shape[0] < g or rdq.shape[1:] != (ny, nx):
+        raise TypeError("rdq must be a uint8 or uint32 cube of at least the fitted groups (updated in place)")
     if truncate_ramp is None:
         K = np.asarray(meta["K"], dtype=np.float32)
     else:   # fitting.py:162-167, float32 as there
@@ -81,13 +84,17 @@ def jump_detect(data, rdq, pdq, meta, caldir, mylog, exclude_first=True, truncat
     pid = ctx.create_plan(desc)
     try:
         cube = np.ascontiguousarray(data[:g])
-        flags = np.ascontiguousarray(rdq[:g])
+        # the group flags the device reads are the low byte (DO_NOT_USE, SATURATED, JUMP_DET); a uint32 cube keeps its other bits
+        flags = np.ascontiguousarray(rdq[:g], dtype=np.uint8) if rdq.dtype == np.uint8 else (rdq[:g] & np.uint32(0xFF)).astype(np.uint8)
         slope, er, ep = (np.empty((ny, nx), np.float32) for _ in range(3))
         smap = np.zeros((2 * (g - start) - 3, ny, nx), np.float32)
         ctx.check(ctx.lib.rip_stage_jump_detect(
             ctx.h, pid, cube.ctypes.data, flags.ctypes.data, ny, nx, int(meta["nborder"]), gain.ctypes.data,
             _native.dtype_code(gain), read.ctypes.data, slope.ctypes.data, er.ctypes.data, ep.ctypes.data, smap.ctypes.data))
-        rdq[:g] = flags
+        if rdq.dtype == np.uint8:
+            rdq[:g] = flags
+        else:
+            rdq[:g] |= flags.astype(np.uint32) & np.uint32(_JUMP_DET)   # the pass only ever adds JUMP_DET (fitting.py:249)
     finally:
         ctx.destroy_plan(pid)
     if mylog is not None:

@@ -114,6 +114,13 @@ def test_noise_layers_end_to_end(tmp_path):
     # list -- read noise with correlated noise, clipping, sky model, resampled Poisson, pseudo-Poisson -- bit for bit
     host_loop = gen_noise_image.make_noise_cube(dict(config, NOISE=dict(config["NOISE"], DEVICE_RESIDENT=False)))
     assert_same_bits(host_loop, noise, "host-array layer loop vs the HBM-resident one")
+    # ... also where a clipped read-noise layer goes on through the sky model, the resampled Poisson or the pseudo-Poisson step in
+    # the SAME layer (the production list's shape, 'Rz4PbrS2' / 'Rz4OS2': the clip bounds are float32 on both sides)
+    prod = dict(config["NOISE"], LAYER=["Rz3S1", "Rz4Pb1rS2", "Rz4OS2", "RaOS1"])
+    dev_loop = gen_noise_image.make_noise_cube(dict(config, NOISE=prod))
+    host_loop = gen_noise_image.make_noise_cube(dict(config, NOISE=dict(prod, DEVICE_RESIDENT=False)))
+    assert_same_bits(host_loop, dev_loop, "host-array layer loop vs the HBM-resident one (clip + sky model + Poisson in one layer)")
+    assert np.std(dev_loop[1][good]) > 0 and not np.array_equal(dev_loop[1], dev_loop[2])
     # the exposures kept in memory (default) or sent through the TEMP files as the reference does: the same layers
     one = dict(config["NOISE"], LAYER=["R", "Raz3S1"])
     mem = gen_noise_image.make_noise_cube(dict(config, NOISE=one))

@@ -239,6 +239,14 @@ def test_jump_detect_returns_smap(name):
     assert_same_bits(ep, g["jd_err_poisson"], "err_poisson", zero_sign_ok=True)
     assert_same_bits(smap, g["jd_smap"], "smap", zero_sign_ok=True)
     assert_same_bits(loc, g["jd_flags"], "flags")
+    # the reference ORs into the uint32 cube it made itself (fitting.py:249): accepted as it is, its other bits kept
+    loc32 = np.zeros(g["groupdq"].shape, np.uint32)
+    loc32[:, 1::7, 2::5] = np.uint32(1 << 20)
+    want32 = loc32 | g["jd_flags"].astype(np.uint32)
+    s2, _, _, smap2 = fitting.jump_detect(g["data"], loc32, g["pixeldq"], meta, caldir, None, exclude_first=ef, ctx=gpu_context())
+    assert_same_bits(s2, s, "slope (uint32 flags)")
+    assert_same_bits(smap2, smap, "smap (uint32 flags)")
+    assert_same_bits(loc32, want32, "uint32 flags")
 
 
 @pytest.mark.parametrize("name,t", [("rampfit_g8", 4), ("rampfit_g8", 6), ("rampfit_g8", 8), ("rampfit_g8_include_first", 3),
