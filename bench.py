@@ -41,7 +41,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-PROFILE_EVERY = int(os.environ.get("BENCH_PROFILE_EVERY", "1"))   # 0: no events at all (kernel times then read 0)
+# HIP events round the kernels of every PROFILE_EVERY-th timed step (the kernel durations of the roofline block are their averages).
+# With events round every kernel of EVERY call the event packets themselves cost 0.02-0.03 ms of wall time per ramp (same-box A/B,
+# profiles/r04_summary.md): every 16th step keeps >= 60 samples of the default 1000 steps and the wall time clean.
+PROFILE_EVERY = max(1, int(os.environ.get("BENCH_PROFILE_EVERY", "16")))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
@@ -276,7 +279,7 @@ def run_steps(cb, calls, warmup, steps, fence, ramp_s=0.0):
     cb.ctx.profile_read()
     t0 = time.perf_counter()
     for i in range(steps):
-        if PROFILE_EVERY and i % PROFILE_EVERY == 0:
+        if i % PROFILE_EVERY == 0:
             cb.ctx.profile(True)
             calls[(warmup + i) % n]()
             cb.ctx.profile(False)
@@ -622,18 +625,20 @@ def main():
         # HBM traffic of the dominant kernel: PMC measurement of the SAME command, committed under profiles/ (not measured by
         # this run: counters need rocprofv3); null when no profile of this configuration and kernel build is there
         traffic, traffic_source = None, None
-        tpath = os.path.join(REPO, "profiles", "r03_hbm_traffic.json")
-        if dom == "chain_fused" and (G, N, args.p_order, args.ipc_dtype, args.workload) == (8, 4096, 8, "f32", "single") \
-                and os.path.exists(tpath):
-            with open(tpath) as tf:
-                tj = json.load(tf)
-            if tj.get("kernel_source_sha16") == kernel_source_hash():
-                traffic = tj.get("traffic_bytes_per_launch")
-                traffic_source = ("profiles/r03_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                  f"(tools/profile_round.sh), kernel {tj.get('kernel')}, kernel sources {tj.get('kernel_source_sha16')}; "
-                                  "not re-measured by this run")
-            else:
-                traffic_source = ("profiles/r03_hbm_traffic.json belongs to other kernel sources "
+        import glob
+
+        if dom == "chain_fused" and (G, N, args.p_order, args.ipc_dtype, args.workload) == (8, 4096, 8, "f32", "single"):
+            for tpath in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")), reverse=True):   # newest round first
+                with open(tpath) as tf:
+                    tj = json.load(tf)
+                name = os.path.relpath(tpath, REPO)
+                if tj.get("kernel_source_sha16") == kernel_source_hash():
+                    traffic = tj.get("traffic_bytes_per_launch")
+                    traffic_source = (f"{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                      f"(tools/profile_round.sh), kernel {tj.get('kernel')}, kernel sources {tj.get('kernel_source_sha16')}; "
+                                      "not re-measured by this run")
+                    break
+                traffic_source = (f"{name} belongs to other kernel sources "
                                   f"({tj.get('kernel_source_sha16')} != {kernel_source_hash()}): traffic not quoted")
         out = {
             "metric": "SCA ramps/sec (4096x4096x8grp full L1->L2 chain)" if (G, N) == (8, 4096) else f"SCA ramps/sec ({N}x{N}x{G}grp full L1->L2 chain)",
@@ -655,6 +660,7 @@ def main():
                                    + ("; ranks share one GPU (rehearsal, not a scaling measurement)" if args.share_gpu else ""),
                        "items_rank0": mine[:8]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "kernel_ms_samples": ncalls, "kernel_ms_sampling": f"HIP events round the kernels of every {PROFILE_EVERY}th timed step",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "alg_bytes_kernel": per_kernel[dom], "kernel_ms": avg_ms[dom],
                          "kernel_form": {0: "stage kernels",

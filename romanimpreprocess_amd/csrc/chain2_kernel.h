@@ -91,21 +91,34 @@ __device__ __forceinline__ unsigned c2_opaque(unsigned x) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t c2_rsrc(const void *p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
 }
-// (non-temporal hints on the once-read arrays: HBM reads -8 %, kernel time +11 %, profiles/r01_summary.md -- not used)
+// Cache policy of the ONCE-read arrays in the narrow forms (aux bits of the buffer loads; 2 = nt: stream through the caches).  The
+// narrow forms' fit role reads the IPC coefficients (NARROW = 2: gain and groupdq bytes too) a second time one row step after the
+// ingest role; a step of an XCD's 96 workgroups moves about 4 MB -- the size of its L2 -- so those lines have left L2 by then and
+// come back over the fabric (1.4-1.5 x the algorithmic bytes at ~5 TB/s of fabric traffic).  With the hint on everything read once,
+// same-box A/B (profiles/r04_summary.md): 16 groups 1.752 -> 1.730 / 1.780 -> 1.738 ms, f64 x 16 groups 2.414 -> 2.383 / 2.411 ->
+// 2.399 ms, f64 x 8 groups (NARROW = 1) 1.179 -> 1.237 ms SLOWER -- so it is on for NARROW = 2 only.  Results are identical either
+// way.  (256-column form, round 1: hints on the once-read arrays cost 11 %: no second read there.)
+#ifndef C2_STREAM_AUX
+#define C2_STREAM_AUX 2
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ float c2_ld_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
 }
 __device__ __forceinline__ double c2_ld_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
+template <int AUX = 0>
 __device__ __forceinline__ uint32_t c2_ld_u32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ uint32_t c2_ld_u16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+    return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ uint32_t c2_ld_u8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, 0);
+    return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(r, voff, soff, AUX);
 }
 // XCD-aware block order (the dispatcher deals consecutive block ids round the 8 XCDs, each with its own L2): block ids that
 // share an XCD get CONSECUTIVE cells of the (row range, strip) grid, so that neighbouring strips -- whose 256-column windows at
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
     // the division by the gain are f64 (numpy promotion, ipc_linearity.py:95-142), so the O1 ring holds doubles, one plane per
     // group: 94 KB of LDS for 8 groups, one workgroup per CU (2 waves/SIMD, up to 256 VGPRs)
     constexpr bool K64 = sizeof(KT) == 8;
+    constexpr int SA = NARROW == 2 ? C2_STREAM_AUX : 0;   // cache policy of the once-read arrays (see C2_STREAM_AUX)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int XR = 3;  // rows of the x ring
     f2 *X2 = reinterpret_cast<f2 *>(lds_raw);                       // [GP][XR][C2_COLS]  x = gain*phi, pair-interleaved
@@ -423,10 +437,10 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
                      o1 = yl * (row4 >> 2) + (unsigned)g0 * npix;
 #pragma unroll
             for (int g = g0; g < g1; ++g) {
-                rr.S[g] = c2_ld_u16(rs, cc2, o2);
-                rr.q[g] = c2_ld_u8(rq, cc1, o1);
-                rr.dk[g] = c2_ld_f32(rd, cc4, o4);
-                rr.bs[g] = c2_ld_f32(rb, cc4, o4);
+                rr.S[g] = c2_ld_u16<SA>(rs, cc2, o2);
+                rr.q[g] = c2_ld_u8<WRING ? SA : 0>(rq, cc1, o1);   // (NARROW = 2: the fit role reads these bytes again)
+                rr.dk[g] = c2_ld_f32<SA>(rd, cc4, o4);
+                rr.bs[g] = c2_ld_f32<SA>(rb, cc4, o4);
                 o4 += pl4;
                 o2 += pl4 >> 1;
                 o1 += npix;
@@ -443,17 +457,17 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
 #pragma unroll
             for (int i = i0; i < i1; ++i) {
                 if (i < NP)
-                    rr.cf[i] = c2_ld_f32(rp, cc4, o4);
+                    rr.cf[i] = c2_ld_f32<SA>(rp, cc4, o4);
                 else if (i == NP)
-                    rr.smin = c2_ld_f32(rp, cc4, o4);
+                    rr.smin = c2_ld_f32<SA>(rp, cc4, o4);
                 else if (i == NP + 1)
-                    rr.smax = c2_ld_f32(rp, cc4, o4);
+                    rr.smax = c2_ld_f32<SA>(rp, cc4, o4);
                 else if (i == NP + 2)
-                    rr.sref = c2_ld_f32(rp, cc4, o4);
+                    rr.sref = c2_ld_f32<SA>(rp, cc4, o4);
                 else if (i == NP + 3)   // the flag word: linearity dq merged with what the finish step ORs into pixeldq (RipCal)
-                    rr.dq = c2_ld_u32(rp, cc4, yl * row4 + (unsigned)(NP + ka->merged_dq) * pl4);
+                    rr.dq = c2_ld_u32<SA>(rp, cc4, yl * row4 + (unsigned)(NP + ka->merged_dq) * pl4);
                 else
-                    rr.gain = c2_ld_f32(rp, cc4, o4);
+                    rr.gain = c2_ld_f32<WRING ? SA : 0>(rp, cc4, o4);
                 o4 += pl4;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -784,16 +798,16 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
             const __amdgpu_buffer_rsrc_t rpl = c2_rsrc(kf->a.planes);
             const unsigned t_row = rc_ * row4;  // byte offset of row r in an f32 plane (uniform)
             const unsigned t_ld = (dbg & 256) ? 0u : t_row;   // timing experiment: the fit role's loads all hit row 0 (cached)
-            const float e_read = c2_ld_f32(rpl, cc4, (unsigned)(NP + 5) * pl4 + t_ld);
+            const float e_read = c2_ld_f32<SA>(rpl, cc4, (unsigned)(NP + 5) * pl4 + t_ld);
             const float e_gain = gain_next;
             // calibration planes of the tail (finish) of the same pixel, consumed after the barrier
             const size_t t_row4 = (size_t)t_row;
             const size_t pe_row = (size_t)(rc_ * (unsigned)nx);   // element offset of row r
-            const float e_dark = c2_ld_f32(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_ld);
+            const float e_dark = c2_ld_f32<SA>(rpl, cc4, (unsigned)(NP + 6) * pl4 + t_ld);
             // (flat flags and dark dq arrive with the linearity dq of the pixel: ChainArgs::merged_dq)
-            const uint32_t e_pdq = c2_ld_u32(c2_rsrc(kf->a.pdq), cc4, t_ld);
+            const uint32_t e_pdq = c2_ld_u32<SA>(c2_rsrc(kf->a.pdq), cc4, t_ld);
             // flat / dark_dq == null: read the first slab plane instead (value unused), keeps the loads in one block
-            const float e_flat_raw = c2_ld_f32(c2_rsrc(kf->a.flat ? (const void *)kf->a.flat : (const void *)kf->a.planes), cc4, t_ld);
+            const float e_flat_raw = c2_ld_f32<SA>(c2_rsrc(kf->a.flat ? (const void *)kf->a.flat : (const void *)kf->a.planes), cc4, t_ld);
             const float e_flat = kf->a.flat ? e_flat_raw : 1.0f;
             float d[G];
             f2 dpair[GP];
@@ -1078,7 +1092,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
                 } else {
                     // the fit role's own loads of row r + 1 (second read of lines its ingest role fetched three steps earlier):
                     // packed as the ingest role packs them; rows / columns outside the frame are never emitted
-                    const unsigned yl = (unsigned)min(max(r + 1, ylo), yhi);
+                    const unsigned yl = (unsigned)min(max((dbg & 1024) ? R0 : r + 1, ylo), yhi);   // (dbg 1024: timing, the re-read hits cache)
                     const __amdgpu_buffer_rsrc_t rq = c2_rsrc(kg->a.gdq);
                     unsigned o1 = yl * (row4 >> 2);
 #pragma unroll
@@ -1099,9 +1113,9 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
 #elif C2_KFIT_EARLY
             if constexpr (!KRING) {
                 if constexpr (K64)
-                    (void)load_kd(kg->a.kern, r + 1, true, kn_d);
+                    (void)load_kd(kg->a.kern, (dbg & 1024) ? R0 : r + 1, true, kn_d);
                 else
-                    (void)load_k(kg->a.kern, r + 1, true, kn);
+                    (void)load_k(kg->a.kern, (dbg & 1024) ? R0 : r + 1, true, kn);
             }
 #endif
             CH_T(6)

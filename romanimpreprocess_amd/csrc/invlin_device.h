@@ -43,8 +43,10 @@ __device__ __forceinline__ ZT rip_invlin_pixel(ZT target, const float (&c)[NP], 
 // decision on, z differs and every step is evaluated (and kept) as in rip_invlin_pixel.  Identical comparisons on identical
 // values: bit-identical results, fewer f64 operations (consecutive reads differ by a few electrons out of ~1e5, so the first
 // steps of their paths coincide).  `have` = a path has been kept; the wave evaluates a step when any of its lanes must.
+// `cw`: the coefficients widened to ZT once per pixel by the caller (the conversion is exact and invariant over the 35 reads x
+// 24 steps; the compiler does not hoist it out of the read loop by itself: 8 of the ~70 f64-rate instructions of an evaluation)
 template <typename ZT, int NP>
-__device__ __forceinline__ ZT rip_invlin_pixel_warm(ZT target, const float (&c)[NP], float smin, float smax, bool &ex,
+__device__ __forceinline__ ZT rip_invlin_pixel_warm(ZT target, const float (&c)[NP], const ZT (&cw)[NP], float smin, float smax, bool &ex,
                                                     float (&phi_path)[24], uint32_t &path, bool &have) {
     ZT c1[NP], c2[NP];
 #pragma unroll
@@ -67,7 +69,7 @@ __device__ __forceinline__ ZT rip_invlin_pixel_warm(ZT target, const float (&c)[
             ZT pp = (ZT)1, p = z;
 #pragma unroll
             for (int L = 1; L < NP; ++L) {
-                phi = (float)((ZT)phi + (ZT)c[L] * p);
+                phi = (float)((ZT)phi + cw[L] * p);
                 const ZT pn = (c1[L] * z) * p - c2[L] * pp;
                 pp = p;
                 p = pn;

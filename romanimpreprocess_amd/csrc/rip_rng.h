@@ -89,17 +89,27 @@ __device__ __forceinline__ double log_factorial(double k) {
 // lam = counts * share: the root and the logarithm of the counts once per pixel, those of the shares once per read pattern).
 // Same algorithm as poisson(); the acceptance test outside the squeeze costs two logarithms (log_factorial, one merged left side)
 // instead of three and a lgamma -- every wave takes that path for some lane on almost every draw.
-__device__ inline double poisson_pre(double lam, double slam, double loglam, uint64_t seed, uint32_t a, uint32_t b, uint32_t tag) {
+// `p0` = exp(-lam) from the caller where lam < 10 (a run of reads with one share has one lam: the exponential, the dearest part of a
+// small-mean deviate, once per pixel instead of once per read); `u` = the uniform deviate for the inversion branch, or a negative
+// number: drawn here from (a, b, tag) -- the caller may hand in the second pair of words of the Philox block of the read before
+__device__ inline double poisson_pre(double lam, double slam, double loglam, uint64_t seed, uint32_t a, uint32_t b, uint32_t tag,
+                                     double p0, double u_in) {
     if (!(lam > 0.0)) return 0.0;
     if (lam < 10.0) {
-        uint32_t c[4] = {a, b, tag, 0x706f6932u};
-        philox(c, seed);
-        const double u = u53(c[0], c[1]);
-        double p = exp(-lam), cdf = p;
+        double u = u_in;
+        if (u < 0.0) {
+            uint32_t c[4] = {a, b, tag, 0x706f6932u};
+            philox(c, seed);
+            u = u53(c[0], c[1]);
+        }
+        double p = p0, cdf = p;
         int k = 0;
-        while (u > cdf && k < 200) {
-            ++k;
-            p *= lam / k;
+        while (u > cdf && k < 200) {   // p_k = p_(k-1) * lam / k through the hardware reciprocal (+ one Newton step): a third of
+            ++k;                       // the instructions of an f64 division, the same probabilities to 1e-16
+            const double kd = (double)k;
+            double rk = __builtin_amdgcn_rcp(kd);
+            rk = __builtin_fma(__builtin_fma(-kd, rk, 1.0), rk, rk);
+            p *= lam * rk;
             cdf += p;
         }
         return (double)k;

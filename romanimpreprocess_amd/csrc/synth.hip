@@ -43,8 +43,23 @@ __global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict_
         const double sc = sqrt(c), lc = (c > 0.0) ? log(c) : 0.0;
         const double *w = share + MAX_READS, *sw = share + 2 * MAX_READS, *lw = share + 3 * MAX_READS;
         double got_d = 0.0;
+        double w_prev = -1.0, lam = 0.0, p0 = 0.0;   // reads of one share have one mean: its exponential once
+        double u_next = -1.0;                        // the second pair of words of a Philox block serves the read after (inversion branch)
         for (int r = 0; r < nreads; ++r) {
-            got_d += riprng::poisson_pre(c * w[r], sc * sw[r], lc + lw[r], seed, (uint32_t)i, (uint32_t)r, TAG_TOTAL);
+            if (fabs(w[r] - w_prev) > 1e-12 * w_prev) {   // (equal read spacings give equal shares up to the rounding of the time differences)
+                w_prev = w[r];
+                lam = c * w[r];
+                p0 = (lam > 0.0 && lam < 10.0) ? exp(-lam) : 0.0;
+            }
+            double u = u_next;
+            u_next = -1.0;
+            if (u < 0.0 && lam > 0.0 && lam < 10.0) {
+                uint32_t cw_[4] = {(uint32_t)i, (uint32_t)r, TAG_TOTAL, 0x706f6932u};
+                riprng::philox(cw_, seed);
+                u = riprng::u53(cw_[0], cw_[1]);
+                u_next = riprng::u53(cw_[2], cw_[3]);
+            }
+            got_d += riprng::poisson_pre(lam, sc * sw[r], lc + lw[r], seed, (uint32_t)i, (uint32_t)r, TAG_TOTAL, p0, u);
             out[(size_t)r * npix + i] = (int)(got_d > 2.0e9 ? 2.0e9 : got_d);
         }
         return;
@@ -128,8 +143,12 @@ __global__ __launch_bounds__(256) void resultants_kernel(ResArgs a) {
         sq[k] = in ? (double)a.start[off[k]] : 0.0;
     }
     float c[NP];
+    double cw[NP];   // widened once (exact): invariant over the reads and the bisection steps
 #pragma unroll
-    for (int L = 0; L < NP; ++L) c[L] = a.coefs[(size_t)L * npix + i];
+    for (int L = 0; L < NP; ++L) {
+        c[L] = a.coefs[(size_t)L * npix + i];
+        cw[L] = (double)c[L];
+    }
     const float smin = a.smin[i], smax = a.smax[i];
     const double g = (double)((const GT *)a.gain)[i];
     const float rn = a.read_noise[i];
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(256) void resultants_kernel(ResArgs a) {
                     if (off[k] >= 0) conv = conv + ((double)ec[k] + sq[k]) * kq[k];
             }
             bool ex;
-            const double S = rip_invlin_pixel_warm<double, NP>(conv / g, c, smin, smax, ex, phi_path, path, have);
+            const double S = rip_invlin_pixel_warm<double, NP>(conv / g, c, cw, smin, smax, ex, phi_path, path, have);
             acc = (float)((double)acc + S);
         }
         float res = acc / (float)a.count[j];

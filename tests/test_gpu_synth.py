@@ -282,8 +282,9 @@ def test_one_over_f_calls_on_both_streams_do_not_share_scratch_unordered():
 
     ctx.synchronize()
     torch.cuda.synchronize()
-    want_frames = frames(21).cpu().numpy()
-    ctx.synchronize()
+    want_t = frames(21)
+    ctx.synchronize()   # (the entry is asynchronous on the context's stream; torch's copy below is not ordered behind it)
+    want_frames = want_t.cpu().numpy()
     want_exp = exposure(22, None)
     for _ in range(3):
         holder = {}

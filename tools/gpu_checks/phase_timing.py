@@ -62,7 +62,7 @@ if os.environ.get("CHAIN3", "0") == "1":
     for m in [int(x) for x in sys.argv[1:]] or [0, 1, 2, 4, 6, 7, 8]:
         print(f"dbg={m:3d} {names3.get(m, ''):28s} {run(m):8.3f} ms", flush=True)
     sys.exit(0)
-names = {0: "full", 1: "no C (O1)", 2: "no E-ipc (O2)", 4: "no fit", 8: "no saturated path", 16: "no legendre",
+names = {1024: "fit role's second reads hit one cached row (narrow forms)", 0: "full", 1: "no C (O1)", 2: "no E-ipc (O2)", 4: "no fit", 8: "no saturated path", 16: "no legendre",
          32: "no lin slow branch", 3: "no ipc", 7: "no ipc, no fit", 23: "no ipc/fit/legendre", 12: "no fit/no sat"}
 for m in [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3, 4, 8, 12, 16, 32, 7, 23]:
     print(f"dbg={m:3d} {names.get(m, ''):28s} {run(m):8.3f} ms", flush=True)
