@@ -3,6 +3,7 @@
 // translation units.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <cmath>
@@ -119,6 +120,8 @@ int rip_ctx_create(int device_id, rip_ctx **out) {
     rip_ctx *ctx = new rip_ctx();
     ctx->device = device_id;
     ctx->ncu = prop.multiProcessorCount;
+    // (queue priorities -- main stream above the second -- and a raised wave priority of the fused kernel were both tried against
+    // the 4 % the overlapped pre-pass costs the fused kernel it runs beside: no effect, profiles/r04_summary.md)
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
