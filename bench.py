@@ -45,6 +45,10 @@ if REPO not in sys.path:
 # With events round every kernel of EVERY call the event packets themselves cost 0.02-0.03 ms of wall time per ramp (same-box A/B,
 # profiles/r04_summary.md): every 16th step keeps >= 60 samples of the default 1000 steps and the wall time clean.
 PROFILE_EVERY = max(1, int(os.environ.get("BENCH_PROFILE_EVERY", "16")))
+# vector-pipe floors of the fused kernel's instantiations (ms per 4096 x 4096 ramp, P_ORDER 8): SQ_INSTS_VALU of the kernel at 2
+# cycles per f32-rate and 4 per f64-rate instruction on 1024 SIMDs at 2.1 GHz (profiles/r03_variant_counters.txt).  Where this floor
+# lies above the HBM floor (16 groups) the HBM fraction alone misstates the bound: the variants carry both.
+VALU_FLOOR_MS = {("f32", 8): 0.407, ("f64", 8): 0.520, ("f32", 16): 0.787, ("f64", 16): 1.024}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
@@ -312,8 +316,10 @@ def host_path(cb, ramp, N, G, batch=8):
     for want_gdq in (True, False):
         ms = best_ms(lambda: cb.calibrate(0, host_ramp, want_groupdq=want_gdq, out=out_pg), 5)
         res["pageable" + ("" if want_gdq else "_no_groupdq_out")] = {"ms_per_ramp": ms, "ramps_per_s": 1e3 / ms}
-    ms = best_ms(lambda: cb.calibrate(0, host_ramp, want_groupdq=True), 3)   # results into fresh numpy arrays (first-touch page faults)
-    res["pageable_fresh_result_arrays"] = {"ms_per_ramp": ms, "ramps_per_s": 1e3 / ms}
+    # the default call: no `out`, the result arrays come from the Calibrator's pool of memory touched before (pipeline.ResultPool;
+    # fresh np.empty arrays cost 33 ms of first-touch page faults per ramp: 20 ramps/s)
+    ms = best_ms(lambda: cb.calibrate(0, host_ramp, want_groupdq=True), 4)
+    res["pageable_default_call"] = {"ms_per_ramp": ms, "ramps_per_s": 1e3 / ms}
     pin = {k: cb.pinned_empty(v.shape, v.dtype) for k, v in h.items()}
     for k in pin:
         pin[k][...] = h[k]
@@ -702,8 +708,12 @@ def main():
                 el_v, ms_v, nc_v = run_steps(cb, [call_for(1, pid_v, vg, res_v)], 5, 100, fence, ramp_s=0.3)
                 sane(res_v)
                 tot_v, pk_v, avg_v, dom_v, ach_v = kernel_report(vg, vp, vk, ms_v, nc_v)
+                hbm_floor = pk_v[dom_v] / (HBM_PEAK_GBS * 1e9) * 1e3
+                valu_floor = VALU_FLOOR_MS.get((vk, vg)) if vp == 8 else None
+                floor = max(hbm_floor, valu_floor or 0.0)
                 variants[vname] = {"ramps_per_s": 100 / el_v, "kernel": dom_v, "kernel_ms": avg_v[dom_v], "alg_bytes_kernel": pk_v[dom_v],
-                                   "frac": ach_v / HBM_PEAK_GBS, "kernel_form": cb.ctx.last_chain_form(),
+                                   "frac": ach_v / HBM_PEAK_GBS, "hbm_floor_ms": hbm_floor, "valu_floor_ms": valu_floor,
+                                   "frac_of_max_floor": floor / avg_v[dom_v], "kernel_form": cb.ctx.last_chain_form(),
                                    "config": f"{N}x{N}x{vg} groups, P_ORDER {vp}, {vk} ipc4d"}
                 cb.ctx.drop_caldir(1)
                 del res_v, cal_v, ramp_v

@@ -299,3 +299,33 @@ def test_bench_refuses_more_ranks_than_gpus_before_any_rendezvous():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(lines[0])
     assert len(d["elapsed_s_per_rank"]) == 2 and max(d["elapsed_s_per_rank"]) * 1e3 / 3 == pytest.approx(d["ms_per_step"])
+
+
+def test_result_pool_recycles_memory_only_when_every_view_is_gone():
+    """Result arrays of Calibrator.calibrate come from memory touched before (no first-touch page faults per call); a block goes
+    back to the pool when the last array or view referring to it dies, never earlier."""
+    import gc
+
+    from romanimpreprocess_amd.pipeline import ResultPool
+
+    pool = ResultPool(keep=2)
+    a = pool.empty((1024, 1024), np.float32)
+    assert a.flags.c_contiguous and a.flags.writeable and a.dtype == np.float32 and a.shape == (1024, 1024)
+    a[...] = 3.0
+    addr = a.ctypes.data
+    view = a[10:20]
+    del a
+    gc.collect()
+    assert not pool.free.get(4 << 20)                      # the view keeps the block
+    assert view[0, 0] == 3.0
+    del view
+    gc.collect()
+    assert len(pool.free[4 << 20]) == 1
+    b = pool.empty((1024, 1024), np.uint32)                # same size, other dtype: the same memory
+    assert b.ctypes.data == addr
+    small = pool.empty((8, 8), np.float32)                 # small arrays are plain numpy arrays
+    assert small.base is None
+    blocks = [pool.empty((1024, 1024), np.float32) for _ in range(4)]
+    del blocks, b
+    gc.collect()
+    assert len(pool.free[4 << 20]) == 2                    # at most `keep` spare blocks per size
