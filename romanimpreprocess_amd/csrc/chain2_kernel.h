@@ -26,7 +26,9 @@
 #pragma once
 #include "chain_common.h"
 
+#ifndef C2_COLS_DEF
 #define C2_COLS_DEF 256   // (128-column workgroups WITH every ring: 4 % slower, profiles/r03_summary.md; the narrow forms drop rings)
+#endif
 // columns of a workgroup's window: a constant `COLS` of the enclosing template (256; 128 in the narrow form, see chain2_kernel)
 #define C2_COLS COLS
 #define C2_THREADS (2 * C2_COLS)
@@ -100,6 +102,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t c2_rsrc(const void *p) {
 // way.  (256-column form, round 1: hints on the once-read arrays cost 11 %: no second read there.)
 #ifndef C2_STREAM_AUX
 #define C2_STREAM_AUX 2
+#endif
+#ifndef C2_STREAM_N1   // the same for NARROW = 1 (A/B)
+#define C2_STREAM_N1 0
 #endif
 template <int AUX = 0>
 __device__ __forceinline__ float c2_ld_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -204,25 +209,43 @@ __device__ __forceinline__ void c2_div64_shared(const double (&a)[NG], float bf,
     }
 }
 
+// Columns of a workgroup's window.  The ring-dropping (NARROW) forms were 128-column workgroups, three (two) per CU; what they
+// pay is windows at a 124-column pitch: a window row of a byte plane is one 128-byte line, misaligned it touches two (u16: two ->
+// three, f32: four -> five), and the lines shared with the neighbouring strip have left L2 by the time that strip wants them --
+// a third of the algorithmic bytes fetched twice.  ONE workgroup of 384 (256) columns with the same rings dropped has the same
+// waves per SIMD and LDS per CU and a third (half) of the seams.  C2_N*_COLS: A/B switches, results identical.
+#ifndef C2_N1_COLS    // NARROW = 1 (f64 ipc4d x 6 / 8 groups): 43 KB per 128 columns
+#define C2_N1_COLS 384
+#endif
+#ifndef C2_N2_COLS    // NARROW = 2, f32 ipc4d (16 groups): 51 KB per 128 columns
+#define C2_N2_COLS 384
+#endif
+#ifndef C2_N2K_COLS   // NARROW = 2, f64 ipc4d (16 groups): 76 KB per 128 columns
+#define C2_N2K_COLS 256
+#endif
+constexpr int c2_cols(bool k64, int narrow) {
+    return narrow == 0 ? C2_COLS_DEF : (narrow == 1 ? C2_N1_COLS : (k64 ? C2_N2K_COLS : C2_N2_COLS));
+}
 // waves per SIMD an instantiation is compiled for (register budget 512 / waves) and launched with
 constexpr int c2_wps(int G, bool k64, int narrow) {
     return !narrow ? ((G > 8 || k64) ? 2 : 4) : ((k64 && G > 8) ? 2 : ((k64 || G > 8) ? 3 : 4));
 }
 
-// NARROW forms: a workgroup of 256 threads (two waves per role) on a 128-column window that drops rings, so that more workgroups
-// fit a CU; what the dropped ring carried, the fit role loads itself one step ahead (a second read of lines the ingest role
-// fetched 1.5 steps earlier: more fabric traffic, more waves -- these configurations are bound by waves per SIMD):
-//   NARROW = 1  no K ring                              f64 ipc4d x 6 / 8 groups: 43 KB (120 KB), 3 workgroups per CU, <= 168 VGPRs
-//   NARROW = 2  no K ring, no gain / groupdq rings     16 groups: 51 KB (132 KB), 3 per CU; f64 ipc4d x 16 groups: 76 KB (180 KB:
-//                                                      did not fit), 2 per CU at <= 256 VGPRs
-// Same arithmetic, same bits as the 256-column form.  For f32 ipc4d x 8 groups the narrow forms are slower (same 16 waves per CU).
+// NARROW forms (the ring-dropping forms): what does not fit the 256-column form's LDS budget twice per CU drops rings, and what a
+// dropped ring carried the fit role loads itself, one step ahead (a second read of lines the ingest role fetched 1.5 steps earlier):
+//   NARROW = 1  no K ring                              f64 ipc4d x 6 / 8 groups: 43 KB per 128 columns (with every ring: 120 KB per 256)
+//   NARROW = 2  no K ring, no gain / groupdq rings     16 groups: 51 KB per 128 columns; f64 ipc4d x 16 groups: 76 KB
+// Round 3 ran them as 128-column workgroups, three (two) per CU: 3 (2) waves per SIMD at <= 168 (256) VGPRs.  Round 4: ONE
+// workgroup per CU of 384 columns (f64 x 16 groups: 256) -- the same waves per SIMD and LDS per CU, a third (half) of the seams
+// between strips, whose misaligned, twice-fetched lines were a third of these forms' excess traffic (c2_cols above): 6-8 % faster,
+// same bits.  Same arithmetic as the 256-column form.  For f32 ipc4d x 8 groups these forms are slower (same 16 waves per CU).
 template <int NP, int G, int START, typename KT = float, int NARROW = 0>
-__global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(KT) == 8, NARROW)) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
+__global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, sizeof(KT) == 8, NARROW)) void chain2_kernel(ChainArgs a, const RipPlanHeader *__restrict__ h,
                                                                const RipVariant *__restrict__ vars,
                                                                const float *__restrict__ kvals,
                                                                const RipDiff *__restrict__ diffs, double guard) {
     static_assert(G % 2 == 0 && G > 4 && G <= 16, "pairs of groups; the groupdq bytes travel packed four to a word");
-    constexpr int COLS = NARROW ? 128 : C2_COLS_DEF;
+    constexpr int COLS = c2_cols(sizeof(KT) == 8, NARROW);
     constexpr bool KRING = !NARROW;
     constexpr bool WRING = NARROW < 2;   // NARROW = 2 (16 groups): gain and packed groupdq bytes do not travel through LDS either --
                                          // the fit role loads them itself, like the coefficients (51 KB: three workgroups per CU)
@@ -232,7 +255,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
     // the division by the gain are f64 (numpy promotion, ipc_linearity.py:95-142), so the O1 ring holds doubles, one plane per
     // group: 94 KB of LDS for 8 groups, one workgroup per CU (2 waves/SIMD, up to 256 VGPRs)
     constexpr bool K64 = sizeof(KT) == 8;
-    constexpr int SA = NARROW == 2 ? C2_STREAM_AUX : 0;   // cache policy of the once-read arrays (see C2_STREAM_AUX)
+    constexpr int SA = NARROW == 2 ? C2_STREAM_AUX : (NARROW == 1 ? C2_STREAM_N1 : 0);   // cache policy of the once-read arrays
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int XR = 3;  // rows of the x ring
     f2 *X2 = reinterpret_cast<f2 *>(lds_raw);                       // [GP][XR][C2_COLS]  x = gain*phi, pair-interleaved
@@ -244,12 +267,13 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
     // thread takes row r+1's at the end of step r): the flag word, the packed groupdq bytes, the gain
     uint32_t *QS = DQ + 3 * C2_COLS;                                // [3][QW][C2_COLS] groupdq bytes of the pixel, packed
     float *GN = reinterpret_cast<float *>(QS + (WRING ? 3 * QW * C2_COLS : 0));   // [3][C2_COLS] gain of the pixel (f32)
-    double *LN = reinterpret_cast<double *>(GN + (WRING ? 3 * C2_COLS : 0));       // [3][G][2] channel lines of this strip
+    double *LN = reinterpret_cast<double *>(GN + (WRING ? 3 * C2_COLS : 0));       // [NLC][G][2] channel lines of this strip
     // K ring: the nine IPC coefficients of destination (row, col), loaded ONCE by the ingest thread of the column and handed to
     // its fit thread (two rows live: C of row y runs two steps before O2 of row y)
-    f2 *KR2 = reinterpret_cast<f2 *>(LN + 3 * G * 2);               // f32 ipc4d: [2][4][C2_COLS] pairs (k0,k1)..(k6,k7)
+    constexpr int NLC = C2_COLS / RIP_CW + 1;                       // channels a window can touch (a window is not channel-aligned)
+    f2 *KR2 = reinterpret_cast<f2 *>(LN + NLC * G * 2);               // f32 ipc4d: [2][4][C2_COLS] pairs (k0,k1)..(k6,k7)
     float *KR1 = reinterpret_cast<float *>(KR2 + 2 * 4 * C2_COLS);  //            [2][C2_COLS] k8
-    double *KRd = reinterpret_cast<double *>(LN + 3 * G * 2);       // f64 ipc4d: [2][9][C2_COLS]
+    double *KRd = reinterpret_cast<double *>(LN + NLC * G * 2);       // f64 ipc4d: [2][9][C2_COLS]
 
     // ChainArgs is the first kernel argument: it sits at offset 0 of the kernarg segment
     const RIP_K C2KernArgs *kargs = (const RIP_K C2KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -260,7 +284,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
     constexpr int dbg = 0;
 #endif
     const bool fit_role = tid >= C2_COLS;
-    const int col = tid & (C2_COLS - 1);
+    const int col = fit_role ? tid - C2_COLS : tid;
     const int ny = a.ny, nx = a.nx, nb = a.nb;
     const int ay0 = nb, ay1 = ny - nb, ax0 = nb, ax1 = nx - nb;
     const unsigned npix = (unsigned)ny * (unsigned)nx;
@@ -297,7 +321,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
     const int cc = col_ok ? c : 0;
     const int ch0 = (strip * C2_OUTW) / RIP_CW;
     const int chr = cc / RIP_CW - ch0;
-    for (int i = tid; i < 3 * G * 2; i += C2_THREADS) {
+    for (int i = tid; i < NLC * G * 2; i += C2_THREADS) {
         const int ch = i / (G * 2), g = (i / 2) % G, w = i & 1;
         LN[i] = (ch0 + ch < nch) ? a.lines[(g * nch + ch0 + ch) * 2 + w] : 0.0;
     }
@@ -820,7 +844,9 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
             CH_T(0)
             C2_DRAIN()
             CH_T(1)
-            constexpr int BAR = (C2_BAR >= 0) ? C2_BAR : (NARROW ? 1 : (K64 ? 2 : (G > 8 ? 1 : 0)));
+            // (round 4, the wide ring-dropping forms, same box: 0 / 1 / 2 = 16 groups 1.704 / 1.770 / 1.751 ms per ramp, f64 x 16
+            // groups 2.251 / 2.278 / 2.302, f64 x 8 groups 1.138 / 1.145 / 1.153)
+            constexpr int BAR = (C2_BAR >= 0) ? C2_BAR : (NARROW ? 0 : (K64 ? 2 : (G > 8 ? 1 : 0)));
             // The tail of pixel (r, c) in three parts; the half-step barrier falls between two of them (C2_BAR: everything after O2 is
             // register-only in a fit thread, so the barrier sits where both roles take about the same time in both halves).
             float s = 0.0f, er = 0.0f, ep = 0.0f;
@@ -1134,7 +1160,7 @@ __global__ __launch_bounds__(2 * (NARROW ? 128 : C2_COLS_DEF), c2_wps(G, sizeof(
 static inline size_t chain2_lds_bytes(int G, size_t ksize = 4, int cols = C2_COLS_DEF, bool kring = true, bool wring = true) {
     // x ring (3 rows) + O1 ring (3 rows) + flag word (+ packed groupdq / gain) rings (3 rows) + channel lines + K ring (2 rows)
     return (size_t)(G / 2) * cols * 8 * 3 + (size_t)G * cols * ksize * 3 + (size_t)cols * 4 * 3 * (wring ? 2 + (G + 3) / 4 : 1) +
-           (size_t)3 * G * 2 * 8 + (kring ? (size_t)2 * 9 * cols * ksize : 0);
+           (size_t)(cols / RIP_CW + 1) * G * 2 * 8 + (kring ? (size_t)2 * 9 * cols * ksize : 0);
 }
 
 // Launch geometry on `slots` co-resident workgroups, `reserve` of them left free where that costs nothing (the pre-pass of the NEXT
@@ -1173,7 +1199,7 @@ static inline long chain2_geometry(ChainArgs &a, int nstrips, int live_last, int
 
 template <int NP, int G, int START, typename KT = float, int NARROW = 0>
 static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
-    constexpr int COLS = NARROW ? 128 : C2_COLS_DEF;
+    constexpr int COLS = c2_cols(sizeof(KT) == 8, NARROW);
     const size_t lds = chain2_lds_bytes(G, sizeof(KT), COLS, !NARROW, NARROW < 2);
     const int ncu = ctx->ncu;
     int per_cu = (int)((160 * 1024) / lds);
