@@ -43,8 +43,9 @@ if REPO not in sys.path:
 
 # HIP events round the kernels of every PROFILE_EVERY-th timed step (the kernel durations of the roofline block are their averages).
 # With events round every kernel of EVERY call the event packets themselves cost 0.02-0.03 ms of wall time per ramp (same-box A/B,
-# profiles/r04_summary.md): every 16th step keeps >= 60 samples of the default 1000 steps and the wall time clean.
-PROFILE_EVERY = max(1, int(os.environ.get("BENCH_PROFILE_EVERY", "16")))
+# profiles/r04_summary.md): every 15th step keeps >= 60 samples of the default 1000 steps and the wall time clean (an ODD period:
+# consecutive calls alternate between two sets of table / flag buffers, an even period would only ever see one of them).
+PROFILE_EVERY = max(1, int(os.environ.get("BENCH_PROFILE_EVERY", "15")))
 # vector-pipe floors of the fused kernel's instantiations (ms per 4096 x 4096 ramp, P_ORDER 8): SQ_INSTS_VALU of the kernel at 2
 # cycles per f32-rate and 4 per f64-rate instruction on 1024 SIMDs at 2.1 GHz (profiles/r03_variant_counters.txt).  Where this floor
 # lies above the HBM floor (16 groups) the HBM fraction alone misstates the bound: the variants carry both.

@@ -151,13 +151,6 @@ __device__ __forceinline__ const RIP_K C2KernArgs *c2_args(const RIP_K C2KernArg
     return p;
 }
 
-struct C2AllT {
-    static constexpr bool value = true;
-};
-struct C2SomeT {
-    static constexpr bool value = false;
-};
-
 // forward IPC operator in f64 for NBB groups in lockstep (f64 ipc4d): v[b][k] = source value of term k of group b, terms in the
 // reference's order (0 centre, 1 (y-1, x), 2 (y+1, x), 3 (y, x-1), 4 (y, x+1), 5 (y-1, x-1), 6 (y-1, x+1), 7 (y+1, x-1),
 // 8 (y+1, x+1) as the rows / columns of the rings hold them); the NBB products of a term first, then the NBB accumulating adds --
@@ -424,26 +417,6 @@ __global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, siz
         const unsigned rowbits = (r0 ? 0x184u : 0u) | (r1 ? 0x019u : 0u) | (r2 ? 0x062u : 0u);
         return r1 ? (lane_mask & rowbits) : 0u;
     };
-    // forward IPC operator in f64 at one column: at_m / at_0 / at_p read rows y-1 / y / y+1 at a column offset; term order
-    // and edge rule of ipc_linearity.py:69-94 (fwd_rows in chain_common.h)
-    auto ipc9 = [&](auto allc, auto at_m, auto at_0, auto at_p, const double (&kk)[9], unsigned valid) -> double {
-        constexpr bool ALL = decltype(allc)::value;
-        double acc = (double)at_0(0) * kk[0];
-        auto term = [&](int k, double v) {
-            const double p_ = v * kk[k];
-            acc = (ALL || ((valid >> k) & 1u)) ? acc + p_ : acc;
-        };
-        term(1, (double)at_m(0));
-        term(2, (double)at_p(0));
-        term(3, (double)at_0(-1));
-        term(4, (double)at_0(1));
-        term(5, (double)at_m(-1));
-        term(6, (double)at_m(1));
-        term(7, (double)at_p(-1));
-        term(8, (double)at_p(1));
-        return acc;
-    };
-
 #ifdef CH_STAMP
     unsigned long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tl_ = __builtin_amdgcn_s_memtime();
