@@ -42,25 +42,45 @@ __global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict_
         c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);
         const double sc = sqrt(c), lc = (c > 0.0) ? log(c) : 0.0;
         const double *w = share + MAX_READS, *sw = share + 2 * MAX_READS, *lw = share + 3 * MAX_READS;
+        // Means below 10 (a few electrons per read: the sky) by inversion in f32 -- the sequential search for the first k whose
+        // cumulative probability passes a 23-bit uniform deviate -- with the exponential once per run of reads of one share (equal read
+        // spacings give equal shares up to the rounding of the time differences) and ONE Philox block for four reads; larger means
+        // by the transformed rejection of poisson_pre in f64.  Device deviates are unpinned by nature (tests: mean, variance, P(0)).
         double got_d = 0.0;
-        double w_prev = -1.0, lam = 0.0, p0 = 0.0;   // reads of one share have one mean: its exponential once
-        double u_next = -1.0;                        // the second pair of words of a Philox block serves the read after (inversion branch)
-        for (int r = 0; r < nreads; ++r) {
-            if (fabs(w[r] - w_prev) > 1e-12 * w_prev) {   // (equal read spacings give equal shares up to the rounding of the time differences)
-                w_prev = w[r];
-                lam = c * w[r];
-                p0 = (lam > 0.0 && lam < 10.0) ? exp(-lam) : 0.0;
+        double w_prev = -1.0, lam = 0.0;
+        float lam32 = 0.0f, p032 = 0.0f;
+        bool small = false;
+        for (int r0 = 0; r0 < nreads; r0 += 4) {
+            uint32_t cw_[4] = {(uint32_t)i, (uint32_t)r0, TAG_TOTAL, 0x706f6934u};
+            riprng::philox(cw_, seed);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + q;
+                if (r >= nreads) break;
+                if (fabs(w[r] - w_prev) > 1e-12 * w_prev) {
+                    w_prev = w[r];
+                    lam = c * w[r];
+                    small = lam > 0.0 && lam < 10.0;
+                    lam32 = (float)lam;
+                    p032 = small ? __expf(-lam32) : 0.0f;
+                }
+                double k = 0.0;
+                if (small) {
+                    const float u = (float)(cw_[q] >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // in (0, 1), never 1
+                    float p_ = p032, cdf = p_;
+                    int kk = 0;
+                    while (u > cdf && p_ > 1e-12f && kk < 200) {   // (p below 1e-12: the sum cannot grow any more)
+                        ++kk;
+                        p_ *= lam32 * __builtin_amdgcn_rcpf((float)kk);
+                        cdf += p_;
+                    }
+                    k = (double)kk;
+                } else if (lam > 0.0) {
+                    k = riprng::poisson_pre(lam, sc * sw[r], lc + lw[r], seed, (uint32_t)i, (uint32_t)r, TAG_TOTAL, 0.0, -1.0);
+                }
+                got_d += k;
+                out[(size_t)r * npix + i] = (int)(got_d > 2.0e9 ? 2.0e9 : got_d);
             }
-            double u = u_next;
-            u_next = -1.0;
-            if (u < 0.0 && lam > 0.0 && lam < 10.0) {
-                uint32_t cw_[4] = {(uint32_t)i, (uint32_t)r, TAG_TOTAL, 0x706f6932u};
-                riprng::philox(cw_, seed);
-                u = riprng::u53(cw_[0], cw_[1]);
-                u_next = riprng::u53(cw_[2], cw_[3]);
-            }
-            got_d += riprng::poisson_pre(lam, sc * sw[r], lc + lw[r], seed, (uint32_t)i, (uint32_t)r, TAG_TOTAL, p0, u);
-            out[(size_t)r * npix + i] = (int)(got_d > 2.0e9 ? 2.0e9 : got_d);
         }
         return;
     }

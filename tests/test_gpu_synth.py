@@ -122,6 +122,18 @@ def test_apportioning_is_binomial_and_ends_at_the_counts():
     lam = np.full(na, 2500.0, dtype=np.float32)
     e = shares(lam, 5, True).astype(np.float64)
     assert abs(e[-1].mean() - 2500) < 5 * 50 / np.sqrt(e[-1].size) and abs(e[-1].var() / 2500 - 1) < 0.06
+    # small means per read (the sky: a few electrons per read -- the f32 inversion branch of the device generator): totals and
+    # per-read increments are Poisson (mean, variance, probability of zero), increments of different reads uncorrelated
+    nr = len(s.t_reads) - 1   # read 0 at t = 0 receives nothing; the others share the total equally
+    for total in (4.0, 70.0, 330.0):
+        e = shares(np.full(na, total, dtype=np.float32), 40 + int(total), True).astype(np.float64)
+        n = e[-1].size
+        assert abs(e[-1].mean() - total) < 5 * np.sqrt(total / n) and abs(e[-1].var() / total - 1) < 0.06
+        d = np.diff(e, axis=0)
+        per = total / nr
+        assert np.all(d >= 0) and abs(d[5].mean() - per) < 5 * np.sqrt(per / n) and abs(d[20].var() / per - 1) < 0.08
+        assert abs(np.mean(d[11] == 0) - np.exp(-per)) < 5 * np.sqrt(np.exp(-per) * (1 - np.exp(-per)) / n) + 1e-4
+        assert abs(np.corrcoef(d[7].ravel(), d[8].ravel())[0, 1]) < 5 / np.sqrt(n)
     # two seeds differ, one seed repeats
     a, b, c = (shares(lam, sd, True) for sd in (5, 6, 5))
     assert np.array_equal(a, c) and not np.array_equal(a, b)

@@ -1,0 +1,40 @@
+"""apportion_kernel alone: time per 4096 x 4096 frame of 35 reads for several mean totals (device Poisson increments)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+
+from romanimpreprocess_amd import _native, synth
+from romanimpreprocess_amd.from_sim import sim_to_isim
+
+rp = synth.READ_PATTERN_8
+ny = nx = 4096
+cal = synth.make_caldir(264, 512, read_pattern=rp, p_order=3, seed=9)
+ctx = _native.default_context(0)
+s = sim_to_isim.L1Synth(cal, rp, synth.FRAME_TIME, ctx=ctx)
+dev = s.dev
+na = (ny - 8, nx - 8)
+from romanimpreprocess_amd import synth as _s
+rate = _s.make_rate_image(ny, nx, 100)
+print("rate image: median %.3f, 99th percentile %.1f, max %.1f DN/s" % (np.median(rate), np.percentile(rate, 99), rate.max()))
+for total in (1.0, 35.0, 160.0, 340.0, 360.0, 3500.0, "rate"):
+    if total == "rate":
+        c = torch.from_numpy(np.ascontiguousarray((rate[4:-4, 4:-4] * 1.5 * 106.4).astype(np.float32))).to(dev)
+    else:
+        c = torch.full(na, float(total), dtype=torch.float32, device=dev)
+    out = torch.empty((35,) + na, dtype=torch.int32, device=dev)
+    tr = np.ascontiguousarray(s.t_reads, dtype=np.float64)
+    def call():
+        ctx.check(ctx.lib.rip_synth_apportion(ctx.h, c.data_ptr(), na[0], na[1], 1, 35, tr.ctypes.data, 7, out.data_ptr()))
+    torch.cuda.synchronize()
+    for _ in range(3):
+        call()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        call()
+    ctx.synchronize()
+    print(f"mean total {total}: {(time.perf_counter() - t0) * 100:.2f} ms per frame", flush=True)
