@@ -419,7 +419,8 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value);
                 last strip of at most 64 live columns is covered by workgroups whose four wave columns take a row range each
                 (4096 x 4096: 504 workgroups of 139 steps instead of 510 of 143; timing-neutral, profiles/r04_summary.md);
    "overlap" -- run the reference-pixel pre-pass of a ramp on a second stream so that it overlaps the previous ramp's
-                fused kernel. */
+                fused kernel: -1 (default) by situation -- wherever the fused kernel leaves room on the CUs (every form except the
+                f64-ipc4d one of up to 8 groups, whose partial coefficient ring fills the LDS), 0 never, 1 always. */
 
 /* how the last rip_calibrate ran: 0 = stage kernels, 2 = the fused kernel (1 and 3 were the general and the wave-private fused
    kernels of rounds 1-2) */

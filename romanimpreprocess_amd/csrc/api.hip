@@ -224,7 +224,9 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value) {
         return RIP_OK;
     }
     if (name && strcmp(name, "overlap") == 0) {
+        if (value < -1 || value > 1) return rip_fail(ctx, RIP_EINVAL, "overlap: -1 (by situation), 0 or 1");
         ctx->use_overlap = value != 0 && ctx->stream2 != nullptr;
+        ctx->overlap_mode = value;
         return RIP_OK;
     }
     if (name && strcmp(name, "chain_dbg") == 0) {
@@ -790,7 +792,11 @@ int rip_calibrate(rip_ctx *ctx, int slot, int plan_id, unsigned stages, const ri
                     ? (char *)rip_ws(ctx, 3, 2 * tab_bytes + npix * 4 + 512)
                     : nullptr;
     const int par = ctx->parity;
-    const bool overlap = do_ref && !host && ctx->use_overlap;
+    // (by situation: the f64-ipc4d form of up to 8 groups fills the 160 KB of every CU with its partial K ring -- the pre-pass of the
+    // next ramp finds no room beside it, runs when it drains, and the single-launch form in front of the own ramp is the shorter way:
+    // 1.121 against 1.140 ms per ramp, profiles/r04_summary.md)
+    const bool lds_full = c.ipc_dtype == RIP_F64 && G <= 8 && ctx->use_fused && in->data_dtype == RIP_U16;
+    const bool overlap = do_ref && !host && ctx->use_overlap && (ctx->overlap_mode == 1 || !lds_full);
     hipStream_t pre = overlap ? ctx->stream2 : ctx->stream;   // where the pre-pass and the saturation pass of THIS call are launched
     double *rowcorr = nullptr, *rowcorr_t = nullptr, *lines = nullptr;
     // dq-init + saturation flagging into workspace copies of the flag arrays (the caller's inputs stay untouched), double

@@ -151,6 +151,11 @@ __device__ __forceinline__ const RIP_K C2KernArgs *c2_args(const RIP_K C2KernArg
     return p;
 }
 
+template <int N>
+struct C2Int {
+    static constexpr int value = N;
+};
+
 // forward IPC operator in f64 for NBB groups in lockstep (f64 ipc4d): v[b][k] = source value of term k of group b, terms in the
 // reference's order (0 centre, 1 (y-1, x), 2 (y+1, x), 3 (y, x-1), 4 (y, x+1), 5 (y-1, x-1), 6 (y-1, x+1), 7 (y+1, x-1),
 // 8 (y+1, x+1) as the rows / columns of the rings hold them); the NBB products of a term first, then the NBB accumulating adds --
@@ -219,6 +224,17 @@ __device__ __forceinline__ void c2_div64_shared(const double (&a)[NG], float bf,
 constexpr int c2_cols(bool k64, int narrow) {
     return narrow == 0 ? C2_COLS_DEF : (narrow == 1 ? C2_N1_COLS : (k64 ? C2_N2K_COLS : C2_N2_COLS));
 }
+// coefficients of the partial K ring of the NARROW = 1 forms: what fits beside the other rings in 160 KB (C2_N1_KRN: A/B switch)
+#ifndef C2_N1_KRN
+#define C2_N1_KRN 9
+#endif
+constexpr int c2_krn(int G) {
+    // x ring + f64 O1 ring + word rings of C2_N1_COLS columns, lines: what is left over / (2 rows x C2_N1_COLS x 8 bytes)
+    const long used = (long)(G / 2) * C2_N1_COLS * 8 * 3 + (long)G * C2_N1_COLS * 8 * 3 + (long)C2_N1_COLS * 4 * 3 * (2 + (G + 3) / 4) +
+                      (long)(C2_N1_COLS / RIP_CW + 1) * G * 2 * 8;
+    const long fit = (160 * 1024 - used) / (2L * C2_N1_COLS * 8);
+    return fit < 0 ? 0 : (fit > C2_N1_KRN ? C2_N1_KRN : (int)fit);
+}
 // waves per SIMD an instantiation is compiled for (register budget 512 / waves) and launched with
 constexpr int c2_wps(int G, bool k64, int narrow) {
     return !narrow ? ((G > 8 || k64) ? 2 : 4) : ((k64 && G > 8) ? 2 : ((k64 || G > 8) ? 3 : 4));
@@ -240,6 +256,11 @@ __global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, siz
     static_assert(G % 2 == 0 && G > 4 && G <= 16, "pairs of groups; the groupdq bytes travel packed four to a word");
     constexpr int COLS = c2_cols(sizeof(KT) == 8, NARROW);
     constexpr bool KRING = !NARROW;
+    // NARROW = 1 (f64 ipc4d x 6 / 8 groups; 129.5 KB of the 160 at 384 columns): the LDS left over holds a PARTIAL K ring -- the
+    // first KRN of the nine f64 coefficients travel from the ingest thread to the fit thread through LDS (two rows, like the full ring
+    // of the 256-column form), the fit role reads only the other 9 - KRN planes a second time: 32 instead of 72 bytes per pixel of
+    // re-read (traffic 1.33 -> 1.18 x), five loads fewer per step in flight in the fit role
+    constexpr int KRN = KRING ? 9 : ((NARROW == 1 && sizeof(KT) == 8) ? c2_krn(G) : 0);
     constexpr bool WRING = NARROW < 2;   // NARROW = 2 (16 groups): gain and packed groupdq bytes do not travel through LDS either --
                                          // the fit role loads them itself, like the coefficients (51 KB: three workgroups per CU)
     constexpr int QW = (G + 3) / 4;  // words of packed group flags per pixel
@@ -266,7 +287,7 @@ __global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, siz
     constexpr int NLC = C2_COLS / RIP_CW + 1;                       // channels a window can touch (a window is not channel-aligned)
     f2 *KR2 = reinterpret_cast<f2 *>(LN + NLC * G * 2);               // f32 ipc4d: [2][4][C2_COLS] pairs (k0,k1)..(k6,k7)
     float *KR1 = reinterpret_cast<float *>(KR2 + 2 * 4 * C2_COLS);  //            [2][C2_COLS] k8
-    double *KRd = reinterpret_cast<double *>(LN + NLC * G * 2);       // f64 ipc4d: [2][9][C2_COLS]
+    double *KRd = reinterpret_cast<double *>(LN + NLC * G * 2);       // f64 ipc4d: [2][KRN][C2_COLS]
 
     // ChainArgs is the first kernel argument: it sits at offset 0 of the kernarg segment
     const RIP_K C2KernArgs *kargs = (const RIP_K C2KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -388,7 +409,9 @@ __global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, siz
     };
 
     // f64 coefficients: the same walk with 8-byte loads, nine scalars in the reference's term order
-    auto load_kd = [&](const void *kern_base, int y, bool want, double (&kk)[9]) -> unsigned {
+    // (kmin: terms below it are not loaded -- the fit role of a form with a partial K ring gets them through LDS)
+    auto load_kd = [&](const void *kern_base, int y, bool want, double (&kk)[9], auto kmin_c) -> unsigned {
+        constexpr int KMIN = decltype(kmin_c)::value;
         unsigned rowoff[3];
         bool rok[3];
 #pragma unroll
@@ -405,7 +428,7 @@ __global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, siz
             const int dy = p / 3 - 1, dx = p % 3 - 1;
             const int k = (dy == 0) ? (dx == 0 ? 0 : dx == 1 ? 3 : 4) : (dy == 1) ? (dx == 0 ? 1 : dx == 1 ? 5 : 6)
                                                                                   : (dx == 0 ? 2 : dx == 1 ? 7 : 8);
-            kk[k] = c2_ld_f64(kr, cx4[dx + 1] * 2u, pofs + rowoff[dy + 1]);
+            if (k >= KMIN) kk[k] = c2_ld_f64(kr, cx4[dx + 1] * 2u, pofs + rowoff[dy + 1]);
             pofs += pl4 * 2u;
         }
         const unsigned um = (want && y >= ay0 && y < ay1) ? rowbits : 0u;
@@ -667,7 +690,7 @@ __global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, siz
             kC[4].y = 0.0f;
             unsigned vC;
             if constexpr (K64)
-                vC = load_kd(ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kCd);
+                vC = load_kd(ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kCd, C2Int<0>{});
             else
                 vC = load_k(ka->kern, yc, do_c && wcol >= 1 && wcol < wl - 1, kC);
             CH_T(2)
@@ -683,11 +706,11 @@ __global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, siz
                 const int so = so_c;  // slot of row yc in both 3-row rings
                 const int sm = (so == 0) ? 2 : so - 1, s0 = so, sp = (so == 2) ? 0 : so + 1;
                 // hand the coefficients of destination row yc to the fit thread of this column (O2 of row yc, two steps on)
-                if constexpr (KRING) {
+                if constexpr (KRN > 0) {
                     const int ks = yc & 1;
                     if constexpr (K64) {
 #pragma unroll
-                        for (int k = 0; k < 9; ++k) KRd[(ks * 9 + k) * C2_COLS + col] = kCd[k];
+                        for (int k = 0; k < KRN; ++k) KRd[(ks * KRN + k) * C2_COLS + col] = kCd[k];
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) KR2[(ks * 4 + i) * C2_COLS + col] = kC[i];
@@ -925,18 +948,18 @@ __global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, siz
 #endif
 #else
                 if constexpr (K64)
-                    (void)load_kd(kf->a.kern, r, true, kFd);
+                    (void)load_kd(kf->a.kern, r, true, kFd, C2Int<KRN>{});
                 else
                     (void)load_k(kf->a.kern, r, true, kF);
 #endif
             }
             if (emit) {
                 // the nine coefficients of destination (r, col) from the ingest thread of this column
-                if constexpr (KRING) {
+                if constexpr (KRN > 0) {
                     const int ks = r & 1;
                     if constexpr (K64) {
 #pragma unroll
-                        for (int k = 0; k < 9; ++k) kFd[k] = KRd[(ks * 9 + k) * C2_COLS + col];
+                        for (int k = 0; k < KRN; ++k) kFd[k] = KRd[(ks * KRN + k) * C2_COLS + col];
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) kF[i] = KR2[(ks * 4 + i) * C2_COLS + col];
@@ -1105,14 +1128,14 @@ __global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, siz
 #if C2_KFIT_EARLY == 2   // (row r + 2: the lines the ingest role fetched half a step ago)
             if constexpr (!KRING) {
                 if constexpr (K64)
-                    (void)load_kd(kg->a.kern, r + 2, true, kn2_d);
+                    (void)load_kd(kg->a.kern, r + 2, true, kn2_d, C2Int<KRN>{});
                 else
                     (void)load_k(kg->a.kern, r + 2, true, kn2);
             }
 #elif C2_KFIT_EARLY
             if constexpr (!KRING) {
                 if constexpr (K64)
-                    (void)load_kd(kg->a.kern, (dbg & 1024) ? R0 : r + 1, true, kn_d);
+                    (void)load_kd(kg->a.kern, (dbg & 1024) ? R0 : r + 1, true, kn_d, C2Int<KRN>{});
                 else
                     (void)load_k(kg->a.kern, (dbg & 1024) ? R0 : r + 1, true, kn);
             }
@@ -1130,10 +1153,10 @@ __global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, siz
 #endif
 }
 
-static inline size_t chain2_lds_bytes(int G, size_t ksize = 4, int cols = C2_COLS_DEF, bool kring = true, bool wring = true) {
+static inline size_t chain2_lds_bytes(int G, size_t ksize = 4, int cols = C2_COLS_DEF, int krn = 9, bool wring = true) {
     // x ring (3 rows) + O1 ring (3 rows) + flag word (+ packed groupdq / gain) rings (3 rows) + channel lines + K ring (2 rows)
     return (size_t)(G / 2) * cols * 8 * 3 + (size_t)G * cols * ksize * 3 + (size_t)cols * 4 * 3 * (wring ? 2 + (G + 3) / 4 : 1) +
-           (size_t)(cols / RIP_CW + 1) * G * 2 * 8 + (kring ? (size_t)2 * 9 * cols * ksize : 0);
+           (size_t)(cols / RIP_CW + 1) * G * 2 * 8 + (size_t)2 * krn * cols * ksize;
 }
 
 // Launch geometry on `slots` co-resident workgroups, `reserve` of them left free where that costs nothing (the pre-pass of the NEXT
@@ -1173,7 +1196,8 @@ static inline long chain2_geometry(ChainArgs &a, int nstrips, int live_last, int
 template <int NP, int G, int START, typename KT = float, int NARROW = 0>
 static int launch_chain2_s(rip_ctx *ctx, const RipPlan *plan, const ChainArgs &a) {
     constexpr int COLS = c2_cols(sizeof(KT) == 8, NARROW);
-    const size_t lds = chain2_lds_bytes(G, sizeof(KT), COLS, !NARROW, NARROW < 2);
+    constexpr int KRN = !NARROW ? 9 : ((NARROW == 1 && sizeof(KT) == 8) ? c2_krn(G) : 0);
+    const size_t lds = chain2_lds_bytes(G, sizeof(KT), COLS, KRN, NARROW < 2);
     const int ncu = ctx->ncu;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;

@@ -125,6 +125,7 @@ struct rip_ctx {
     bool ev_done_valid[2] = {false, false};
     int parity = 0;
     bool use_overlap = true;
+    int overlap_mode = -1;   // -1: by situation (see rip_calibrate), 1: wherever possible
     bool use_chain2 = true;  // wave-specialised fused kernel where it applies
     int last_form = 0;       // diagnostic: how the last rip_calibrate ran (0 stage kernels, 2 the fused kernel; 1 and 3 were the general and the wave-private fused kernels of rounds 1-2)
     std::string err;

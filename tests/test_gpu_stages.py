@@ -377,7 +377,10 @@ def test_refpix_tables_fullframe_vs_reference_medians(name):
 
 @pytest.mark.parametrize("ny,nx,G,kind", [(8, 128, 1, "noise"), (40, 256, 3, "noise"), (136, 384, 8, "ties"), (300, 128, 16, "noise"),
                                           (1160, 256, 5, "drift"), (129, 128, 2, "const"), (4096, 512, 8, "noise"),
-                                          (520, 128, 64, "ties")])
+                                          (520, 128, 64, "ties"),
+                                          # 64 groups x 32 workgroups = 2048 workgroups of 1024 threads, eight times what the device
+                                          # holds at once: the groups' barriers complete in dispatch order (no deadlock, status 0)
+                                          (4096, 128, 64, "noise")])
 def test_refpix_tables_single_launch_equals_multi_launch_and_oracle(ny, nx, G, kind):
     """The two forms of the pre-pass (multi-launch, single launch).  Random frames -- ragged row counts (partial workgroups and slots), one to 32 workgroups per group, up to 64 groups, heavy
     ties (few distinct values: every histogram level has crowded bins), constant blocks, drifting rows, f32 cubes: the two forms
