@@ -503,10 +503,10 @@ int rip_synth_fill(rip_ctx *ctx, const rip_synth_cal *cal, int ngrp, const int32
 int rip_synth_noise_1f(rip_ctx *ctx, int rows, int width, int nframes, uint64_t seed, uint32_t stream_id, float *out);
 /* The 1/f frames of the NEXT rip_synth_fill(frames = NULL, banding != 0, the same seed and geometry: rows = ny, width =
    channelwidth, nframes = ngrp * (nx / channelwidth + 2)) made AHEAD on the context's second stream, so that the Fourier
-   transforms (HBM-bound) run beside the apportioning / inverse-linearity kernels (arithmetic-bound) queued on rip_stream()
-   between this call and the fill: same frames, same bits, 17 ms of a 4096^2 x 8 exposure's 74 ms hidden.  The fill waits for
-   them; a fill with another seed or geometry, or any other 1/f call, waits too and makes its own.  No-op without a second
-   stream. */
+   transforms (HBM-bound) run beside the inverse-linearity kernel (arithmetic-bound) queued on rip_stream() between this call
+   and the fill: same frames, same bits.  They start behind whatever rip_stream() holds at the time of the call -- call it AFTER
+   rip_synth_apportion (HBM-bound too) and before rip_synth_resultants.  The fill waits for them; a fill with another seed or
+   geometry, or any other 1/f call, waits too and makes its own.  No-op without a second stream. */
 int rip_synth_frames_ahead(rip_ctx *ctx, int rows, int width, int nframes, uint64_t seed);
 
 /* EXTRACT_REF (:711-730) on n-element planes: reference_read = data[0]; data[k] = clip(i32(data[k]) - (i32(data[0]) -

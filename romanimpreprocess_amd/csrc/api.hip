@@ -143,6 +143,8 @@ void rip_ctx_destroy(rip_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     for (auto &c : ctx->cals) free_cal(c);
     for (auto *p : ctx->plans)
         if (p) {
@@ -150,7 +152,7 @@ void rip_ctx_destroy(rip_ctx *ctx) {
             delete p;
         }
     rip_pink_release(ctx);
-    for (hipEvent_t e : {ctx->ev_tab[0], ctx->ev_tab[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_in, ctx->ev_pre, ctx->ev_frames, ctx->ev_fill, ctx->ev_pink})
+    for (hipEvent_t e : {ctx->ev_tab[0], ctx->ev_tab[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_in, ctx->ev_pre, ctx->ev_frames, ctx->ev_fill, ctx->ev_pink, ctx->ev_ahead})
         if (e) (void)hipEventDestroy(e);
     for (void *p : ctx->ws)   // every workspace slot, the Level-1 synthesis ones included
         if (p) (void)hipFree(p);
@@ -221,6 +223,10 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value) {
     if (name && strcmp(name, "prepass_form") == 0) {
         if (value < -1 || value > 1) return rip_fail(ctx, RIP_EINVAL, "prepass_form: -1 (by situation), 0 or 1");
         ctx->prepass_form = value;
+        return RIP_OK;
+    }
+    if (name && strcmp(name, "pink_form") == 0) {
+        ctx->pink_form = value;
         return RIP_OK;
     }
     if (name && strcmp(name, "overlap") == 0) {

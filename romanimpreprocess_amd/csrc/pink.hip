@@ -14,6 +14,7 @@
 
 #include <algorithm>
 
+#include "pink_fft.h"
 #include "rip_common.h"
 
 namespace {
@@ -53,11 +54,16 @@ __device__ __forceinline__ void pink_term(const double *__restrict__ normals, co
     } else {
         uint32_t c[4] = {(uint32_t)k, (uint32_t)(k >> 32) ^ (uint32_t)f, stream_id, 0x70696e6bu};
         philox10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        // Box-Muller on a 53-bit and a 32-bit uniform deviate, the logarithm and the circular functions in f32 (as every other
+        // device deviate of the library, rip_rng.h): the frames are f32, the deviates need no more -- and the f64 versions were
+        // half of the generator's instructions, which run beside rip_synth_resultants' f64 arithmetic (profiles/r04_summary.md)
         const double u1 = ((double)(((uint64_t)c[0] << 21) | (c[1] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);   // 53 bits, (0, 1)
-        const double u2 = ((double)(((uint64_t)c[2] << 21) | (c[3] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);
-        const double r = sqrt(-2.0 * log(u1));
-        a = r * cospi(2.0 * u2);
-        b = r * sinpi(2.0 * u2);
+        const float u2 = ((float)(c[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);                                      // 24 bits, (0, 1)
+        const float r = sqrtf(-2.0f * logf((float)u1));   // ((float)u1 keeps the small values: the tail is the 53-bit one)
+        float sn, cs;
+        sincospif(2.0f * u2, &sn, &cs);
+        a = (double)(r * cs);
+        b = (double)(r * sn);
     }
     const double amp = amps[k];
     re = a * amp;
@@ -68,24 +74,68 @@ __device__ __forceinline__ void pink_term(const double *__restrict__ normals, co
 // S_{L/2} = Re z_{L/2}, S_j = ((Re z_j + Re z_{L-j}) - i (Im z_j - Im z_{L-j})) / 2 (the transform counts those terms twice)
 __global__ __launch_bounds__(256) void pink_fill_kernel(const double *__restrict__ normals, const double *__restrict__ amps,
                                                         hipfftDoubleComplex *__restrict__ S, size_t L, int nframes, uint64_t seed,
-                                                        uint32_t stream_id) {
+                                                        uint32_t stream_id, int f_first, int f_block) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
     const size_t half = L / 2;
     if (j > half) return;
+    // generator coordinates of frame F = f_first + f of the call: (F mod f_block, stream_id + F - F mod f_block) -- what the frames
+    // get when they are made in blocks of f_block, whatever the batch of the transform is; the caller's deviates are indexed by f
+    const int fg = normals ? f : (f_first + f) % f_block;
+    stream_id += (uint32_t)((f_first + f) - (f_first + f) % f_block);
     double re, im;
-    pink_term(normals, amps, L, f, j, seed, stream_id, re, im);
+    pink_term(normals, amps, L, fg, j, seed, stream_id, re, im);
     hipfftDoubleComplex v;
     if (j == 0 || j == half) {
         v.x = re;
         v.y = 0.0;
     } else {
         double re2, im2;
-        pink_term(normals, amps, L, f, L - j, seed, stream_id, re2, im2);
+        pink_term(normals, amps, L, fg, L - j, seed, stream_id, re2, im2);
         v.x = (re + re2) * 0.5;
         v.y = -(im - im2) * 0.5;
     }
     S[(size_t)f * (half + 1) + j] = v;
+}
+
+// The coefficients W_j of the hand-written transform (pink_fft.h), j = 0 .. N-1, N = L/2: thread j <= N/2 forms W_j and W_{N-j}
+// from the four deviate pairs (j, L-j, N-j, N+j) they share -- the folded S_j, S_{N-j} of pink_fill_kernel, never stored:
+//     E = S_j + conj S_{N-j},  D = S_j - conj S_{N-j},  w = e^{2 pi i j / L}:   W_j = E + i w D,   W_{N-j} = conj(E - i w D)
+//     W_0 = (S_0 + S_N) + i (S_0 - S_N)  (both real),   W_{N/2} = 2 conj S_{N/2}
+__global__ __launch_bounds__(256) void pink_fill_w_kernel(const double *__restrict__ normals, const double *__restrict__ amps,
+                                                          double2 *__restrict__ W, size_t L, uint64_t seed, uint32_t stream_id,
+                                                          int f_first, int f_block) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    const size_t N = L / 2;
+    if (j > N / 2) return;
+    const int fg = normals ? f : (f_first + f) % f_block;
+    stream_id += (uint32_t)((f_first + f) - (f_first + f) % f_block);
+    double2 *Wf = W + (size_t)f * N;
+    double ra, ia, rb, ib;
+    if (j == 0) {
+        pink_term(normals, amps, L, fg, 0, seed, stream_id, ra, ia);
+        pink_term(normals, amps, L, fg, N, seed, stream_id, rb, ib);
+        Wf[0] = make_double2(ra + rb, ra - rb);
+        return;
+    }
+    pink_term(normals, amps, L, fg, j, seed, stream_id, ra, ia);
+    pink_term(normals, amps, L, fg, L - j, seed, stream_id, rb, ib);
+    const double2 sj = make_double2((ra + rb) * 0.5, -(ia - ib) * 0.5);
+    const size_t m = N - j;
+    if (m == j) {
+        Wf[j] = make_double2(2.0 * sj.x, -2.0 * sj.y);
+        return;
+    }
+    pink_term(normals, amps, L, fg, m, seed, stream_id, ra, ia);
+    pink_term(normals, amps, L, fg, L - m, seed, stream_id, rb, ib);
+    const double2 sm = make_double2((ra + rb) * 0.5, -(ia - ib) * 0.5);
+    const double2 E = make_double2(sj.x + sm.x, sj.y - sm.y), D = make_double2(sj.x - sm.x, sj.y + sm.y);
+    double ws, wc;
+    sincospi((double)j / (double)N, &ws, &wc);   // e^{i pi j / N}
+    const double2 wd = make_double2(wc * D.x - ws * D.y, wc * D.y + ws * D.x), iwd = make_double2(-wd.y, wd.x);
+    Wf[j] = make_double2(E.x + iwd.x, E.y + iwd.y);
+    Wf[m] = make_double2(E.x - iwd.x, -(E.y - iwd.y));
 }
 
 // sum of x[0 : L/2] / sqrt(2) per frame (f64): 256 block partials per frame, added in a FIXED order by pink_out_kernel
@@ -105,16 +155,31 @@ __global__ __launch_bounds__(256) void pink_sum_kernel(const double *__restrict_
     if (threadIdx.x == 0) sums[(size_t)f * gridDim.x + blockIdx.x] = sh[0];
 }
 
+// the frame's mean from the 256 block sums, added in index order (same bits in every run); written over the frame's first sum
+__global__ __launch_bounds__(64) void pink_mean_kernel(double *__restrict__ sums, size_t half, int nframes) {
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= nframes) return;
+    double tot = 0.0;
+    for (int b = 0; b < 256; ++b) tot += sums[(size_t)f * 256 + b];
+    sums[(size_t)f * 256] = tot / (double)half;
+}
+
 __global__ __launch_bounds__(256) void pink_out_kernel(const double *__restrict__ x, size_t L, const double *__restrict__ sums,
                                                        float *__restrict__ out) {
-    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t k = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;   // two samples per thread
     const int f = blockIdx.y;
     const size_t half = L / 2;
     if (k >= half) return;
-    double tot = 0.0;
-    for (int b = 0; b < 256; ++b) tot += sums[(size_t)f * 256 + b];  // same order in every thread and every run
-    const double mean = tot / (double)half;
-    out[(size_t)f * half + k] = (float)(x[(size_t)f * L + k] / sqrt(2.0) - mean);
+    const double mean = sums[(size_t)f * 256];
+    const double *xf = x + (size_t)f * L;
+    float *of = out + (size_t)f * half;
+    if ((half & 1) == 0) {   // (an odd frame size: the pairs of the odd frames are not aligned)
+        const double2 v = *reinterpret_cast<const double2 *>(xf + k);
+        *reinterpret_cast<float2 *>(of + k) = make_float2((float)(v.x / sqrt(2.0) - mean), (float)(v.y / sqrt(2.0) - mean));
+    } else {
+        of[k] = (float)(xf[k] / sqrt(2.0) - mean);
+        if (k + 1 < half) of[k + 1] = (float)(xf[k + 1] / sqrt(2.0) - mean);
+    }
 }
 
 // out: host memory (frames copied back chunk by chunk, call synchronous) or, out_dev, device memory (asynchronous: the transform
@@ -144,9 +209,15 @@ int noise_1f_impl(rip_ctx *ctx, hipStream_t st, int rows, int width, int nframes
             return rc;                                                                 \
         }                                                                              \
     } while (0)
-    // frames are transformed in chunks so that the complex buffer stays below ~1 GB
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nframes, ((size_t)1 << 30) / (L * sizeof(hipfftDoubleComplex))));
-    if (ctx->pink_L != L || ctx->pink_chunk != chunk) {   // another frame length or batch: new plan and buffers
+    // frames are transformed in chunks so that the complex buffer stays at about 1 GB: equal chunks (272 frames of 2^20 points:
+    // 5 x 55, not 4 x 64 + 16 padded to 64 -- the transform runs its full batch every time).  The device generator's streams are
+    // laid out in blocks of `fblock` frames whatever the chunk is (pink_fill_kernel)
+    const int fblock = (int)std::max<size_t>(1, ((size_t)1 << 30) / (L * sizeof(hipfftDoubleComplex)));
+    const int nchunks = (nframes + fblock - 1) / fblock;
+    const int chunk = (nframes + nchunks - 1) / nchunks;
+    // power-of-two frames: the hand-written two-pass transform (pink_fft.h); otherwise (and with option "pink_form" = 0) the library's
+    const bool own = ctx->pink_form != 0 && pf::supported(L);
+    if (ctx->pink_L != L || ctx->pink_chunk != chunk || ctx->pink_own != own) {   // another frame length or batch: new plan and buffers
         PK_HIP(hipStreamSynchronize(ctx->stream));       // (either stream may still be using the old ones)
         if (ctx->stream2) PK_HIP(hipStreamSynchronize(ctx->stream2));
         rip_pink_release(ctx);
@@ -155,17 +226,30 @@ int noise_1f_impl(rip_ctx *ctx, hipStream_t st, int rows, int width, int nframes
         PK_HIP(hipMalloc(&ctx->pink_s, ((size_t)chunk * 256 + L) * sizeof(double)));   // the block sums, then the amplitudes a_k
         hipLaunchKernelGGL(pink_amp_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, (double *)ctx->pink_s + (size_t)chunk * 256, L);
         PK_HIP(hipStreamSynchronize(st));   // (once per frame length: later calls may come on the context's other stream)
-        int n1 = (int)L;
-        hipfftHandle made = 0;
-        if (hipfftPlanMany(&made, 1, &n1, nullptr, 1, (int)(half + 1), nullptr, 1, n1, HIPFFT_Z2D, chunk) != HIPFFT_SUCCESS) {
-            rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftPlanMany(%zu points x %d) failed", L, chunk);
-            rip_pink_release(ctx);
-            done();
-            return rc;
+        if (own) {
+            pf::Tables *t = new pf::Tables();
+            ctx->pink_tab = t;
+            const hipError_t e = pf::make_tables(L, *t);
+            if (e != hipSuccess) {
+                rc = rip_fail(ctx, RIP_EHIP, "noise_1f: transform tables for %zu points: %s", L, hipGetErrorString(e));
+                rip_pink_release(ctx);
+                done();
+                return rc;
+            }
+        } else {
+            int n1 = (int)L;
+            hipfftHandle made = 0;
+            if (hipfftPlanMany(&made, 1, &n1, nullptr, 1, (int)(half + 1), nullptr, 1, n1, HIPFFT_Z2D, chunk) != HIPFFT_SUCCESS) {
+                rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftPlanMany(%zu points x %d) failed", L, chunk);
+                rip_pink_release(ctx);
+                done();
+                return rc;
+            }
+            ctx->pink_plan = (void *)made;
         }
-        ctx->pink_plan = (void *)made;
         ctx->pink_L = L;
         ctx->pink_chunk = chunk;
+        ctx->pink_own = own;
     }
     hipfftDoubleComplex *z = (hipfftDoubleComplex *)ctx->pink_z;
     double *x = reinterpret_cast<double *>(z + (size_t)chunk * (half + 1));
@@ -174,7 +258,7 @@ int noise_1f_impl(rip_ctx *ctx, hipStream_t st, int rows, int width, int nframes
     hipfftHandle plan = (hipfftHandle)ctx->pink_plan;
     if (!out_dev) PK_HIP(hipMalloc((void **)&d_o, (size_t)chunk * half * sizeof(float)));
     if (normals) PK_HIP(hipMalloc((void **)&d_n, (size_t)chunk * 2 * L * sizeof(double)));
-    if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS) {
+    if (!own && hipfftSetStream(plan, st) != HIPFFT_SUCCESS) {
         rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftSetStream failed");
         done();
         return rc;
@@ -183,18 +267,28 @@ int noise_1f_impl(rip_ctx *ctx, hipStream_t st, int rows, int width, int nframes
         const int nf = std::min(chunk, nframes - f0);
         if (normals)
             PK_HIP(hipMemcpyAsync(d_n, normals + (size_t)f0 * 2 * L, (size_t)nf * 2 * L * sizeof(double), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(pink_fill_kernel, dim3((unsigned)((half + 1 + 255) / 256), nf), dim3(256), 0, st, (const double *)d_n, d_amp, z, L,
-                           nf, seed, stream_id + (uint32_t)f0);
-        if (nf < chunk)
-            PK_HIP(hipMemsetAsync(z + (size_t)nf * (half + 1), 0, (size_t)(chunk - nf) * (half + 1) * sizeof(hipfftDoubleComplex), st));
-        if (hipfftExecZ2D(plan, z, x) != HIPFFT_SUCCESS) {
-            rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftExecZ2D failed");
-            done();
-            return rc;
+        if (own) {
+            const pf::Tables &t = *(const pf::Tables *)ctx->pink_tab;
+            double2 *w = reinterpret_cast<double2 *>(z);
+            hipLaunchKernelGGL(pink_fill_w_kernel, dim3((unsigned)((half / 2 + 1 + 255) / 256), nf), dim3(256), 0, st, (const double *)d_n, d_amp,
+                               w, L, seed, stream_id, f0, fblock);
+            hipLaunchKernelGGL(pf::pf_cols_kernel, dim3(t.dev.n2 / pf::TW, nf), dim3(pf::NT1), t.lds1, st, w, t.dev);
+            hipLaunchKernelGGL(pf::pf_rows_kernel, dim3(t.dev.n1 / pf::TW, nf), dim3(pf::NT2), t.lds2, st, (const double2 *)w, x, t.dev);
+        } else {
+            hipLaunchKernelGGL(pink_fill_kernel, dim3((unsigned)((half + 1 + 255) / 256), nf), dim3(256), 0, st, (const double *)d_n, d_amp, z, L,
+                               nf, seed, stream_id, f0, fblock);
+            if (nf < chunk)
+                PK_HIP(hipMemsetAsync(z + (size_t)nf * (half + 1), 0, (size_t)(chunk - nf) * (half + 1) * sizeof(hipfftDoubleComplex), st));
+            if (hipfftExecZ2D(plan, z, x) != HIPFFT_SUCCESS) {
+                rc = rip_fail(ctx, RIP_EHIP, "noise_1f: hipfftExecZ2D failed");
+                done();
+                return rc;
+            }
         }
         hipLaunchKernelGGL(pink_sum_kernel, dim3(256, nf), dim3(256), 0, st, (const double *)x, L, d_s);
         float *dst = out_dev ? out + (size_t)f0 * half : d_o;
-        hipLaunchKernelGGL(pink_out_kernel, dim3((unsigned)((half + 255) / 256), nf), dim3(256), 0, st, (const double *)x, L,
+        hipLaunchKernelGGL(pink_mean_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, d_s, half, nf);
+        hipLaunchKernelGGL(pink_out_kernel, dim3((unsigned)(((half + 1) / 2 + 255) / 256), nf), dim3(256), 0, st, (const double *)x, L,
                            (const double *)d_s, dst);
         PK_HIP(hipGetLastError());
         if (!out_dev) PK_HIP(hipMemcpyAsync(out + (size_t)f0 * half, d_o, (size_t)nf * half * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -213,6 +307,12 @@ int noise_1f_impl(rip_ctx *ctx, hipStream_t st, int rows, int width, int nframes
 
 void rip_pink_release(rip_ctx *ctx) {
     if (ctx->pink_plan) (void)hipfftDestroy((hipfftHandle)ctx->pink_plan);
+    if (ctx->pink_tab) {
+        pf::Tables *t = (pf::Tables *)ctx->pink_tab;
+        if (t->mem) (void)hipFree(t->mem);
+        delete t;
+        ctx->pink_tab = nullptr;
+    }
     if (ctx->pink_z) (void)hipFree(ctx->pink_z);
     if (ctx->pink_s) (void)hipFree(ctx->pink_s);
     ctx->pink_plan = ctx->pink_z = ctx->pink_s = nullptr;
@@ -246,8 +346,12 @@ extern "C" int rip_synth_frames_ahead(rip_ctx *ctx, int rows, int width, int nfr
     float *made = (float *)rip_ws(ctx, 12, (size_t)nframes * rows * width * sizeof(float));
     if (!made) return RIP_ENOMEM;
     if (!ctx->ev_frames) RIP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_frames, hipEventDisableTiming));
-    // behind the previous exposure's fill kernels (they read the frames this call overwrites)
-    if (ctx->ev_fill_valid) RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fill, 0));
+    // behind what the main stream holds at the time of the call: the previous exposure's fill kernels (they read the frames this
+    // call overwrites), and whatever the caller wants out of the way first -- the transforms take HBM bandwidth from a
+    // bandwidth-bound neighbour (rip_synth_apportion beside rocFFT's transposes: 2.7 -> 9.3 ms), not from rip_synth_resultants
+    if (!ctx->ev_ahead) RIP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ahead, hipEventDisableTiming));
+    RIP_HIP(ctx, hipEventRecord(ctx->ev_ahead, ctx->stream));
+    RIP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_ahead, 0));
     const int rc = noise_1f_impl(ctx, ctx->stream2, rows, width, nframes, nullptr, seed, 0x31660000u, made, true);
     if (rc) return rc;
     RIP_HIP(ctx, hipEventRecord(ctx->ev_frames, ctx->stream2));

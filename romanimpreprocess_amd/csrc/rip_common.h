@@ -155,7 +155,9 @@ struct rip_ctx {
     void *batch_buf[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t batch_bytes[4] = {0, 0, 0, 0};
     // 1/f frames (pink.hip): transform plan and buffers of the last (length, batch) kept between calls
-    void *pink_plan = nullptr, *pink_z = nullptr, *pink_s = nullptr;
+    void *pink_plan = nullptr, *pink_z = nullptr, *pink_s = nullptr, *pink_tab = nullptr;   // (library plan OR own tables: pink_own)
+    bool pink_own = false;
+    int pink_form = -1;   // option "pink_form": 0 = the library's transform for every frame length
     hipEvent_t ev_pink = nullptr;   // end of the last 1/f call, on pink_stream: the next call on the OTHER stream waits for it
     hipStream_t pink_stream = nullptr;
     bool ev_pink_valid = false;
@@ -171,7 +173,7 @@ struct rip_ctx {
     int ncu = 0;
     // 1/f frames made AHEAD on the second stream (rip_synth_frames_ahead, pink.hip) for the next rip_synth_fill: the transforms
     // (HBM-bound) then run beside the apportioning and the inverse-linearity kernels (arithmetic-bound) of the same exposure
-    hipEvent_t ev_frames = nullptr, ev_fill = nullptr;
+    hipEvent_t ev_frames = nullptr, ev_fill = nullptr, ev_ahead = nullptr;
     bool frames_pending = false, ev_fill_valid = false;
     uint64_t frames_seed = 0;
     int frames_geom[3] = {0, 0, 0};   // rows, channel width, frames

@@ -189,10 +189,11 @@ class L1Synth:
     def make(self, counts, seed, poisson=False, banding=True):
         """One exposure: (cube (ngrp, ny, nx), amp33 (ngrp, ny, cw)) int16 device tensors holding the u16 bits."""
         torch = self.torch
-        if banding:   # the 1/f frames of this exposure's fill: started now on the second stream, beside the kernels below
+        reads_e = self.apportion(counts, seed, poisson)
+        if banding:   # the 1/f frames of this exposure's fill: on the second stream beside the resultants (f64 arithmetic), behind
+            # the apportioning (bound by HBM like the transforms)
             self.ctx.check(self.ctx.lib.rip_synth_frames_ahead(self.ctx.h, self.ny, self.cw, self.ngrp * (self.nx // self.cw + 2),
                                                                int(seed)))
-        reads_e = self.apportion(counts, seed, poisson)
         cube = self.resultants(reads_e, seed)["cube"]
         amp33 = torch.zeros((self.ngrp, self.ny, self.cw), dtype=torch.int16, device=self.dev)
         torch.cuda.current_stream(self.dev).synchronize()   # torch's zero fill runs on torch's stream, the kernels below on the context's

@@ -215,6 +215,25 @@ def test_device_poisson_deviates():
             assert abs(p0 - np.exp(-lam)) < 5 * np.sqrt(np.exp(-lam) / n) + 1e-4
 
 
+@pytest.mark.parametrize("rows,width,form", [(60, 128, -1), (5, 7, -1), (64, 128, 0), (64, 64, -1), (16, 8, -1), (8, 8, -1), (8192, 128, -1)])
+def test_1f_frames_of_other_lengths_against_numpy_fft(rows, width, form):
+    """Frame lengths that are no power of two (and, option pink_form = 0, any length) go through the library's transform, powers
+    of two from 2^7 points through the hand-written one (pink_fft.h: 8 x 8 up to 1024 x 1024, odd and even log2); a frame of
+    2^6 points is below it.  Odd frame sizes take the unpaired stores of the last kernel."""
+    ctx = gpu_context()
+    rng = np.random.default_rng(5)
+    normals = rng.standard_normal((3, 4 * rows * width))
+    ctx.set_option("pink_form", form)
+    try:
+        got = gen_noise_image.noise_1f_frames(3, rows=rows, width=width, normals=normals, ctx=ctx)
+    finally:
+        ctx.set_option("pink_form", -1)
+    for f in range(3):
+        want = onoise.noise_1f_frame(normals[f], rows, width)
+        np.testing.assert_allclose(got[f], want, rtol=0, atol=2e-6 * np.abs(want).max())
+        assert np.mean(got[f] != want) < 0.01
+
+
 @pytest.mark.parametrize("rows,width", [(64, 128), (4096, 128)])
 def test_1f_frames_against_numpy_fft(rows, width):
     rng = np.random.default_rng(23)

@@ -308,3 +308,25 @@ def test_one_over_f_calls_on_both_streams_do_not_share_scratch_unordered():
         got_exp = exposure(22, both)
         assert np.array_equal(holder["f"].cpu().numpy().view(np.uint32), want_frames.view(np.uint32))
         assert np.array_equal(got_exp[0], want_exp[0]) and np.array_equal(got_exp[1], want_exp[1])
+
+
+def test_one_over_f_frames_do_not_depend_on_the_transform_batch():
+    """More frames than one transform buffer holds (64 of 2^20 points) are transformed in EQUAL chunks (70 -> 2 x 35, a full
+    4096-wide exposure's 272 -> 5 x 55); the device generator's streams stay laid out in blocks of 64 frames: frame 64 + k of a
+    long call with stream id s is frame k of a call with stream id s + 64, whatever the chunking."""
+    ctx = _native.default_context(0)
+    dev = torch.device("cuda", ctx.device)
+    rows, width = 4096, 128
+
+    def frames(n, sid):
+        out = torch.empty((n, rows, width), dtype=torch.float32, device=dev)
+        ctx.check(ctx.lib.rip_synth_noise_1f(ctx.h, rows, width, n, 31, sid, out.data_ptr()))
+        ctx.synchronize()
+        return out
+
+    long = frames(70, 7)
+    head, tail = frames(3, 7), frames(6, 7 + 64)
+    assert torch.equal(long[:3], head)
+    assert torch.equal(long[64:], tail)
+    assert not torch.equal(long[0], long[64])
+    assert abs(float(long.double().std()) / float(head.double().std()) - 1.0) < 0.05

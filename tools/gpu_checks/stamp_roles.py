@@ -1,5 +1,5 @@
 """Diagnostic: cycles per row step of every role of the wave-specialised fused kernel (needs libromanhip_stamp.so built with
--DCH_STAMP: bash tools/gpu_checks/build_flags_variant.sh stamp -DCH_STAMP).  NGROUPS=16 / IPC64=1 select the variant."""
+-DCH_STAMP: bash tools/gpu_checks/build_flags_variant.sh stamp -DRIP_TIMING_BUILD -DCH_STAMP; ROMANHIP_ALLOW_TIMING_BUILD=1).  NGROUPS=16 / IPC64=1 select the variant."""
 import ctypes as C
 import os
 import sys
@@ -51,10 +51,12 @@ def call():
 
 
 split = SPLIT and (NG == 16 or KDT is np.float64)
-nw = 16 if split else 8
 two_per_cu = (NG == 8 and KDT is np.float32)
-nwg = 510 if two_per_cu else 255
-steps = (4096 + (nwg // 17) - 1) // (nwg // 17) + 6
+# waves per workgroup: 256-column form 8; the wide ring-dropping forms 12 (384 columns), f64 ipc4d x 16 groups 8 (256 columns)
+nw = 16 if split else (8 if two_per_cu or (NG == 16 and KDT is np.float64) else 12)
+nstrips = 17 if nw == 8 else 11
+nwg = 504 if two_per_cu else (256 // nstrips) * nstrips
+steps = (4096 + (nwg // nstrips) - 1) // (nwg // nstrips) + 6
 roles = ["ingest-lo", "ingest-hi", "fit-lo", "fit-hi"] if split else ["ingest", "fit"]
 lab_i = ["-", "-", "A (S1)", "barrier 1", "-", "C + loads (S2)", "-", "barrier 2", "-"]
 lab_f = ["issue loads", "-", "O2 + F first half (S1)", "barrier 1", "-", "F second half + T (S2)", "ring reads", "barrier 2", "-"]
@@ -71,9 +73,10 @@ for mask in [int(x) for x in sys.argv[1:]] or [0]:
     print(f"form {cb.ctx.lib.rip_last_chain_form(cb.ctx.h)} dbg={mask} groups={NG} split={split}: cycles per row step and wave ({steps} steps, {nwg} workgroups)")
     for ri, name in enumerate(roles):
         acc = [0.0] * 9
-        for w in range(4 * ri, 4 * ri + 4):
+        wr = nw // len(roles)
+        for w in range(wr * ri, wr * ri + wr):
             for i in range(9):
                 acc[i] += out[w * 9 + i]
-        per = [a / n / nwg / 4 / steps for a in acc]
+        per = [a / n / nwg / wr / steps for a in acc]
         lab = lab_i if name.startswith("ingest") else lab_f
         print(f"  {name:10s} total {sum(per):7.0f} | " + " | ".join(f"{lab[i]} {per[i]:.0f}" for i in range(9) if lab[i] != "-"))
