@@ -44,30 +44,42 @@ __global__ __launch_bounds__(256) void pink_amp_kernel(double *__restrict__ amp,
     amp[k] = (k == 0) ? 0.0 : pow(1.0e-99 + fabs(freq * (double)L), -0.5);
 }
 
-// the deviate pair (n_k, n_{L+k}) of frame f times the amplitude a_k: from the caller's array or from the device generator
-__device__ __forceinline__ void pink_term(const double *__restrict__ normals, const double *__restrict__ amps, size_t L, int f, size_t k,
-                                          uint64_t seed, uint32_t stream_id, double &re, double &im) {
-    double a, b;
+// z_j and z_{L-j} of frame f, j <= L/2: the deviate pairs (n_k, n_{L+k}) times the amplitude a_k, from the caller's array or from
+// the device generator -- ONE Philox block per pair of terms (every user of z_j uses z_{L-j} too): words 0, 1 make z_j, words 2, 3
+// z_{L-j}, each by Box-Muller on a 40-bit and a 24-bit uniform deviate with the logarithm and the circular functions in f32 (as
+// every other device deviate of the library, rip_rng.h: the frames are f32, the deviates need no more -- the f64 versions and a
+// block per term were two thirds of the generator's instructions, which run beside rip_synth_resultants' f64 arithmetic,
+// profiles/r04_summary.md).  j = 0 and j = L/2: the second term is the first one's index (or none): not to be used.
+__device__ __forceinline__ void box_muller_64(uint32_t w0, uint32_t w1, double &a, double &b) {
+    const double u1 = ((double)(((uint64_t)w0 << 8) | (w1 >> 24)) + 0.5) * (1.0 / 1099511627776.0);   // 40 bits, (0, 1)
+    const float u2 = ((float)(w1 & 0xFFFFFFu) + 0.5f) * (1.0f / 16777216.0f);                          // 24 bits, (0, 1)
+    const float r = sqrtf(-2.0f * logf((float)u1));   // ((float)u1 keeps the small values: the tail is the 40-bit one, 7.4 sigma)
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    a = (double)(r * cs);
+    b = (double)(r * sn);
+}
+
+__device__ __forceinline__ void pink_pair(const double *__restrict__ normals, const double *__restrict__ amps, size_t L, int f, size_t j,
+                                          uint64_t seed, uint32_t stream_id, double &re, double &im, double &re2, double &im2) {
+    const size_t j2 = (j == 0) ? 0 : L - j;
+    double a, b, a2, b2;
     if (normals) {
-        a = normals[(size_t)f * 2 * L + k];
-        b = normals[(size_t)f * 2 * L + L + k];
+        a = normals[(size_t)f * 2 * L + j];
+        b = normals[(size_t)f * 2 * L + L + j];
+        a2 = normals[(size_t)f * 2 * L + j2];
+        b2 = normals[(size_t)f * 2 * L + L + j2];
     } else {
-        uint32_t c[4] = {(uint32_t)k, (uint32_t)(k >> 32) ^ (uint32_t)f, stream_id, 0x70696e6bu};
+        uint32_t c[4] = {(uint32_t)j, (uint32_t)(j >> 32) ^ (uint32_t)f, stream_id, 0x70696e6bu};
         philox10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        // Box-Muller on a 53-bit and a 32-bit uniform deviate, the logarithm and the circular functions in f32 (as every other
-        // device deviate of the library, rip_rng.h): the frames are f32, the deviates need no more -- and the f64 versions were
-        // half of the generator's instructions, which run beside rip_synth_resultants' f64 arithmetic (profiles/r04_summary.md)
-        const double u1 = ((double)(((uint64_t)c[0] << 21) | (c[1] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);   // 53 bits, (0, 1)
-        const float u2 = ((float)(c[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);                                      // 24 bits, (0, 1)
-        const float r = sqrtf(-2.0f * logf((float)u1));   // ((float)u1 keeps the small values: the tail is the 53-bit one)
-        float sn, cs;
-        sincospif(2.0f * u2, &sn, &cs);
-        a = (double)(r * cs);
-        b = (double)(r * sn);
+        box_muller_64(c[0], c[1], a, b);
+        box_muller_64(c[2], c[3], a2, b2);
     }
-    const double amp = amps[k];
+    const double amp = amps[j], amp2 = amps[j2];
     re = a * amp;
     im = b * amp;
+    re2 = a2 * amp2;
+    im2 = b2 * amp2;
 }
 
 // folded coefficients S[f*(L/2+1) + j], j = 0 .. L/2, of the complex-to-real transform (see the head of the file): S_0 = Re z_0,
@@ -83,15 +95,13 @@ __global__ __launch_bounds__(256) void pink_fill_kernel(const double *__restrict
     // get when they are made in blocks of f_block, whatever the batch of the transform is; the caller's deviates are indexed by f
     const int fg = normals ? f : (f_first + f) % f_block;
     stream_id += (uint32_t)((f_first + f) - (f_first + f) % f_block);
-    double re, im;
-    pink_term(normals, amps, L, fg, j, seed, stream_id, re, im);
+    double re, im, re2, im2;
+    pink_pair(normals, amps, L, fg, j, seed, stream_id, re, im, re2, im2);
     hipfftDoubleComplex v;
     if (j == 0 || j == half) {
         v.x = re;
         v.y = 0.0;
     } else {
-        double re2, im2;
-        pink_term(normals, amps, L, fg, L - j, seed, stream_id, re2, im2);
         v.x = (re + re2) * 0.5;
         v.y = -(im - im2) * 0.5;
     }
@@ -114,21 +124,20 @@ __global__ __launch_bounds__(256) void pink_fill_w_kernel(const double *__restri
     double2 *Wf = W + (size_t)f * N;
     double ra, ia, rb, ib;
     if (j == 0) {
-        pink_term(normals, amps, L, fg, 0, seed, stream_id, ra, ia);
-        pink_term(normals, amps, L, fg, N, seed, stream_id, rb, ib);
-        Wf[0] = make_double2(ra + rb, ra - rb);
+        double r0, rn, unused[3];
+        pink_pair(normals, amps, L, fg, 0, seed, stream_id, r0, ia, unused[0], unused[1]);
+        pink_pair(normals, amps, L, fg, N, seed, stream_id, rn, ib, unused[0], unused[2]);
+        Wf[0] = make_double2(r0 + rn, r0 - rn);
         return;
     }
-    pink_term(normals, amps, L, fg, j, seed, stream_id, ra, ia);
-    pink_term(normals, amps, L, fg, L - j, seed, stream_id, rb, ib);
+    pink_pair(normals, amps, L, fg, j, seed, stream_id, ra, ia, rb, ib);
     const double2 sj = make_double2((ra + rb) * 0.5, -(ia - ib) * 0.5);
     const size_t m = N - j;
     if (m == j) {
         Wf[j] = make_double2(2.0 * sj.x, -2.0 * sj.y);
         return;
     }
-    pink_term(normals, amps, L, fg, m, seed, stream_id, ra, ia);
-    pink_term(normals, amps, L, fg, L - m, seed, stream_id, rb, ib);
+    pink_pair(normals, amps, L, fg, m, seed, stream_id, ra, ia, rb, ib);
     const double2 sm = make_double2((ra + rb) * 0.5, -(ia - ib) * 0.5);
     const double2 E = make_double2(sj.x + sm.x, sj.y - sm.y), D = make_double2(sj.x - sm.x, sj.y + sm.y);
     double ws, wc;
