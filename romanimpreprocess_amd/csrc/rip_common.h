@@ -139,10 +139,10 @@ struct rip_ctx {
     double guard_band = 1e-5;  // relative half-width of the exact-order re-evaluation band of the jump test (rip_set_option_f64)
     bool prof = false;
     std::vector<hipEvent_t> prof_events;  // 6 per rip_calibrate call
-    void *ws[16] = {};          // 0-9: calibration path and stage entries; 10-12: Level-1 synthesis (synth.hip); 13: the multi-launch
+    void *ws[18] = {};          // 0-9: calibration path and stage entries; 10-12: Level-1 synthesis (synth.hip); 13: the multi-launch
                                 // pre-pass's selection histograms (zero between calls); 14: control words + histograms of the
-                                // single-launch pre-pass (zero between calls), 15: its row / channel scratch
-    size_t ws_bytes[16] = {};
+                                // single-launch pre-pass (zero between calls), 15: its row / channel scratch; 16: the apportioning's list of deferred pixels
+    size_t ws_bytes[18] = {};
     void *prepass_stamps = nullptr;   // diagnostic: device buffer of 16 clock stamps per workgroup of the single-launch pre-pass
     bool chain_quad = true;     // a last strip of <= 64 live columns in quad mode (chain2_geometry); false: every strip alike (A/B timing)
     int chain_reserve = 8;      // workgroup slots the 256-column fused kernel leaves free (the next ramp's pre-pass runs in them)

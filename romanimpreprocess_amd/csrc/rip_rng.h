@@ -128,6 +128,53 @@ __device__ inline double poisson_pre(double lam, double slam, double loglam, uin
     return floor(lam + 0.5);   // not reached in practice
 }
 
+// Poisson deviates of ONE mean lam >= 10 drawn many times (the apportioning: the reads of one share of a pixel): the constants of
+// the transformed rejection once (PtrsPlan), and the acceptance test outside the squeeze -- which some lane of a wave needs on
+// almost every draw, so every wave pays for it -- first in f32 in a form without the large cancelling terms:
+//     -lam + k log lam - log k!  =  d - k log1p(d / lam) - log(2 pi k) / 2 - 1/(12 k) + 1/(360 k^3) - ...,   d = k - lam
+// (Stirling; |d| is a few sqrt(lam), so the f32 error is ~4e-7 |d|, not 1e-7 k log lam), decided when the two sides differ by more
+// than eps = 2e-6 + 1e-6 |d| and re-done in f64 otherwise (a few draws in 10^5: the distribution is that of the f64 test).
+struct PtrsPlan {
+    double lam, loglam, bb, aa, inv_alpha, vr;
+    float bb32, aa32, ia32, inv_lam32;
+};
+
+__device__ __forceinline__ PtrsPlan ptrs_plan(double lam, double slam, double loglam) {
+    PtrsPlan p;
+    p.lam = lam, p.loglam = loglam;
+    p.bb = 0.931 + 2.53 * slam;
+    p.aa = -0.059 + 0.02483 * p.bb;
+    p.inv_alpha = 1.1239 + 1.1328 / (p.bb - 3.4);
+    p.vr = 0.9277 - 3.6224 / (p.bb - 2.0);
+    p.bb32 = (float)p.bb, p.aa32 = (float)p.aa, p.ia32 = (float)p.inv_alpha, p.inv_lam32 = (float)(1.0 / lam);
+    return p;
+}
+
+__device__ inline double poisson_ptrs(const PtrsPlan &p, uint64_t seed, uint32_t a, uint32_t b, uint32_t tag) {
+    for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+        uint32_t c[4] = {a, b, tag ^ (attempt << 24), 0x70747232u};
+        philox(c, seed);
+        const double u = u53(c[0], c[1]) - 0.5, v = u53(c[2], c[3]);
+        const double us = 0.5 - fabs(u);
+        double r = __builtin_amdgcn_rcp(us);   // 1 / us: hardware reciprocal + one Newton step (us >= 2^-54)
+        r = __builtin_fma(__builtin_fma(-us, r, 1.0), r, r);
+        const double k = floor((2.0 * p.aa * r + p.bb) * u + p.lam + 0.43);
+        if (us >= 0.07 && v <= p.vr) return k;
+        if (k < 0.0 || (us < 0.013 && v > us)) continue;
+        if (k >= 16.0 && k < 8.0e6) {
+            const float kf = (float)k, d = (float)(k - p.lam), r32 = (float)r;
+            const float lhs = logf((float)v * p.ia32 * __builtin_amdgcn_rcpf(p.aa32 * (r32 * r32) + p.bb32));
+            const float ik = __builtin_amdgcn_rcpf(kf);
+            const float rhs = d - kf * log1pf(d * p.inv_lam32) - 0.5f * logf(6.2831853f * kf) - ik * (1.0f / 12.0f - ik * ik * (1.0f / 360.0f));
+            const float eps = 2.0e-6f + 1.0e-6f * fabsf(d);
+            if (rhs - lhs > eps) return k;
+            if (rhs - lhs < -eps) continue;
+        }
+        if (log(v * p.inv_alpha / (p.aa * (r * r) + p.bb)) <= -p.lam + k * p.loglam - log_factorial(k)) return k;
+    }
+    return floor(p.lam + 0.5);   // not reached in practice
+}
+
 // Binomial(n, p) deviate: inversion (sequential search) where n min(p, 1-p) < 10, else W. Hoermann's transformed rejection
 // with squeeze (BTRS, "The generation of binomial random variates", 1993); the acceptance test compares with the exact ratio
 // of probabilities through lgamma.

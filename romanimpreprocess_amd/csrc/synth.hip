@@ -30,58 +30,77 @@ struct ShareTable {
     double lw[MAX_READS];
 };
 
+// Poisson increments of one pixel (see apportion_kernel)
+__device__ __forceinline__ void apportion_poisson_pixel(size_t i, double c, size_t npix, int nreads, const double *__restrict__ share,
+                                                        uint64_t seed, int32_t *__restrict__ out) {
+    const double sc = sqrt(c), lc = (c > 0.0) ? log(c) : 0.0;
+    const double *w = share + MAX_READS, *sw = share + 2 * MAX_READS, *lw = share + 3 * MAX_READS;
+    double got_d = 0.0;
+    double w_prev = -1.0, lam = 0.0;
+    float lam32 = 0.0f, p032 = 0.0f;
+    bool small = false;
+    riprng::PtrsPlan plan{};
+    for (int r0 = 0; r0 < nreads; r0 += 4) {
+        uint32_t cw_[4] = {(uint32_t)i, (uint32_t)r0, TAG_TOTAL, 0x706f6934u};
+        riprng::philox(cw_, seed);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + q;
+            if (r >= nreads) break;
+            if (fabs(w[r] - w_prev) > 1e-12 * w_prev) {
+                w_prev = w[r];
+                lam = c * w[r];
+                small = lam > 0.0 && lam < 10.0;
+                lam32 = (float)lam;
+                p032 = small ? __expf(-lam32) : 0.0f;
+                if (!small && lam > 0.0) plan = riprng::ptrs_plan(lam, sc * sw[r], lc + lw[r]);
+            }
+            double k = 0.0;
+            if (small) {
+                const float u = (float)(cw_[q] >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // in (0, 1), never 1
+                float p_ = p032, cdf = p_;
+                int kk = 0;
+                while (u > cdf && p_ > 1e-12f && kk < 200) {   // (p below 1e-12: the sum cannot grow any more)
+                    ++kk;
+                    p_ *= lam32 * __builtin_amdgcn_rcpf((float)kk);
+                    cdf += p_;
+                }
+                k = (double)kk;
+            } else if (lam > 0.0) {
+                k = riprng::poisson_ptrs(plan, seed, (uint32_t)i, (uint32_t)r, TAG_TOTAL);
+            }
+            got_d += k;
+            out[(size_t)r * npix + i] = (int)(got_d > 2.0e9 ? 2.0e9 : got_d);
+        }
+    }
+}
+
+// `defer` (Poisson only): pixels whose largest mean per read reaches defer_lam are not done here but appended to the list
+// defer[1 ..] (count in defer[0]) for apportion_deferred_kernel.  A frame's bright and hot pixels are few (2 % of the bench scene)
+// and scattered: half of the waves hold one, and a wave takes as long as its slowest lane -- twenty steps of the sequential
+// search, or the transformed rejection, where the sky's lanes need three (6.2 -> 3 ms per 4096^2 frame of 35 reads).  The
+// deviates are functions of (seed, pixel, read): the same electrons whichever kernel draws them.
 __global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict__ counts, size_t npix, int poisson, int nreads,
-                                                        const double *__restrict__ share, uint64_t seed, int32_t *__restrict__ out) {
+                                                        const double *__restrict__ share, uint64_t seed, int32_t *__restrict__ out,
+                                                        uint32_t *__restrict__ defer, double defer_lam, double w_max) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= npix) return;
     double c = (double)counts[i];
     if (poisson) {
         // A Poisson total split multinomially over the reads IS a set of independent Poisson increments of mean counts * share:
         // same joint distribution as drawing the total first and then the binomial shares (romanisim's order), one cheap deviate
-        // per read instead of an expensive one (the binomial's acceptance test costs four log-gammas)
-        c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);
-        const double sc = sqrt(c), lc = (c > 0.0) ? log(c) : 0.0;
-        const double *w = share + MAX_READS, *sw = share + 2 * MAX_READS, *lw = share + 3 * MAX_READS;
+        // per read instead of an expensive one (the binomial's acceptance test costs four log-gammas).
         // Means below 10 (a few electrons per read: the sky) by inversion in f32 -- the sequential search for the first k whose
         // cumulative probability passes a 23-bit uniform deviate -- with the exponential once per run of reads of one share (equal read
         // spacings give equal shares up to the rounding of the time differences) and ONE Philox block for four reads; larger means
-        // by the transformed rejection of poisson_pre in f64.  Device deviates are unpinned by nature (tests: mean, variance, P(0)).
-        double got_d = 0.0;
-        double w_prev = -1.0, lam = 0.0;
-        float lam32 = 0.0f, p032 = 0.0f;
-        bool small = false;
-        for (int r0 = 0; r0 < nreads; r0 += 4) {
-            uint32_t cw_[4] = {(uint32_t)i, (uint32_t)r0, TAG_TOTAL, 0x706f6934u};
-            riprng::philox(cw_, seed);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = r0 + q;
-                if (r >= nreads) break;
-                if (fabs(w[r] - w_prev) > 1e-12 * w_prev) {
-                    w_prev = w[r];
-                    lam = c * w[r];
-                    small = lam > 0.0 && lam < 10.0;
-                    lam32 = (float)lam;
-                    p032 = small ? __expf(-lam32) : 0.0f;
-                }
-                double k = 0.0;
-                if (small) {
-                    const float u = (float)(cw_[q] >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // in (0, 1), never 1
-                    float p_ = p032, cdf = p_;
-                    int kk = 0;
-                    while (u > cdf && p_ > 1e-12f && kk < 200) {   // (p below 1e-12: the sum cannot grow any more)
-                        ++kk;
-                        p_ *= lam32 * __builtin_amdgcn_rcpf((float)kk);
-                        cdf += p_;
-                    }
-                    k = (double)kk;
-                } else if (lam > 0.0) {
-                    k = riprng::poisson_pre(lam, sc * sw[r], lc + lw[r], seed, (uint32_t)i, (uint32_t)r, TAG_TOTAL, 0.0, -1.0);
-                }
-                got_d += k;
-                out[(size_t)r * npix + i] = (int)(got_d > 2.0e9 ? 2.0e9 : got_d);
-            }
+        // by transformed rejection, its constants once per run of reads too and its acceptance test in f32 first (riprng::
+        // poisson_ptrs).  Device deviates are unpinned by nature (tests: mean, variance, third moment, histogram, P(0)).
+        c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);
+        if (defer && c * w_max >= defer_lam) {
+            defer[1 + atomicAdd(defer, 1u)] = (uint32_t)i;
+            return;
         }
+        apportion_poisson_pixel(i, c, npix, nreads, share, seed, out);
         return;
     }
     c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);   // np.clip(counts, 0, 2e9).astype(i4)
@@ -91,6 +110,17 @@ __global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict_
         got += riprng::binomial(total - got, share[r], seed, (uint32_t)i, (uint32_t)r, TAG_SHARE);
         out[(size_t)r * npix + i] = got;
     }
+}
+
+__global__ __launch_bounds__(256) void apportion_deferred_kernel(const float *__restrict__ counts, size_t npix, int nreads,
+                                                                 const double *__restrict__ share, uint64_t seed, int32_t *__restrict__ out,
+                                                                 const uint32_t *__restrict__ defer) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= defer[0]) return;
+    const size_t i = defer[1 + t];
+    double c = (double)counts[i];
+    c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);
+    apportion_poisson_pixel(i, c, npix, nreads, share, seed, out);
 }
 
 // numpy: f32 array (op)= array of GT -- computed in promote(f32, GT), stored back as f32
@@ -356,8 +386,21 @@ extern "C" int rip_synth_apportion(rip_ctx *ctx, const float *counts, int nya, i
         RIP_HIP(ctx, hipMemcpy(d_tab, &tab, sizeof(ShareTable), hipMemcpyHostToDevice));
     }
     const size_t npix = (size_t)nya * nxa;
+    // Poisson increments: the pixels with more than 4 electrons per read in a second, dense launch (apportion_kernel's note).  The
+    // list is sized for every pixel; the second launch too (its workgroups beyond the count return at once)
+    uint32_t *defer = nullptr;
+    double w_max = 0.0;
+    if (poisson && npix < 0xFFFFFFFFull) {
+        defer = (uint32_t *)rip_ws(ctx, 16, (npix + 1) * sizeof(uint32_t));
+        if (!defer) return RIP_ENOMEM;
+        RIP_HIP(ctx, hipMemsetAsync(defer, 0, sizeof(uint32_t), ctx->stream));
+        for (int r = 0; r < nreads; ++r) w_max = tab.w[r] > w_max ? tab.w[r] : w_max;
+    }
     hipLaunchKernelGGL(apportion_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, counts, npix, poisson, nreads,
-                       (const double *)d_tab, seed, reads_e);
+                       (const double *)d_tab, seed, reads_e, defer, 4.0, w_max);
+    if (defer)
+        hipLaunchKernelGGL(apportion_deferred_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, counts, npix, nreads,
+                           (const double *)d_tab, seed, reads_e, (const uint32_t *)defer);
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
 }

@@ -134,6 +134,24 @@ def test_apportioning_is_binomial_and_ends_at_the_counts():
         assert np.all(d >= 0) and abs(d[5].mean() - per) < 5 * np.sqrt(per / n) and abs(d[20].var() / per - 1) < 0.08
         assert abs(np.mean(d[11] == 0) - np.exp(-per)) < 5 * np.sqrt(np.exp(-per) * (1 - np.exp(-per)) / n) + 1e-4
         assert abs(np.corrcoef(d[7].ravel(), d[8].ravel())[0, 1]) < 5 / np.sqrt(n)
+    # larger means per read (transformed rejection, its acceptance test in f32 first with an f64 re-test inside the error band):
+    # the histogram of 4 x 10^5 increments against the Poisson probabilities (chi-square), and the third central moment
+    from scipy import stats
+
+    for total in (400.0, 2500.0, 40000.0):
+        e = shares(np.full(na, total, dtype=np.float32), 70 + int(total), True).astype(np.float64)
+        d = np.diff(e, axis=0).ravel()
+        per = total / nr
+        n = d.size
+        assert abs(d.mean() - per) < 5 * np.sqrt(per / n) and abs(d.var() / per - 1) < 0.02
+        assert abs(np.mean((d - per) ** 3) / per - 1) < 12 * np.sqrt(6.0 * per * per * per / n) / per + 0.02   # mu_3 = lam
+        lo, hi = int(stats.poisson.ppf(1e-4, per)), int(stats.poisson.ppf(1 - 1e-4, per))
+        ks = np.arange(lo, hi + 1)
+        obs = np.array([np.sum(d == k) for k in ks], dtype=np.float64)
+        obs = np.concatenate([[np.sum(d < lo)], obs, [np.sum(d > hi)]])
+        exp = n * np.concatenate([[stats.poisson.cdf(lo - 1, per)], stats.poisson.pmf(ks, per), [stats.poisson.sf(hi, per)]])
+        chi2 = np.sum((obs - exp) ** 2 / exp)
+        assert chi2 < stats.chi2.ppf(1 - 1e-6, len(obs) - 1), (total, chi2, len(obs))
     # two seeds differ, one seed repeats
     a, b, c = (shares(lam, sd, True) for sd in (5, 6, 5))
     assert np.array_equal(a, c) and not np.array_equal(a, b)

@@ -38,3 +38,21 @@ for total in (1.0, 35.0, 160.0, 340.0, 360.0, 3500.0, "rate"):
         call()
     ctx.synchronize()
     print(f"mean total {total}: {(time.perf_counter() - t0) * 100:.2f} ms per frame", flush=True)
+
+# the many-realisations harness' own mean counts (BASELINE config 5: scene + dark current of the bench's calibration set)
+from romanimpreprocess_amd import synth_gpu
+cal5 = synth_gpu.make_caldir(ny, nx, read_pattern=rp, p_order=8, seed=1001, ipc_dtype=np.float32, device=0)
+s5 = sim_to_isim.L1Synth(cal5, rp, synth.FRAME_TIME, ctx=ctx)
+per_s = (np.asarray(rate, dtype=np.float64)[4:-4, 4:-4] + cal5["dark"]["dark_slope"][4:-4, 4:-4]) * cal5["gain"]["data"][4:-4, 4:-4]
+cm = np.clip(per_s * s5.t_reads[-1], 0.0, None).astype(np.float32)
+print("harness counts: percentiles 1, 50, 99, 99.9:", np.percentile(cm, [1, 50, 99, 99.9]), "per read / 34")
+c = torch.from_numpy(cm).to(dev)
+torch.cuda.synchronize()
+for _ in range(3):
+    call()
+ctx.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    call()
+ctx.synchronize()
+print(f"harness counts: {(time.perf_counter() - t0) * 100:.2f} ms per frame", flush=True)
