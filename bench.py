@@ -361,11 +361,20 @@ def run_realizations(args, cb, torch, dist, fence, rank, world, local_rank, cdev
     cal = synth_gpu.make_caldir(N, N, read_pattern=rp, p_order=args.p_order, seed=1001,
                                 ipc_dtype=np.float64 if args.ipc_dtype == "f64" else np.float32, device=local_rank)
     cb.load_caldir(0, cal)
-    mr.run(cb, 0, cal, nseeds=max(world, 2), seed0=900, read_pattern=rp, generator="hip")   # warm-up: plans, workspaces, clocks
+    # inputs of the job, resident before the clock starts like the calibration set of the chain: the scene (synthetic, numpy) and
+    # the synthesis side's copy of the calibration arrays
+    from romanimpreprocess_amd.from_sim import sim_to_isim
+
+    scene = synth.make_rate_image(N, N, 100)
+    from romanimpreprocess_amd import _native
+
+    # (a context of its own: the calibration of exposure k runs beside the synthesis of exposure k + 1, many_realizations.run)
+    l1s = sim_to_isim.L1Synth(cal, rp, synth.FRAME_TIME, ctx=_native.Context(cb.ctx.device))
+    mr.run(cb, 0, cal, nseeds=max(world, 2), seed0=900, read_pattern=rp, generator="hip", l1synth=l1s)   # warm-up: plans, workspaces, clocks
     fence()
     tm = {}
     t0 = time.perf_counter()
-    planes = mr.run(cb, 0, cal, nseeds=n, seed0=100, read_pattern=rp, generator="hip", timings=tm)
+    planes = mr.run(cb, 0, cal, nseeds=n, seed0=100, read_pattern=rp, generator="hip", timings=tm, rate=scene, l1synth=l1s)
     fence()
     elapsed, per_rank = gather_elapsed(torch, dist, time.perf_counter() - t0, world, cdev)
     if rank == 0:

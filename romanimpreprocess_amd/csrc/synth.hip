@@ -249,10 +249,23 @@ __global__ __launch_bounds__(256) void resultants_kernel(ResArgs a) {
     }
 }
 
+// zeroes the nb-pixel border of every group's plane (blockIdx.y): one thread per border pixel -- the 2 nb full rows, then the
+// 2 nb edge columns of the other rows
 __global__ __launch_bounds__(256) void zero_border_kernel(uint16_t *cube, int ny, int nx, int nb) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= nx) return;
-    if (y < nb || y >= ny - nb || x < nb || x >= nx - nb) cube[((size_t)blockIdx.z * ny + y) * nx + x] = 0;
+    const int t = blockIdx.x * 256 + threadIdx.x, full = 2 * nb * nx;
+    int x, y;
+    if (t < full) {
+        const int q = t / nx;
+        x = t - q * nx;
+        y = q < nb ? q : ny - 2 * nb + q;
+    } else {
+        const int u = t - full;
+        if (u >= (ny - 2 * nb) * 2 * nb) return;
+        const int j = u % (2 * nb);
+        y = nb + u / (2 * nb);
+        x = j < nb ? j : nx - 2 * nb + j;
+    }
+    cube[((size_t)blockIdx.y * ny + y) * nx + x] = 0;
 }
 
 struct FillArgs {
@@ -453,7 +466,9 @@ extern "C" int rip_synth_resultants(rip_ctx *ctx, const rip_synth_cal *cal, int 
         a.count[j] = group_count[j];
         a.root[j] = std::pow((double)group_count[j], 0.5);   // len(x) ** 0.5
     }
-    if (cube) hipLaunchKernelGGL(zero_border_kernel, dim3((unsigned)((cal->nx + 255) / 256), (unsigned)cal->ny, (unsigned)ngrp), block, 0, ctx->stream, cube, cal->ny, cal->nx, cal->nb);
+    if (cube && cal->nb > 0)
+        hipLaunchKernelGGL(zero_border_kernel, dim3((unsigned)((2 * cal->nb * (cal->nx + cal->ny - 2 * cal->nb) + 255) / 256), (unsigned)ngrp), block, 0,
+                           ctx->stream, cube, cal->ny, cal->nx, cal->nb);
     if (g64 && k64) return launch_resultants<double, double>(ctx, cal->nplanes, a);
     if (g64) return launch_resultants<double, float>(ctx, cal->nplanes, a);
     if (k64) return launch_resultants<float, double>(ctx, cal->nplanes, a);

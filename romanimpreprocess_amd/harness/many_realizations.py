@@ -78,7 +78,7 @@ def ideal_slope(cal, rate, nb=pars.nborder):
 
 
 def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=None, reference_alias=True, generator="host",
-        timings=None):
+        timings=None, rate=None, l1synth=None):
     """Generate and calibrate ``nseeds`` realisations (this rank's share of them), exchange, reduce.  Returns the
     (8, ny, nx) f32 planes as a numpy array on rank 0, None on the other ranks.
 
@@ -87,7 +87,10 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
     "hip" = the reference's own synthesis path on the device (``from_sim.sim_to_isim.L1Synth``: Poisson totals apportioned to
     the reads, ``make_l1_fullcal``, ``fill_in_refdata_and_1f`` as HIP kernels; dq-init and saturation flagging by the
     calibration call itself).
-    ``timings``: optional dict that receives the seconds spent generating, calibrating + stacking, and reducing."""
+    ``timings``: optional dict that receives the seconds spent generating, calibrating + stacking, and reducing.
+    ``rate``: the scene, (ny, nx) DN/s (default: ``synth.make_rate_image(ny, nx, seed0)``, 0.6 s of numpy for a full frame).
+    ``l1synth``: generator "hip" -- a ``sim_to_isim.L1Synth`` of this calibration set and read pattern whose arrays are on the
+    device already (the synthesis side's counterpart of ``calibrator.load_caldir``: 1.5 GB of uploads for a full frame)."""
     import time
 
     import torch
@@ -97,7 +100,8 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
     rp = synth.READ_PATTERN_8 if read_pattern is None else read_pattern
     ny, nx = cal["gain"]["data"].shape
     nb = pars.nborder
-    rate = synth.make_rate_image(ny, nx, seed0)
+    if rate is None:
+        rate = synth.make_rate_image(ny, nx, seed0)
     seeds = sharding.scatter_items([seed0 + 10 * (j + 1) for j in range(nseeds)], device=device)
     pid, _ = calibrator.plan_for(rp, synth.FRAME_TIME)
     # the four stacks (13 B per pixel and realisation: 56 GB for 256 realisations of an SCA) are allocated by a helper thread while
@@ -139,7 +143,7 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
     if generator == "hip":
         from ..from_sim import sim_to_isim
 
-        hip_synth = sim_to_isim.L1Synth(cal, rp, synth.FRAME_TIME, ctx=calibrator.ctx, nb=nb)
+        hip_synth = l1synth or sim_to_isim.L1Synth(cal, rp, synth.FRAME_TIME, ctx=calibrator.ctx, nb=nb)
         act = (slice(nb, ny - nb), slice(nb, nx - nb))
         per_s = (np.asarray(rate, dtype=np.float64)[act] + cal["dark"]["dark_slope"][act]) * cal["gain"]["data"][act]   # e/s
         counts_mean = torch.from_numpy(np.clip(per_s * hip_synth.t_reads[-1], 0.0, None).astype(np.float32)).to(device)
@@ -152,14 +156,20 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
     for k, sd in enumerate(seeds):
         t0 = time.perf_counter()
         if hip_synth is not None:
-            cube, a33 = hip_synth.make(counts_mean, sd, poisson=True)
-            calibrator.synchronize()
+            # The synthesis runs on ITS context's streams, the calibration + stacking of the exposure on the calibrator's: with
+            # two contexts (``l1synth`` made on its own) exposure k is calibrated (HBM-bound kernels, 1.6 ms) beside the inverse
+            # linearity of exposure k+1 (f64 arithmetic); with one context everything is in stream order as before.  The tensors
+            # of exposure k stay referenced until the calibrator has been waited for, an exposure later.
+            cube, a33 = hip_synth.make(counts_mean, sd, poisson=True)   # (returns with the exposure complete)
             t1 = time.perf_counter()
+            calibrator.synchronize()   # calibration + stacking of the exposure before: done beside this make(), or long ago
+            held = (cube, a33)         # noqa: F841 -- replaces (frees) the exposure before
             calibrator.calibrate_device(slot, pid, len(rp), cube.data_ptr(), True, a33.data_ptr(), None, t_pdq_hip.data_ptr(),
                                         slope.data_ptr(), er.data_ptr(), ep.data_ptr(), pdq.data_ptr(), flag_saturation=True,
                                         read_pattern=rp)   # the saturation rule calibrateimage applies (gen_cal_image.py:172-185)
             stacks().push(k, cube, slope, er, ep, pdq)
-            calibrator.synchronize()
+            if hip_synth.ctx is calibrator.ctx or k + 1 == len(seeds):
+                calibrator.synchronize()
             t_gen += t1 - t0
             t_cal += time.perf_counter() - t1
             continue
