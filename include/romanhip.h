@@ -418,6 +418,8 @@ int rip_set_option(rip_ctx *ctx, const char *name, int value);
    "chain_reserve" -- (default 8) workgroup slots the 256-column fused kernel's grid leaves free; "chain_quad" -- (default 1) a
                 last strip of at most 64 live columns is covered by workgroups whose four wave columns take a row range each
                 (4096 x 4096: 504 workgroups of 139 steps instead of 510 of 143; timing-neutral, profiles/r04_summary.md);
+   "pink_form" -- the complex-to-real transform of the 1/f frames: -1 (default) the library's own two-pass transform for
+                power-of-two frame lengths (2^8 .. 2^21 points; csrc/pink_fft.h) and hipFFT otherwise, 0 hipFFT for every length;
    "overlap" -- run the reference-pixel pre-pass of a ramp on a second stream so that it overlaps the previous ramp's
                 fused kernel: -1 (default) by situation -- wherever the fused kernel leaves room on the CUs (every form except the
                 f64-ipc4d one of up to 8 groups, whose partial coefficient ring fills the LDS), 0 never, 1 always. */

@@ -14,7 +14,7 @@
 //                                T: flag propagation, finish (dark rate, error split, flat), stores of pixel (r, c)
 // so each role needs <= 128 VGPRs and a CU holds 2 workgroups = 16 waves = 4 waves/SIMD.  That is the 256-column form (f32 ipc4d
 // with 6 / 8 groups, the bench path); 16 groups and f64 ipc4d, whose rings would leave one such workgroup per CU or none, run the
-// NARROW forms (128-column workgroups that drop rings; see the template below).  Per step:
+// NARROW forms (one wide workgroup per CU that drops rings; see the template below).  Per step:
 //     S1: ingest A(r+3)   | fit O2(r), F(r) up to the half-step barrier (C2_BAR)       -- barrier --
 //     S2: ingest C(r+2)   | fit: the rest of F(r) and T(r), the ring words of row r+1  -- barrier --
 // Everything after O2 is register-only in a fit thread, so the half-step barrier can fall anywhere in it (C2_BAR, chosen per
@@ -29,7 +29,7 @@
 #ifndef C2_COLS_DEF
 #define C2_COLS_DEF 256   // (128-column workgroups WITH every ring: 4 % slower, profiles/r03_summary.md; the narrow forms drop rings)
 #endif
-// columns of a workgroup's window: a constant `COLS` of the enclosing template (256; 128 in the narrow form, see chain2_kernel)
+// columns of a workgroup's window: a constant `COLS` of the enclosing template (c2_cols: 256; 384 / 256 in the ring-dropping forms)
 #define C2_COLS COLS
 #define C2_THREADS (2 * C2_COLS)
 // Diagnostic builds only (RIP_TIMING_BUILD: rip_version() then reports a timing build and the Python binding refuses the library
@@ -242,7 +242,9 @@ constexpr int c2_wps(int G, bool k64, int narrow) {
 
 // NARROW forms (the ring-dropping forms): what does not fit the 256-column form's LDS budget twice per CU drops rings, and what a
 // dropped ring carried the fit role loads itself, one step ahead (a second read of lines the ingest role fetched 1.5 steps earlier):
-//   NARROW = 1  no K ring                              f64 ipc4d x 6 / 8 groups: 43 KB per 128 columns (with every ring: 120 KB per 256)
+//   NARROW = 1  a PARTIAL K ring (what the LDS left   f64 ipc4d x 6 / 8 groups: 43 KB per 128 columns (with every ring: 120 KB per 256);
+//               over holds: c2_krn, KRN below)         at 384 columns 5 (8 groups) / 9 (6 groups) of the nine f64 coefficients travel
+//                                                      through LDS, the fit role reads the others again: traffic 1.33 -> 1.17 x
 //   NARROW = 2  no K ring, no gain / groupdq rings     16 groups: 51 KB per 128 columns; f64 ipc4d x 16 groups: 76 KB
 // Round 3 ran them as 128-column workgroups, three (two) per CU: 3 (2) waves per SIMD at <= 168 (256) VGPRs.  Round 4: ONE
 // workgroup per CU of 384 columns (f64 x 16 groups: 256) -- the same waves per SIMD and LDS per CU, a third (half) of the seams
