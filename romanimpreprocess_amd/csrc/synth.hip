@@ -30,6 +30,10 @@ struct ShareTable {
     double lw[MAX_READS];
 };
 
+constexpr unsigned DEFER_LISTS = 256, DEFER_HEAD = 2 * DEFER_LISTS * 32;
+// capacity of one list: the pixels of the workgroups that feed it
+__host__ __device__ inline size_t defer_cap(size_t npix) { return (((npix + 255) / 256 + DEFER_LISTS - 1) / DEFER_LISTS) * 256; }
+
 // Poisson increments of one pixel (see apportion_kernel)
 __device__ __forceinline__ void apportion_poisson_pixel(size_t i, double c, size_t npix, int nreads, const double *__restrict__ share,
                                                         uint64_t seed, int32_t *__restrict__ out) {
@@ -37,9 +41,17 @@ __device__ __forceinline__ void apportion_poisson_pixel(size_t i, double c, size
     const double *w = share + MAX_READS, *sw = share + 2 * MAX_READS, *lw = share + 3 * MAX_READS;
     double got_d = 0.0;
     double w_prev = -1.0, lam = 0.0;
-    float lam32 = 0.0f, p032 = 0.0f;
+    float lam32 = 0.0f;
     bool small = false;
     riprng::PtrsPlan plan{};
+    // small means: the cumulative probabilities of the first NT counts once per run of reads of one mean (registers), a deviate is
+    // then NT comparisons without a loop -- the sequential search of the same sums (cdf_j = cdf_(j-1) + p_j, p_j = p_(j-1) lam / j,
+    // stopped where p_j <= 1e-12 cannot move the sum any more: those entries are +inf), continued in a loop past the table
+    // (lam < 4 here when the brighter pixels are deferred: one draw in a thousand)
+    constexpr int NT = 12;
+    float cdf_tab[NT], p_end = 0.0f, cdf_end = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cdf_tab[j] = 0.0f;
     for (int r0 = 0; r0 < nreads; r0 += 4) {
         uint32_t cw_[4] = {(uint32_t)i, (uint32_t)r0, TAG_TOTAL, 0x706f6934u};
         riprng::philox(cw_, seed);
@@ -52,18 +64,33 @@ __device__ __forceinline__ void apportion_poisson_pixel(size_t i, double c, size
                 lam = c * w[r];
                 small = lam > 0.0 && lam < 10.0;
                 lam32 = (float)lam;
-                p032 = small ? __expf(-lam32) : 0.0f;
+                if (small) {
+                    float p_ = __expf(-lam32), cdf = p_;
+                    bool live = true;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        live = live && p_ > 1e-12f;
+                        cdf_tab[j] = live ? cdf : __builtin_inff();
+                        p_ *= lam32 * __builtin_amdgcn_rcpf((float)(j + 1));
+                        cdf += p_;
+                    }
+                    p_end = p_, cdf_end = cdf;
+                }
                 if (!small && lam > 0.0) plan = riprng::ptrs_plan(lam, sc * sw[r], lc + lw[r]);
             }
             double k = 0.0;
             if (small) {
                 const float u = (float)(cw_[q] >> 9) * (1.0f / 8388608.0f) + (1.0f / 16777216.0f);   // in (0, 1), never 1
-                float p_ = p032, cdf = p_;
                 int kk = 0;
-                while (u > cdf && p_ > 1e-12f && kk < 200) {   // (p below 1e-12: the sum cannot grow any more)
-                    ++kk;
-                    p_ *= lam32 * __builtin_amdgcn_rcpf((float)kk);
-                    cdf += p_;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) kk += (u > cdf_tab[j]) ? 1 : 0;
+                if (kk == NT) {
+                    float p_ = p_end, cdf = cdf_end;
+                    while (u > cdf && p_ > 1e-12f && kk < 200) {   // (p below 1e-12: the sum cannot grow any more)
+                        ++kk;
+                        p_ *= lam32 * __builtin_amdgcn_rcpf((float)kk);
+                        cdf += p_;
+                    }
                 }
                 k = (double)kk;
             } else if (lam > 0.0) {
@@ -75,8 +102,8 @@ __device__ __forceinline__ void apportion_poisson_pixel(size_t i, double c, size
     }
 }
 
-// `defer` (Poisson only): pixels whose largest mean per read reaches defer_lam are not done here but appended to the list
-// defer[1 ..] (count in defer[0]) for apportion_deferred_kernel.  A frame's bright and hot pixels are few (2 % of the bench scene)
+// `defer` (Poisson only): pixels whose largest mean per read reaches defer_lam are not done here but appended to a list for
+// apportion_deferred_kernel (layout: DEFER_HEAD counter words, then 2 x DEFER_LISTS lists of defer_cap(npix) pixels).  A frame's bright and hot pixels are few (2 % of the bench scene)
 // and scattered: half of the waves hold one, and a wave takes as long as its slowest lane -- twenty steps of the sequential
 // search, or the transformed rejection, where the sky's lanes need three (6.2 -> 3 ms per 4096^2 frame of 35 reads).  The
 // deviates are functions of (seed, pixel, read): the same electrons whichever kernel draws them.
@@ -97,7 +124,16 @@ __global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict_
         // poisson_ptrs).  Device deviates are unpinned by nature (tests: mean, variance, third moment, histogram, P(0)).
         c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);
         if (defer && c * w_max >= defer_lam) {
-            defer[1 + atomicAdd(defer, 1u)] = (uint32_t)i;
+            // two classes of lists -- means below 10 (sequential search) and above (transformed rejection) -- of DEFER_LISTS lists
+            // each, a workgroup's pixels into list blockIdx.x mod DEFER_LISTS: the counters are a cache line apart, and the atomics
+            // have a wave-uniform address (the compiler makes them one per wave).  One counter for the frame serialises: half of
+            // the waves hold a deferred pixel, 130 k atomics on one line took longer than the arithmetic.
+            const size_t cap = defer_cap(npix);
+            const unsigned q = blockIdx.x % DEFER_LISTS;
+            if (c * w_max >= 10.0)
+                defer[DEFER_HEAD + (DEFER_LISTS + q) * cap + atomicAdd(defer + (DEFER_LISTS + q) * 32, 1u)] = (uint32_t)i;
+            else
+                defer[DEFER_HEAD + q * cap + atomicAdd(defer + q * 32, 1u)] = (uint32_t)i;
             return;
         }
         apportion_poisson_pixel(i, c, npix, nreads, share, seed, out);
@@ -112,12 +148,37 @@ __global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict_
     }
 }
 
+// where each of the 2 * DEFER_LISTS lists starts in the concatenation of all of them (class 0 first): defer[l * 32 + 1], the total
+// in defer[2]; one workgroup of 2 * DEFER_LISTS threads
+__global__ __launch_bounds__(2 * DEFER_LISTS) void defer_scan_kernel(uint32_t *__restrict__ defer) {
+    __shared__ uint32_t sh[2 * DEFER_LISTS];
+    const unsigned l = threadIdx.x;
+    const uint32_t mine = defer[l * 32];
+    sh[l] = mine;
+    __syncthreads();
+    for (unsigned d = 1; d < 2 * DEFER_LISTS; d <<= 1) {
+        const uint32_t add = l >= d ? sh[l - d] : 0u;
+        __syncthreads();
+        sh[l] += add;
+        __syncthreads();
+    }
+    defer[l * 32 + 1] = sh[l] - mine;
+    if (l == 2 * DEFER_LISTS - 1) defer[2] = sh[l];
+}
+
+// thread t takes entry t of the concatenated lists: waves are dense whatever the lists hold (a single wave needs 250 us for its 35
+// dependent draws: the launch is bound by waves in flight, not by arithmetic)
 __global__ __launch_bounds__(256) void apportion_deferred_kernel(const float *__restrict__ counts, size_t npix, int nreads,
                                                                  const double *__restrict__ share, uint64_t seed, int32_t *__restrict__ out,
                                                                  const uint32_t *__restrict__ defer) {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= defer[0]) return;
-    const size_t i = defer[1 + t];
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= defer[2]) return;
+    unsigned lo = 0, hi = 2 * DEFER_LISTS;   // the last list whose start is <= t
+    while (hi - lo > 1) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (defer[mid * 32 + 1] <= t) lo = mid; else hi = mid;
+    }
+    const size_t i = defer[DEFER_HEAD + lo * defer_cap(npix) + (t - defer[lo * 32 + 1])];
     double c = (double)counts[i];
     c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);
     apportion_poisson_pixel(i, c, npix, nreads, share, seed, out);
@@ -400,20 +461,22 @@ extern "C" int rip_synth_apportion(rip_ctx *ctx, const float *counts, int nya, i
     }
     const size_t npix = (size_t)nya * nxa;
     // Poisson increments: the pixels with more than 4 electrons per read in a second, dense launch (apportion_kernel's note).  The
-    // list is sized for every pixel; the second launch too (its workgroups beyond the count return at once)
+    // lists are sized for every pixel, the second launch too (its workgroups beyond a list's count return at once)
     uint32_t *defer = nullptr;
     double w_max = 0.0;
     if (poisson && npix < 0xFFFFFFFFull) {
-        defer = (uint32_t *)rip_ws(ctx, 16, (npix + 1) * sizeof(uint32_t));
+        defer = (uint32_t *)rip_ws(ctx, 16, (DEFER_HEAD + 2 * DEFER_LISTS * defer_cap(npix)) * sizeof(uint32_t));
         if (!defer) return RIP_ENOMEM;
-        RIP_HIP(ctx, hipMemsetAsync(defer, 0, sizeof(uint32_t), ctx->stream));
+        RIP_HIP(ctx, hipMemsetAsync(defer, 0, DEFER_HEAD * sizeof(uint32_t), ctx->stream));
         for (int r = 0; r < nreads; ++r) w_max = tab.w[r] > w_max ? tab.w[r] : w_max;
     }
     hipLaunchKernelGGL(apportion_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, counts, npix, poisson, nreads,
                        (const double *)d_tab, seed, reads_e, defer, 4.0, w_max);
-    if (defer)
+    if (defer) {
+        hipLaunchKernelGGL(defer_scan_kernel, dim3(1), dim3(2 * DEFER_LISTS), 0, ctx->stream, defer);
         hipLaunchKernelGGL(apportion_deferred_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, counts, npix, nreads,
                            (const double *)d_tab, seed, reads_e, (const uint32_t *)defer);
+    }
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
 }
