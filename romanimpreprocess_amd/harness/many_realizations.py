@@ -78,7 +78,7 @@ def ideal_slope(cal, rate, nb=pars.nborder):
 
 
 def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=None, reference_alias=True, generator="host",
-        timings=None, rate=None, l1synth=None):
+        timings=None, rate=None, l1synth=None, stack_capacity=None):
     """Generate and calibrate ``nseeds`` realisations (this rank's share of them), exchange, reduce.  Returns the
     (8, ny, nx) f32 planes as a numpy array on rank 0, None on the other ranks.
 
@@ -89,6 +89,9 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
     calibration call itself).
     ``timings``: optional dict that receives the seconds spent generating, calibrating + stacking, and reducing.
     ``rate``: the scene, (ny, nx) DN/s (default: ``synth.make_rate_image(ny, nx, seed0)``, 0.6 s of numpy for a full frame).
+    ``stack_capacity``: allocate the stacks for this many realisations on this rank (at least its share of ``nseeds``): a warm-up
+    run with the capacity of the job that follows leaves the 56 GB with torch's caching allocator, and the job does not wait
+    0.3-1.9 s for the driver to map them.
     ``l1synth``: generator "hip" -- a ``sim_to_isim.L1Synth`` of this calibration set and read pattern whose arrays are on the
     device already (the synthesis side's counterpart of ``calibrator.load_caldir``: 1.5 GB of uploads for a full frame)."""
     import time
@@ -113,7 +116,7 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
 
     def _alloc_stacks():
         try:
-            st_box["st"] = SeedStacks(len(seeds), ny, nx, device, nb=nb, ctx=calibrator.ctx)
+            st_box["st"] = SeedStacks(max(len(seeds), int(stack_capacity or 0)), ny, nx, device, nb=nb, ctx=calibrator.ctx)
         except BaseException as exc:   # re-raised by the main thread
             st_box["exc"] = exc
 
@@ -196,7 +199,7 @@ def run(calibrator, slot, cal, nseeds=256, seed0=100, read_pattern=None, device=
     ideal = torch.from_numpy(ideal_slope(cal, rate, nb)).to(device)
     rows = []
     for stack in (st.diffs, st.images, st.err, st.good):
-        t, y0 = sharding.seeds_to_rows(stack, nseeds)
+        t, y0 = sharding.seeds_to_rows(stack[:len(seeds)], nseeds)
         rows.append(t)
     nrows = rows[0].shape[1]
     planes = reduce_rows(*rows, ideal[y0:y0 + nrows].contiguous(), y0, ny, nb=nb, reference_alias=reference_alias,
