@@ -56,3 +56,19 @@ for _ in range(10):
     call()
 ctx.synchronize()
 print(f"harness counts: {(time.perf_counter() - t0) * 100:.2f} ms per frame", flush=True)
+
+# resultants_kernel on the same two scenes (does a frame's hot pixels cost its waves evaluations?)
+for label, cm_ in (("smooth scene (no dark current, flat gain)", (rate[4:-4, 4:-4] * 1.5 * 106.4).astype(np.float32)), ("harness counts", cm),
+                   ("flat 72 electrons", np.full(na, 72.0, dtype=np.float32))):
+    c = torch.from_numpy(np.ascontiguousarray(cm_)).to(dev)
+    torch.cuda.synchronize()
+    reads_e = s5.apportion(c, 7, poisson=True)
+    ctx.synchronize()
+    for _ in range(2):
+        out_c = s5.resultants(reads_e, 7)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        out_c = s5.resultants(reads_e, 7)
+    ctx.synchronize()
+    print(f"resultants, {label}: {(time.perf_counter() - t0) * 200:.2f} ms per frame", flush=True)
