@@ -34,7 +34,10 @@ constexpr unsigned DEFER_LISTS = 256, DEFER_HEAD = 2 * DEFER_LISTS * 32;
 // capacity of one list: the pixels of the workgroups that feed it
 __host__ __device__ inline size_t defer_cap(size_t npix) { return (((npix + 255) / 256 + DEFER_LISTS - 1) / DEFER_LISTS) * 256; }
 
-// Poisson increments of one pixel (see apportion_kernel)
+// Poisson increments of one pixel (see apportion_kernel).  NT: entries of the table of cumulative probabilities (12 cover a mean of 4
+// -- the first launch -- to one draw in a thousand; 28 for the deferred pixels, which would cover a mean of 10, measured slower:
+// 3.4 against 2.8 ms for a frame at 4.7 electrons per read -- the comparisons cost more than the rare loop)
+template <int NT>
 __device__ __forceinline__ void apportion_poisson_pixel(size_t i, double c, size_t npix, int nreads, const double *__restrict__ share,
                                                         uint64_t seed, int32_t *__restrict__ out) {
     const double sc = sqrt(c), lc = (c > 0.0) ? log(c) : 0.0;
@@ -47,8 +50,6 @@ __device__ __forceinline__ void apportion_poisson_pixel(size_t i, double c, size
     // small means: the cumulative probabilities of the first NT counts once per run of reads of one mean (registers), a deviate is
     // then NT comparisons without a loop -- the sequential search of the same sums (cdf_j = cdf_(j-1) + p_j, p_j = p_(j-1) lam / j,
     // stopped where p_j <= 1e-12 cannot move the sum any more: those entries are +inf), continued in a loop past the table
-    // (lam < 4 here when the brighter pixels are deferred: one draw in a thousand)
-    constexpr int NT = 12;
     float cdf_tab[NT], p_end = 0.0f, cdf_end = 0.0f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) cdf_tab[j] = 0.0f;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict_
                 defer[DEFER_HEAD + q * cap + atomicAdd(defer + q * 32, 1u)] = (uint32_t)i;
             return;
         }
-        apportion_poisson_pixel(i, c, npix, nreads, share, seed, out);
+        apportion_poisson_pixel<12>(i, c, npix, nreads, share, seed, out);
         return;
     }
     c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);   // np.clip(counts, 0, 2e9).astype(i4)
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void apportion_deferred_kernel(const float *__
     const size_t i = defer[DEFER_HEAD + lo * defer_cap(npix) + (t - defer[lo * 32 + 1])];
     double c = (double)counts[i];
     c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);
-    apportion_poisson_pixel(i, c, npix, nreads, share, seed, out);
+    apportion_poisson_pixel<12>(i, c, npix, nreads, share, seed, out);
 }
 
 // numpy: f32 array (op)= array of GT -- computed in promote(f32, GT), stored back as f32
