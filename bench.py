@@ -391,7 +391,9 @@ def run_realizations(args, cb, torch, dist, fence, rank, world, local_rank, cdev
             "ms_per_step": 1e3 * elapsed / n, "elapsed_s_per_rank": per_rank, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"many_realizations: {n} noise seeds of one {N}x{N}x{len(rp)}-group scene, seed j on rank j mod {world}; "
-                                   "stacks (13 B per pixel and realisation) resident in HBM, one all-to-all per stack, planes gathered on rank 0",
+                                   "stacks (13 B per pixel and realisation) resident in HBM, one all-to-all per stack, planes gathered on rank 0; "
+                                   "in place before the clock: the calibration set (the chain's and the synthesis side's device copies), the scene, "
+                                   "and -- through a warm-up of two realisations at the job's stack capacity -- the allocator's memory for the stacks",
                        "sharding": ("RCCL" if args.dist_backend == "nccl" else "gloo (rehearsal)")
                                    + ("; ranks share one GPU (rehearsal, not a scaling measurement)" if args.share_gpu else "")},
             "phases_rank0_s": tm,
