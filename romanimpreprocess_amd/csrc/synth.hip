@@ -37,7 +37,9 @@ __host__ __device__ inline size_t defer_cap(size_t npix) { return (((npix + 255)
 // Poisson increments of one pixel (see apportion_kernel).  NT: entries of the table of cumulative probabilities (12 cover a mean of 4
 // -- the first launch -- to one draw in a thousand; 28 for the deferred pixels, which would cover a mean of 10, measured slower:
 // 3.4 against 2.8 ms for a frame at 4.7 electrons per read -- the comparisons cost more than the rare loop)
-template <int NT>
+// BIG = false: every mean is below 10 (the first launch when the brighter pixels are deferred): no transformed rejection in the code,
+// half the registers
+template <int NT, bool BIG>
 __device__ __forceinline__ void apportion_poisson_pixel(size_t i, double c, size_t npix, int nreads, const double *__restrict__ share,
                                                         uint64_t seed, int32_t *__restrict__ out) {
     const double sc = sqrt(c), lc = (c > 0.0) ? log(c) : 0.0;
@@ -77,7 +79,8 @@ __device__ __forceinline__ void apportion_poisson_pixel(size_t i, double c, size
                     }
                     p_end = p_, cdf_end = cdf;
                 }
-                if (!small && lam > 0.0) plan = riprng::ptrs_plan(lam, sc * sw[r], lc + lw[r]);
+                if constexpr (BIG)
+                    if (!small && lam > 0.0) plan = riprng::ptrs_plan(lam, sc * sw[r], lc + lw[r]);
             }
             double k = 0.0;
             if (small) {
@@ -95,7 +98,7 @@ __device__ __forceinline__ void apportion_poisson_pixel(size_t i, double c, size
                 }
                 k = (double)kk;
             } else if (lam > 0.0) {
-                k = riprng::poisson_ptrs(plan, seed, (uint32_t)i, (uint32_t)r, TAG_TOTAL);
+                if constexpr (BIG) k = riprng::poisson_ptrs(plan, seed, (uint32_t)i, (uint32_t)r, TAG_TOTAL);
             }
             got_d += k;
             out[(size_t)r * npix + i] = (int)(got_d > 2.0e9 ? 2.0e9 : got_d);
@@ -108,13 +111,16 @@ __device__ __forceinline__ void apportion_poisson_pixel(size_t i, double c, size
 // and scattered: half of the waves hold one, and a wave takes as long as its slowest lane -- twenty steps of the sequential
 // search, or the transformed rejection, where the sky's lanes need three (6.2 -> 3 ms per 4096^2 frame of 35 reads).  The
 // deviates are functions of (seed, pixel, read): the same electrons whichever kernel draws them.
-__global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict__ counts, size_t npix, int poisson, int nreads,
+// MODE 0: given totals (binomial shares); 1: Poisson increments, every pixel here; 2: Poisson increments, the brighter pixels deferred
+// (separate instantiations: the rejection sampler's and the binomial's registers halve the occupancy of the sky's straight-line code)
+template <int MODE>
+__global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict__ counts, size_t npix, int nreads,
                                                         const double *__restrict__ share, uint64_t seed, int32_t *__restrict__ out,
                                                         uint32_t *__restrict__ defer, double defer_lam, double w_max) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= npix) return;
     double c = (double)counts[i];
-    if (poisson) {
+    if constexpr (MODE != 0) {
         // A Poisson total split multinomially over the reads IS a set of independent Poisson increments of mean counts * share:
         // same joint distribution as drawing the total first and then the binomial shares (romanisim's order), one cheap deviate
         // per read instead of an expensive one (the binomial's acceptance test costs four log-gammas).
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict_
         // by transformed rejection, its constants once per run of reads too and its acceptance test in f32 first (riprng::
         // poisson_ptrs).  Device deviates are unpinned by nature (tests: mean, variance, third moment, histogram, P(0)).
         c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);
-        if (defer && c * w_max >= defer_lam) {
+        if (MODE == 2 && c * w_max >= defer_lam) {
             // two classes of lists -- means below 10 (sequential search) and above (transformed rejection) -- of DEFER_LISTS lists
             // each, a workgroup's pixels into list blockIdx.x mod DEFER_LISTS: the counters are a cache line apart, and the atomics
             // have a wave-uniform address (the compiler makes them one per wave).  One counter for the frame serialises: half of
@@ -137,15 +143,15 @@ __global__ __launch_bounds__(256) void apportion_kernel(const float *__restrict_
                 defer[DEFER_HEAD + q * cap + atomicAdd(defer + q * 32, 1u)] = (uint32_t)i;
             return;
         }
-        apportion_poisson_pixel<12>(i, c, npix, nreads, share, seed, out);
-        return;
-    }
-    c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);   // np.clip(counts, 0, 2e9).astype(i4)
-    const int total = (int)c;
-    int got = 0;
-    for (int r = 0; r < nreads; ++r) {
-        got += riprng::binomial(total - got, share[r], seed, (uint32_t)i, (uint32_t)r, TAG_SHARE);
-        out[(size_t)r * npix + i] = got;
+        apportion_poisson_pixel<12, MODE == 1>(i, c, npix, nreads, share, seed, out);   // (MODE 2: what is left has fewer than defer_lam <= 10 per read)
+    } else {
+        c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);   // np.clip(counts, 0, 2e9).astype(i4)
+        const int total = (int)c;
+        int got = 0;
+        for (int r = 0; r < nreads; ++r) {
+            got += riprng::binomial(total - got, share[r], seed, (uint32_t)i, (uint32_t)r, TAG_SHARE);
+            out[(size_t)r * npix + i] = got;
+        }
     }
 }
 
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(256) void apportion_deferred_kernel(const float *__
     const size_t i = defer[DEFER_HEAD + lo * defer_cap(npix) + (t - defer[lo * 32 + 1])];
     double c = (double)counts[i];
     c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);
-    apportion_poisson_pixel<12>(i, c, npix, nreads, share, seed, out);
+    apportion_poisson_pixel<12, true>(i, c, npix, nreads, share, seed, out);
 }
 
 // numpy: f32 array (op)= array of GT -- computed in promote(f32, GT), stored back as f32
@@ -471,8 +477,13 @@ extern "C" int rip_synth_apportion(rip_ctx *ctx, const float *counts, int nya, i
         RIP_HIP(ctx, hipMemsetAsync(defer, 0, DEFER_HEAD * sizeof(uint32_t), ctx->stream));
         for (int r = 0; r < nreads; ++r) w_max = tab.w[r] > w_max ? tab.w[r] : w_max;
     }
-    hipLaunchKernelGGL(apportion_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, counts, npix, poisson, nreads,
-                       (const double *)d_tab, seed, reads_e, defer, 4.0, w_max);
+    const dim3 ag((unsigned)((npix + 255) / 256));
+    if (!poisson)
+        hipLaunchKernelGGL(apportion_kernel<0>, ag, dim3(256), 0, ctx->stream, counts, npix, nreads, (const double *)d_tab, seed, reads_e, defer, 4.0, w_max);
+    else if (!defer)
+        hipLaunchKernelGGL(apportion_kernel<1>, ag, dim3(256), 0, ctx->stream, counts, npix, nreads, (const double *)d_tab, seed, reads_e, defer, 4.0, w_max);
+    else
+        hipLaunchKernelGGL(apportion_kernel<2>, ag, dim3(256), 0, ctx->stream, counts, npix, nreads, (const double *)d_tab, seed, reads_e, defer, 4.0, w_max);
     if (defer) {
         hipLaunchKernelGGL(defer_scan_kernel, dim3(1), dim3(2 * DEFER_LISTS), 0, ctx->stream, defer);
         hipLaunchKernelGGL(apportion_deferred_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, counts, npix, nreads,
