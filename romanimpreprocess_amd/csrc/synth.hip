@@ -173,22 +173,26 @@ __global__ __launch_bounds__(2 * DEFER_LISTS) void defer_scan_kernel(uint32_t *_
     if (l == 2 * DEFER_LISTS - 1) defer[2] = sh[l];
 }
 
-// thread t takes entry t of the concatenated lists: waves are dense whatever the lists hold (a single wave needs 250 us for its 35
-// dependent draws: the launch is bound by waves in flight, not by arithmetic)
+// thread t takes entry t of the concatenated lists of class CLS (0: means of 4 .. 10 per read, sequential search only; 1: 10 and
+// more): waves are dense whatever the lists hold (a single wave needs 250 us for its 35 dependent draws: the launch is bound by
+// waves in flight, not by arithmetic -- hence one instantiation per class, each with the registers of its own path only).  The grid
+// strides over the entries (it is sized for a few per cent of the frame, the usual case, in one pass)
+template <int CLS>
 __global__ __launch_bounds__(256) void apportion_deferred_kernel(const float *__restrict__ counts, size_t npix, int nreads,
                                                                  const double *__restrict__ share, uint64_t seed, int32_t *__restrict__ out,
                                                                  const uint32_t *__restrict__ defer) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= defer[2]) return;
-    unsigned lo = 0, hi = 2 * DEFER_LISTS;   // the last list whose start is <= t
-    while (hi - lo > 1) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (defer[mid * 32 + 1] <= t) lo = mid; else hi = mid;
+    const uint32_t first = CLS ? defer[DEFER_LISTS * 32 + 1] : 0u, last = CLS ? defer[2] : defer[DEFER_LISTS * 32 + 1];
+    for (uint32_t t = first + blockIdx.x * 256 + threadIdx.x; t < last; t += gridDim.x * 256) {
+        unsigned lo = CLS ? DEFER_LISTS : 0, hi = CLS ? 2 * DEFER_LISTS : DEFER_LISTS;   // the last list whose start is <= t
+        while (hi - lo > 1) {
+            const unsigned mid = (lo + hi) >> 1;
+            if (defer[mid * 32 + 1] <= t) lo = mid; else hi = mid;
+        }
+        const size_t i = defer[DEFER_HEAD + lo * defer_cap(npix) + (t - defer[lo * 32 + 1])];
+        double c = (double)counts[i];
+        c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);
+        apportion_poisson_pixel<12, CLS == 1>(i, c, npix, nreads, share, seed, out);
     }
-    const size_t i = defer[DEFER_HEAD + lo * defer_cap(npix) + (t - defer[lo * 32 + 1])];
-    double c = (double)counts[i];
-    c = c < 0.0 ? 0.0 : (c > 2.0e9 ? 2.0e9 : c);
-    apportion_poisson_pixel<12, true>(i, c, npix, nreads, share, seed, out);
 }
 
 // numpy: f32 array (op)= array of GT -- computed in promote(f32, GT), stored back as f32
@@ -468,7 +472,7 @@ extern "C" int rip_synth_apportion(rip_ctx *ctx, const float *counts, int nya, i
     }
     const size_t npix = (size_t)nya * nxa;
     // Poisson increments: the pixels with more than 4 electrons per read in a second, dense launch (apportion_kernel's note).  The
-    // lists are sized for every pixel, the second launch too (its workgroups beyond a list's count return at once)
+    // lists are sized for every pixel; the launches that draw them stride over what they hold
     uint32_t *defer = nullptr;
     double w_max = 0.0;
     if (poisson && npix < 0xFFFFFFFFull) {
@@ -486,8 +490,11 @@ extern "C" int rip_synth_apportion(rip_ctx *ctx, const float *counts, int nya, i
         hipLaunchKernelGGL(apportion_kernel<2>, ag, dim3(256), 0, ctx->stream, counts, npix, nreads, (const double *)d_tab, seed, reads_e, defer, 4.0, w_max);
     if (defer) {
         hipLaunchKernelGGL(defer_scan_kernel, dim3(1), dim3(2 * DEFER_LISTS), 0, ctx->stream, defer);
-        hipLaunchKernelGGL(apportion_deferred_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, ctx->stream, counts, npix, nreads,
-                           (const double *)d_tab, seed, reads_e, (const uint32_t *)defer);
+        const dim3 dg((unsigned)std::min<size_t>((npix + 255) / 256, 4096));
+        hipLaunchKernelGGL(apportion_deferred_kernel<0>, dg, dim3(256), 0, ctx->stream, counts, npix, nreads, (const double *)d_tab, seed, reads_e,
+                           (const uint32_t *)defer);
+        hipLaunchKernelGGL(apportion_deferred_kernel<1>, dg, dim3(256), 0, ctx->stream, counts, npix, nreads, (const double *)d_tab, seed, reads_e,
+                           (const uint32_t *)defer);
     }
     RIP_HIP(ctx, hipGetLastError());
     return RIP_OK;
