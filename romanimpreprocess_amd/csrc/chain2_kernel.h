@@ -543,9 +543,10 @@ __global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, siz
             const bool fastdiv = __all(rcp_safe(span));
             const float rspan = rip_rcp_mid(span);  // used only when every lane passes rcp_safe (2^-59.8 .. 2^59.8)
             const double yd = (double)yi;
-            // pairs per block (their recurrences interleave): 2 at 128 registers; the forms with a 256-register budget (16 groups, f64
-            // ipc4d: one workgroup per CU) may take C2_PBW
-            constexpr int PBW = (C2_PBW > 0) ? C2_PBW : ((G > 8 && !K64 && !NARROW) ? 4 : 2);
+            // pairs per block (their recurrences interleave): 2 at 128 registers; per instantiation by same-box A/B at the wide forms
+            // (profiles/r04_ab_runs.txt): 16 groups at 168 registers 1 (1.697 against 1.710 ms; 4 spills: 3.46), f64 ipc4d x 16 groups at
+            // 256 registers 4 (2.24 against 2.27)
+            constexpr int PBW = (C2_PBW > 0) ? C2_PBW : (NARROW == 2 ? (K64 ? 4 : 1) : 2);
             constexpr int PB = ((K64 || G > 8) && GP % PBW == 0) ? PBW : (GP % 2 == 0) ? 2 : 1;
 #pragma unroll
             for (int pb = 0; pb < GP; pb += PB) {
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(2 * c2_cols(sizeof(KT) == 8, NARROW), c2_wps(G, siz
                 if constexpr (K64) {
                     // two pairs (four groups) in lockstep: their 18 ring reads first, then four interleaved f64 chains
                     constexpr bool BIG = !NARROW || (K64 && G > 8);   // 256-register budget (narrow f64 x 8 groups: 168 -- one pair at a time)
-                    constexpr int PBC = (C2_PBC > 0) ? C2_PBC : ((GP % 2 == 0 && BIG) ? 2 : 1);
+                    constexpr int PBC = (C2_PBC > 0) ? C2_PBC : ((GP % 2 == 0 && BIG) ? 2 : 1);   // (f64 x 16 groups with C2_PBW 4: 2.23 / 2.25 ms for 2 / 1)
 #pragma unroll
                     for (int p0 = 0; p0 < GP; p0 += PBC) {
 #pragma unroll
