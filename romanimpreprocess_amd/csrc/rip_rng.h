@@ -37,37 +37,6 @@ __device__ __forceinline__ float normal_f32(uint64_t seed, uint32_t a, uint32_t 
     return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
 }
 
-// Poisson deviate of mean lam: inversion below 10, W. Hoermann's transformed rejection (PTRS, 1993) above
-__device__ inline double poisson(double lam, uint64_t seed, uint32_t a, uint32_t b, uint32_t tag) {
-    if (!(lam > 0.0)) return 0.0;
-    if (lam < 10.0) {
-        uint32_t c[4] = {a, b, tag, 0x706f6932u};
-        philox(c, seed);
-        const double u = u53(c[0], c[1]);
-        double p = exp(-lam), cdf = p;
-        int k = 0;
-        while (u > cdf && k < 200) {
-            ++k;
-            p *= lam / k;
-            cdf += p;
-        }
-        return (double)k;
-    }
-    const double slam = sqrt(lam), loglam = log(lam);
-    const double bb = 0.931 + 2.53 * slam, aa = -0.059 + 0.02483 * bb, inv_alpha = 1.1239 + 1.1328 / (bb - 3.4), vr = 0.9277 - 3.6224 / (bb - 2.0);
-    for (uint32_t attempt = 0; attempt < 64; ++attempt) {
-        uint32_t c[4] = {a, b, tag ^ (attempt << 24), 0x70747232u};
-        philox(c, seed);
-        const double u = u53(c[0], c[1]) - 0.5, v = u53(c[2], c[3]);
-        const double us = 0.5 - fabs(u);
-        const double k = floor((2.0 * aa / us + bb) * u + lam + 0.43);
-        if (us >= 0.07 && v <= vr) return k;
-        if (k < 0.0 || (us < 0.013 && v > us)) continue;
-        if (log(v) + log(inv_alpha) - log(aa / (us * us) + bb) <= -lam + k * loglam - lgamma(k + 1.0)) return k;
-    }
-    return floor(lam + 0.5);   // not reached in practice
-}
-
 // log(k!) for integer-valued k >= 0: exact table below 8, Stirling's series above (truncation < 2e-12 at k + 1 = 9): one logarithm
 // where lgamma costs several
 __device__ __forceinline__ double log_factorial(double k) {
@@ -85,51 +54,8 @@ __device__ __forceinline__ double log_factorial(double k) {
     return (k + 0.5) * log(x) - x + 0.9189385332046727 + corr;
 }
 
-// Poisson deviate of mean lam with sqrt(lam) and log(lam) handed in (the apportioning draws 35 of them per pixel with
-// lam = counts * share: the root and the logarithm of the counts once per pixel, those of the shares once per read pattern).
-// Same algorithm as poisson(); the acceptance test outside the squeeze costs two logarithms (log_factorial, one merged left side)
-// instead of three and a lgamma -- every wave takes that path for some lane on almost every draw.
-// `p0` = exp(-lam) from the caller where lam < 10 (a run of reads with one share has one lam: the exponential, the dearest part of a
-// small-mean deviate, once per pixel instead of once per read); `u` = the uniform deviate for the inversion branch, or a negative
-// number: drawn here from (a, b, tag) -- the caller may hand in the second pair of words of the Philox block of the read before
-__device__ inline double poisson_pre(double lam, double slam, double loglam, uint64_t seed, uint32_t a, uint32_t b, uint32_t tag,
-                                     double p0, double u_in) {
-    if (!(lam > 0.0)) return 0.0;
-    if (lam < 10.0) {
-        double u = u_in;
-        if (u < 0.0) {
-            uint32_t c[4] = {a, b, tag, 0x706f6932u};
-            philox(c, seed);
-            u = u53(c[0], c[1]);
-        }
-        double p = p0, cdf = p;
-        int k = 0;
-        while (u > cdf && k < 200) {   // p_k = p_(k-1) * lam / k through the hardware reciprocal (+ one Newton step): a third of
-            ++k;                       // the instructions of an f64 division, the same probabilities to 1e-16
-            const double kd = (double)k;
-            double rk = __builtin_amdgcn_rcp(kd);
-            rk = __builtin_fma(__builtin_fma(-kd, rk, 1.0), rk, rk);
-            p *= lam * rk;
-            cdf += p;
-        }
-        return (double)k;
-    }
-    const double bb = 0.931 + 2.53 * slam, aa = -0.059 + 0.02483 * bb, inv_alpha = 1.1239 + 1.1328 / (bb - 3.4), vr = 0.9277 - 3.6224 / (bb - 2.0);
-    for (uint32_t attempt = 0; attempt < 64; ++attempt) {
-        uint32_t c[4] = {a, b, tag ^ (attempt << 24), 0x70747232u};
-        philox(c, seed);
-        const double u = u53(c[0], c[1]) - 0.5, v = u53(c[2], c[3]);
-        const double us = 0.5 - fabs(u);
-        const double k = floor((2.0 * aa / us + bb) * u + lam + 0.43);
-        if (us >= 0.07 && v <= vr) return k;
-        if (k < 0.0 || (us < 0.013 && v > us)) continue;
-        if (log(v * inv_alpha / (aa / (us * us) + bb)) <= -lam + k * loglam - log_factorial(k)) return k;
-    }
-    return floor(lam + 0.5);   // not reached in practice
-}
-
-// Poisson deviates of ONE mean lam >= 10 drawn many times (the apportioning: the reads of one share of a pixel): the constants of
-// the transformed rejection once (PtrsPlan), and the acceptance test outside the squeeze -- which some lane of a wave needs on
+// Poisson deviates of ONE mean lam >= 10 drawn many times (the apportioning: the reads of one share of a pixel) by W. Hoermann's
+// transformed rejection (PTRS, 1993): its constants once (PtrsPlan), and the acceptance test outside the squeeze -- which some lane of a wave needs on
 // almost every draw, so every wave pays for it -- first in f32 in a form without the large cancelling terms:
 //     -lam + k log lam - log k!  =  d - k log1p(d / lam) - log(2 pi k) / 2 - 1/(12 k) + 1/(360 k^3) - ...,   d = k - lam
 // (Stirling; |d| is a few sqrt(lam), so the f32 error is ~4e-7 |d|, not 1e-7 k log lam), decided when the two sides differ by more
