@@ -303,3 +303,26 @@ def test_injection_and_resampling_against_the_executed_reference_loop(golden):
     ctx.check(ctx.lib.rip_stage_noise_inject(ctx.h, t_cube.data_ptr(), G, 64, 64, nb, t_read.data_ptr(), nreads.ctypes.data,
                                              nrm.ctypes.data, 0, 0, t_cube.data_ptr()))
     assert_same_bits(t_cube.cpu().numpy().view(np.uint16), g["injected_Ra"], "injection in place in HBM")
+
+
+def test_1f_frames_from_both_transforms_agree():
+    """The same device deviates through the hand-written two-pass transform and through hipFFT (option pink_form = 0): frames of
+    2^20 points equal to rounding -- a handful of f32 samples in 10^7 differ by one unit in the last place."""
+    ctx = gpu_context()
+    rows, width, n = 4096, 128, 12
+    dev = torch.device("cuda", ctx.device)
+    outs = []
+    try:
+        for form in (0, -1):
+            ctx.set_option("pink_form", form)
+            out = torch.empty((n, rows, width), dtype=torch.float32, device=dev)
+            ctx.check(ctx.lib.rip_synth_noise_1f(ctx.h, rows, width, n, 123, 9, out.data_ptr()))
+            ctx.synchronize()
+            outs.append(out)
+    finally:
+        ctx.set_option("pink_form", -1)
+    a, b = outs
+    scale = float(a.abs().max())
+    assert float((a - b).abs().max()) <= 4e-7 * scale
+    assert float((a != b).double().mean()) < 1e-4
+    assert 0.5 < float(a.std()) < 50.0 and not torch.equal(a[0], a[1])
