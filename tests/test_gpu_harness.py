@@ -245,3 +245,15 @@ def test_harness_with_the_reference_synthesis_path_on_the_device():
     # a second run gives the same planes: the device generators are keyed by the seeds
     again = mr.run(cb, 0, cal, nseeds=nseeds, seed0=100, read_pattern=rp, device=DEV, reference_alias=False, generator="hip")
     assert np.array_equal(out, again)
+    # the synthesis on a context of its own (exposure k is calibrated and stacked beside the synthesis of exposure k+1), the scene
+    # handed in, the stacks larger than the run needs: the same planes, bit for bit
+    from romanimpreprocess_amd import _native
+    from romanimpreprocess_amd.from_sim import sim_to_isim
+
+    own = _native.Context(cb.ctx.device)
+    l1s = sim_to_isim.L1Synth(cal, rp, synth.FRAME_TIME, ctx=own)
+    piped = mr.run(cb, 0, cal, nseeds=nseeds, seed0=100, read_pattern=rp, device=DEV, reference_alias=False, generator="hip",
+                   l1synth=l1s, rate=synth.make_rate_image(ny, nx, 100), stack_capacity=nseeds + 5)
+    assert np.array_equal(out, piped)
+    del l1s
+    own.close()
