@@ -1,6 +1,6 @@
 // The complex-to-real transform of the 1/f frames (pink.hip) for power-of-two frame lengths, hand-written: two passes over the data
 // where the library's plan for 2^20 points makes seven (a pre-processing kernel, three transposes, two row transforms; 4.0 ms for
-// 64 frames, 3.3 of them in the transposes -- profiles/r04_config5_kernels.txt).
+// 64 frames, 3.3 of them in the transposes -- profiles/r04_config5_kernels_start_of_round.txt: beside the other kernels of a realisation; alone 1.06 ms, r04_pink_form_ab.txt).
 //
 //   x[n], n = 0 .. L-1, real, from the folded coefficients S_0 .. S_N (N = L/2; pink.hip's head):  with y[m] = x[2m] + i x[2m+1]
 //       y[m] = sum_{j<N} W_j e^{+2 pi i j m / N},   W_j = (S_j + conj S_{N-j}) + i w^j (S_j - conj S_{N-j}),  w = e^{2 pi i / L}
