@@ -93,6 +93,18 @@ __device__ inline double poisson_ptrs(const PtrsPlan &p, uint64_t seed, uint32_t
             const float eps = 2.0e-6f + 1.0e-6f * fabsf(d);
             if (rhs - lhs > eps) return true;
             if (rhs - lhs < -eps) return false;
+        } else if (k < 16.0) {   // small counts (means of 10 .. 20): log k! from a table, terms below 50: f32 error below 1e-5
+            const float lf[16] = {0.0f,       0.0f,       0.6931472f, 1.7917595f, 3.1780539f, 4.7874917f, 6.5792513f, 8.5251614f,
+                                  10.604603f, 12.801827f, 15.104413f, 17.502308f, 19.987214f, 22.552164f, 25.191221f, 27.899271f};
+            const int ki = (int)k;
+            float lfk = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) lfk = (ki == j) ? lf[j] : lfk;
+            const float r32 = (float)r;
+            const float lhs = logf((float)v * p.ia32 * __builtin_amdgcn_rcpf(p.aa32 * (r32 * r32) + p.bb32));
+            const float rhs = (float)k * (float)p.loglam - (float)p.lam - lfk;
+            if (rhs - lhs > 3.0e-5f) return true;
+            if (rhs - lhs < -3.0e-5f) return false;
         }
         return log(v * p.inv_alpha / (p.aa * (r * r) + p.bb)) <= -p.lam + k * p.loglam - log_factorial(k);
     };
