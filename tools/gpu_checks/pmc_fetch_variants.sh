@@ -9,8 +9,9 @@ for v in "0 8" "1 8" "0 16" "1 16"; do
   done
 done
 python3 - <<PY
-import csv,glob
-alg={("0","8"):220,("1","8"):256,("0","16"):320,("1","16"):392}
+import csv,glob,sys
+sys.path.insert(0,"$R")
+import bench   # the bench's own algorithmic bytes (an earlier version of this script had its own table: 320 / 392 B per pixel for 16 groups, the bench counts 316 / 352)
 for k in (("0","8"),("1","8"),("0","16"),("1","16")):
     tot={}
     for c in ("FETCH_SIZE","WRITE_SIZE"):
@@ -19,6 +20,6 @@ for k in (("0","8"),("1","8"),("0","16"),("1","16")):
             for r in csv.DictReader(open(f)):
                 if 'chain2' in r['Kernel_Name'] and r['Counter_Name']==c: v.append(float(r['Counter_Value']))
         tot[c]=1024.0*sum(v)/max(len(v),1)
-    t=2*tot["FETCH_SIZE"]+tot["WRITE_SIZE"]; a=alg[k]*4096*4096
+    t=2*tot["FETCH_SIZE"]+tot["WRITE_SIZE"]; a=bench.alg_bytes(int(k[1]),4096,4096,4,9,ipc_size=8 if k[0]=="1" else 4)[1]["chain_fused"]
     print(f"ipc4d {'f64' if k[0]=='1' else 'f32'} x {k[1]:>2} groups: FETCH_SIZE {tot['FETCH_SIZE']/1e9:.3f} GB (x2), WRITE_SIZE {tot['WRITE_SIZE']/1e9:.3f} GB -> traffic {t/1e9:.2f} GB = {t/a:.3f} x the algorithmic {a/1e9:.2f} GB")
 PY
